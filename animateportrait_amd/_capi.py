@@ -1,0 +1,84 @@
+"""ctypes binding of libapamd.so (C ABI declared in include/animateportrait_amd.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails,
+a RuntimeError is raised.  PyTorch is used only for device memory and streams; the
+signatures below carry raw device pointers and sizes.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libapamd.so')
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+PAD_ZERO, PAD_REFLECT = 0, 1
+W_OIHW, W_IOHW = 0, 1
+
+c_f32p = ctypes.c_void_p
+
+
+class ApSrc(ctypes.Structure):
+    _fields_ = [('data', c_f32p), ('mean', c_f32p), ('rstd', c_f32p),
+                ('C', ctypes.c_int32), ('act', ctypes.c_int32)]
+
+
+class ApConvDesc(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int32), ('H', ctypes.c_int32), ('W', ctypes.c_int32),
+                ('Cout', ctypes.c_int32), ('KH', ctypes.c_int32), ('KW', ctypes.c_int32),
+                ('stride', ctypes.c_int32), ('pad', ctypes.c_int32), ('pad_mode', ctypes.c_int32),
+                ('transposed', ctypes.c_int32), ('output_padding', ctypes.c_int32),
+                ('w_layout', ctypes.c_int32), ('w_flip', ctypes.c_int32), ('act', ctypes.c_int32),
+                ('nsrc', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('src', ApSrc * 3)]
+
+
+# name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
+SIGNATURES = {
+    'ap_version': (ctypes.c_char_p, []),
+    'ap_last_error': (ctypes.c_char_p, []),
+    'ap_conv2d_out_size': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ctypes.c_int32),
+                                          ctypes.POINTER(ctypes.c_int32)]),
+    'ap_conv2d_packed_floats': (ctypes.c_int64, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_stat_tiles': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
+    'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_instnorm_finalize': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                            c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
+    'ap_warp_concat_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libapamd.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        'animateportrait_amd: %s not found. Build it with '
+                        '`python -c "import __graft_entry__ as g; g.build()"` or '
+                        '`make -C animateportrait_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
+                l = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(l, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = l
+    return _lib
+
+
+def check(rc, what=''):
+    if rc < 0:
+        msg = lib().ap_last_error()
+        raise RuntimeError('libapamd %s failed (%d): %s' % (what, rc, msg.decode() if msg else '?'))
+    return rc

@@ -1,0 +1,16 @@
+// common.h -- error reporting shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/animateportrait_amd.h"
+
+namespace apamd {
+char* last_error_buf();   // thread-local, 512 bytes
+int fail(int code, const char* fmt, ...);
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return AP_OK;
+}
+}  // namespace apamd

@@ -1,0 +1,379 @@
+// conv_host.hip -- host-side planning and the C ABI of the convolution operator.
+//
+// A descriptor (ap_conv_desc) is turned into one launch (Conv2d) or four launches
+// (ConvTranspose2d stride 2 as sub-pixel phases) of conv_igemm_f32; the same plan drives
+// the weight packer so that the packed image and the kernel always agree.
+#include "common.h"
+#include "conv_registry.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace apamd {
+
+static thread_local char g_err[512];
+char* last_error_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static const std::vector<ConvKernelInfo>& registry() {
+    static std::vector<ConvKernelInfo> v;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        register_s1e1(v);
+        register_s1e2(v);
+        register_s1e3(v);
+        register_s1e6(v);
+        register_s2e2(v);
+        register_s2e3(v);
+    });
+    return v;
+}
+
+static const ConvKernelInfo* find_kernel(int CI, int S, int EXT, int CO_TILE) {
+    for (const auto& k : registry())
+        if (k.CI == CI && k.S == S && k.EXT == EXT && k.CO_TILE == CO_TILE) return &k;
+    return nullptr;
+}
+
+struct Tap { int ky, kx, ly, lx; };  // (ky,kx): index into the caller's weight; (ly,lx): LDS tile offset
+
+struct Launch {
+    std::vector<Tap> taps;
+    int OH, OW, dy0, dx0;
+    int osy, osx, oy_off, ox_off;
+    int tiles_x, tiles_y;
+    long long wp_off;      // float offset of this launch's weights in the packed buffer
+    int stat_tile_off;
+};
+
+struct Plan {
+    const ConvKernelInfo* k = nullptr;
+    std::vector<Launch> launches;
+    int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
+    int chunk_begin[kMaxSeg] = {0, 0, 0};
+    int Hout = 0, Wout = 0, stat_tiles = 0;
+    long long packed_floats = 0;
+};
+
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
+static int make_plan(const ap_conv_desc* d, Plan& pl) {
+    if (!d) return fail(AP_ERR_INVALID, "null descriptor");
+    if (d->nsrc < 1 || d->nsrc > kMaxSeg) return fail(AP_ERR_INVALID, "nsrc=%d out of range", d->nsrc);
+    if (d->N < 1 || d->H < 1 || d->W < 1 || d->Cout < 1) return fail(AP_ERR_INVALID, "bad dims");
+    if (d->KH != d->KW || d->KH < 1 || d->KH > 7) return fail(AP_ERR_UNSUPPORTED, "kernel %dx%d", d->KH, d->KW);
+    const int K = d->KH;
+    int S, EXT;
+    if (!d->transposed) {
+        if (d->stride != 1 && d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "stride %d", d->stride);
+        S = d->stride;
+        EXT = K - 1;
+        pl.Hout = (d->H + 2 * d->pad - K) / S + 1;
+        pl.Wout = (d->W + 2 * d->pad - K) / S + 1;
+        if (d->pad_mode == AP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
+            return fail(AP_ERR_INVALID, "reflection pad %d >= input size", d->pad);
+    } else {
+        if (d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "transposed conv needs stride 2");
+        if (d->pad_mode != AP_PAD_ZERO) return fail(AP_ERR_UNSUPPORTED, "transposed conv with reflection pad");
+        S = 1;
+        EXT = 1;
+        pl.Hout = (d->H - 1) * 2 - 2 * d->pad + K + d->output_padding;
+        pl.Wout = (d->W - 1) * 2 - 2 * d->pad + K + d->output_padding;
+    }
+    if (pl.Hout < 1 || pl.Wout < 1) return fail(AP_ERR_INVALID, "empty output");
+
+    int minC = 1 << 30;
+    pl.Cin = 0;
+    for (int s = 0; s < d->nsrc; ++s) {
+        if (d->src[s].C < 1) return fail(AP_ERR_INVALID, "segment %d has C=%d", s, d->src[s].C);
+        pl.Cin += d->src[s].C;
+        if (d->src[s].C < minC) minC = d->src[s].C;
+    }
+    // tile configuration by output width
+    int co_tile = d->Cout >= 96 ? 128 : (d->Cout >= 48 ? 64 : 32);
+    co_tile = env_int("APAMD_CONV_COTILE", co_tile);
+    // channel chunk: largest of {8,4,2} that does not over-pad the narrowest segment, then shrink
+    // until two workgroups fit a CU's LDS
+    int ci = minC <= 2 ? 2 : (minC <= 4 ? 4 : 8);
+    for (int s = 0; s < d->nsrc; ++s)
+        while (ci > 2 && d->src[s].C % ci != 0 && d->src[s].C > ci) ci >>= 1;
+    int ntaps_max = d->transposed ? ((K + 1) / 2) * ((K + 1) / 2) : K * K;
+    const size_t lds_target = (size_t)env_int("APAMD_CONV_LDS_TARGET", 72 * 1024);
+    for (;;) {
+        const ConvKernelInfo* k = find_kernel(ci, S, EXT, co_tile);
+        if (!k) return fail(AP_ERR_UNSUPPORTED, "no kernel for CI=%d S=%d EXT=%d CO_TILE=%d", ci, S, EXT, co_tile);
+        int nch = 0;
+        for (int s = 0; s < d->nsrc; ++s) nch += (d->src[s].C + ci - 1) / ci;
+        size_t bytes = 4 * k->lds_floats(ntaps_max, nch > 1 ? 2 : 1, nch * ci);
+        if (bytes <= lds_target || ci == 2) {
+            if (bytes > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "LDS tile of %zu bytes does not fit", bytes);
+            pl.k = k;
+            break;
+        }
+        ci >>= 1;
+    }
+    {
+        int forced = env_int("APAMD_CONV_CI", 0);
+        if (forced) {
+            const ConvKernelInfo* k = find_kernel(forced, S, EXT, co_tile);
+            if (k) { pl.k = k; ci = forced; }
+        }
+    }
+    pl.nchunks = 0;
+    for (int s = 0; s < d->nsrc; ++s) {
+        pl.chunk_begin[s] = pl.nchunks;
+        pl.nchunks += (d->src[s].C + ci - 1) / ci;
+    }
+    pl.cin_pad = pl.nchunks * ci;
+    pl.co_tiles = (d->Cout + co_tile - 1) / co_tile;
+
+    auto finish = [&](Launch& L) {
+        L.tiles_x = (L.OW + 31) / 32;
+        L.tiles_y = (L.OH + pl.k->TH - 1) / pl.k->TH;
+        L.wp_off = pl.packed_floats;
+        L.stat_tile_off = pl.stat_tiles;
+        pl.packed_floats += (long long)pl.co_tiles * pl.nchunks * pl.k->wfloats((int)L.taps.size());
+        pl.stat_tiles += L.tiles_x * L.tiles_y;
+    };
+    if (!d->transposed) {
+        Launch L;
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                Tap t;
+                t.ly = ky;
+                t.lx = kx;
+                t.ky = d->w_flip ? K - 1 - ky : ky;
+                t.kx = d->w_flip ? K - 1 - kx : kx;
+                L.taps.push_back(t);
+            }
+        L.OH = pl.Hout; L.OW = pl.Wout;
+        L.dy0 = -d->pad; L.dx0 = -d->pad;
+        L.osy = L.osx = 1; L.oy_off = L.ox_off = 0;
+        finish(L);
+        pl.launches.push_back(L);
+    } else {
+        // y[co, 2q+ph] = sum over taps k with (ph + pad - k) even of x[ci, q + (ph + pad - k)/2] * w[ci,co,k]
+        for (int phy = 0; phy < 2; ++phy)
+            for (int phx = 0; phx < 2; ++phx) {
+                Launch L;
+                L.OH = (pl.Hout - phy + 1) / 2;
+                L.OW = (pl.Wout - phx + 1) / 2;
+                if (L.OH < 1 || L.OW < 1) continue;
+                std::vector<std::pair<int, int>> ys, xs;  // (k, shift)
+                for (int k = 0; k < K; ++k) {
+                    if (((phy + d->pad - k) % 2 + 2) % 2 == 0) ys.push_back({k, (phy + d->pad - k) / 2});
+                    if (((phx + d->pad - k) % 2 + 2) % 2 == 0) xs.push_back({k, (phx + d->pad - k) / 2});
+                }
+                int miny = 1 << 30, minx = 1 << 30, maxy = -(1 << 30), maxx = -(1 << 30);
+                for (auto& a : ys) { miny = std::min(miny, a.second); maxy = std::max(maxy, a.second); }
+                for (auto& a : xs) { minx = std::min(minx, a.second); maxx = std::max(maxx, a.second); }
+                if (ys.empty() || xs.empty() || maxy - miny > 1 || maxx - minx > 1)
+                    return fail(AP_ERR_UNSUPPORTED, "transposed conv k=%d pad=%d not decomposable", K, d->pad);
+                for (auto& a : ys)
+                    for (auto& b : xs) {
+                        Tap t;
+                        t.ky = d->w_flip ? K - 1 - a.first : a.first;
+                        t.kx = d->w_flip ? K - 1 - b.first : b.first;
+                        t.ly = a.second - miny;
+                        t.lx = b.second - minx;
+                        L.taps.push_back(t);
+                    }
+                L.dy0 = miny; L.dx0 = minx;
+                L.osy = L.osx = 2; L.oy_off = phy; L.ox_off = phx;
+                finish(L);
+                pl.launches.push_back(L);
+            }
+    }
+    return AP_OK;
+}
+
+// ------------------------------------------------------------------ weight packer
+struct PackParams {
+    const float* w;
+    float* out;
+    int Cin, Cout, K, layout;
+    int nseg, segC[kMaxSeg], chunk_begin[kMaxSeg];
+    int CI, CO_TILE, nchunks, co_tiles, ntaps, wfloats;
+    int tap_ky[kMaxTaps], tap_kx[kMaxTaps];
+};
+
+__global__ void pack_weights_kernel(const PackParams p) {
+    const long long total = (long long)p.co_tiles * p.nchunks * p.wfloats;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int within = (int)(idx % p.wfloats);
+        const long long blk = idx / p.wfloats;
+        const int chunk = (int)(blk % p.nchunks);
+        const int cot = (int)(blk / p.nchunks);
+        float v = 0.f;
+        if (within < p.ntaps * p.CI * p.CO_TILE) {
+            const int col = within % p.CO_TILE;
+            const int ci = (within / p.CO_TILE) % p.CI;
+            const int t = within / (p.CO_TILE * p.CI);
+            const int co = cot * p.CO_TILE + col;
+            int s = 0;
+            if (p.nseg > 1 && chunk >= p.chunk_begin[1]) s = 1;
+            if (p.nseg > 2 && chunk >= p.chunk_begin[2]) s = 2;
+            const int cs = (chunk - p.chunk_begin[s]) * p.CI + ci;
+            if (cs < p.segC[s] && co < p.Cout) {
+                int cin = cs;
+                for (int j = 0; j < s; ++j) cin += p.segC[j];
+                const int ky = p.tap_ky[t], kx = p.tap_kx[t];
+                const long long off = p.layout == AP_W_OIHW
+                                          ? (((long long)co * p.Cin + cin) * p.K + ky) * p.K + kx
+                                          : (((long long)cin * p.Cout + co) * p.K + ky) * p.K + kx;
+                v = p.w[off];
+            }
+        }
+        p.out[idx] = v;
+    }
+}
+
+static std::mutex g_attr_mu;
+static std::vector<const void*> g_attr_done;
+
+static int ensure_lds_attr(const ConvKernelInfo* k) {
+    std::lock_guard<std::mutex> lk(g_attr_mu);
+    for (auto f : g_attr_done)
+        if (f == k->fn) return AP_OK;
+    hipError_t e = hipFuncSetAttribute(k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    g_attr_done.push_back(k->fn);
+    return AP_OK;
+}
+
+}  // namespace apamd
+
+using namespace apamd;
+
+extern "C" {
+
+const char* ap_version(void) { return "animateportrait_amd 0.1 (gfx950)"; }
+const char* ap_last_error(void) { return last_error_buf(); }
+
+int ap_conv2d_out_size(const ap_conv_desc* d, int32_t* Hout, int32_t* Wout) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (Hout) *Hout = pl.Hout;
+    if (Wout) *Wout = pl.Wout;
+    return AP_OK;
+}
+
+int64_t ap_conv2d_packed_floats(const ap_conv_desc* d) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    return rc ? rc : pl.packed_floats;
+}
+
+int32_t ap_conv2d_stat_tiles(const ap_conv_desc* d) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    return rc ? rc : pl.stat_tiles;
+}
+
+int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (!buf || buflen < 1) return fail(AP_ERR_INVALID, "kernel_name: bad buffer");
+    snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->EXT, pl.k->WCO, pl.k->MT,
+             pl.k->WPX, pl.k->NT);
+    return AP_OK;
+}
+
+int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* packed, ap_stream_t stream) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (!weight || !packed) return fail(AP_ERR_INVALID, "null weight/packed pointer");
+    for (const auto& L : pl.launches) {
+        PackParams p;
+        memset(&p, 0, sizeof(p));
+        p.w = weight;
+        p.out = packed + L.wp_off;
+        p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout;
+        p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
+        p.CI = pl.k->CI; p.CO_TILE = pl.k->CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
+        p.ntaps = (int)L.taps.size();
+        p.wfloats = pl.k->wfloats(p.ntaps);
+        for (int t = 0; t < p.ntaps; ++t) { p.tap_ky[t] = L.taps[t].ky; p.tap_kx[t] = L.taps[t].kx; }
+        const long long total = (long long)p.co_tiles * p.nchunks * p.wfloats;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        rc = check_launch("pack_weights_kernel");
+        if (rc) return rc;
+    }
+    return AP_OK;
+}
+
+int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
+                  float* stat_partials, ap_stream_t stream) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
+    for (int s = 0; s < d->nsrc; ++s) {
+        if (!d->src[s].data) return fail(AP_ERR_INVALID, "segment %d: null data", s);
+        if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
+            return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
+        if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
+    }
+    rc = ensure_lds_attr(pl.k);
+    if (rc) return rc;
+    for (const auto& L : pl.launches) {
+        ConvKParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) {
+            p.seg[s].data = d->src[s].data;
+            p.seg[s].mean = d->src[s].mean;
+            p.seg[s].rstd = d->src[s].rstd;
+            p.seg[s].C = d->src[s].C;
+            p.seg[s].act = d->src[s].act;
+            p.seg[s].chunk_begin = pl.chunk_begin[s];
+        }
+        p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+        p.OH = L.OH; p.OW = L.OW; p.dy0 = L.dy0; p.dx0 = L.dx0;
+        p.pad_mode = d->pad_mode;
+        p.y = y;
+        p.o_nstride = (long long)d->Cout * pl.Hout * pl.Wout;
+        p.o_cstride = (long long)pl.Hout * pl.Wout;
+        p.o_rstride = pl.Wout;
+        p.osy = L.osy; p.osx = L.osx; p.oy_off = L.oy_off; p.ox_off = L.ox_off;
+        p.wp = packed + L.wp_off;
+        p.bias = bias;
+        p.act = d->act;
+        p.stats = stat_partials;
+        p.stat_tiles = pl.stat_tiles;
+        p.stat_tile_off = L.stat_tile_off;
+        p.ntaps = (int)L.taps.size();
+        p.nchunks = pl.nchunks;
+        p.tiles_x = L.tiles_x; p.tiles_y = L.tiles_y; p.co_tiles = pl.co_tiles;
+        p.cin_pad = pl.cin_pad;
+        p.wfloats = pl.k->wfloats(p.ntaps);
+        const int IW = 31 * pl.k->S + pl.k->EXT + 1;
+        for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = L.taps[t].ly * IW + L.taps[t].lx;
+        const size_t lds = 4 * pl.k->lds_floats(p.ntaps, p.nchunks > 1 ? 2 : 1, p.cin_pad);
+        const long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
+        if (nblk > 0x7fffffffLL) return fail(AP_ERR_UNSUPPORTED, "grid too large");
+        void* args[] = {&p};
+        hipError_t e = hipLaunchKernel(pl.k->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_igemm_f32 launch: %s", hipGetErrorString(e));
+    }
+    return AP_OK;
+}
+
+}  // extern "C"

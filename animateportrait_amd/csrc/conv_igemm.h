@@ -1,0 +1,390 @@
+// conv_igemm.h -- im2col-free implicit-GEMM convolution for gfx950 (CDNA4), exact fp32.
+//
+// One kernel template covers every convolution-shaped layer of the Module2 generator and
+// PatchGAN discriminators (reference: Module2/models/networks.py:1218-1282, 2329-2421,
+// 2620-2643): Conv2d k3/k4/k7, stride 1/2, zero or reflection padding, ConvTranspose2d
+// (as four sub-pixel phases), and -- with swapped weight roles -- their data gradients.
+//
+// GEMM view per workgroup:  D[co, pix] = sum_{tap, ci} Wp[tap][ci][co] * X[ci][pix + tap]
+//   * A operand (weights) and B operand (activations) are both read from LDS with one
+//     ds_read_b32 per lane per MFMA operand; v_mfma_f32_32x32x2_f32 consumes the channel
+//     pair (ci, ci+1) held by the two half-waves (exact fp32, 64 FLOP/clk/SIMD).
+//   * The activation tile is staged ONCE per channel chunk with its halo; the KHxKW taps
+//     are shifted reads of that tile (no im2col expansion anywhere).
+//   * The loader fuses: torch.cat of up to 3 sources, InstanceNorm + ReLU/LeakyReLU of the
+//     producer layer ((x-mean)*rstd, act), zero / reflection padding.
+//   * The epilogue fuses: bias, activation (LeakyReLU/tanh), and the per-(n,cout) partial
+//     sum / sum-of-squares that InstanceNorm of THIS layer needs (deterministic, no atomics).
+//
+// Wave layout: 256 threads = 4 waves arranged WCO x WPX; each wave owns MT x NT MFMA tiles
+// of 32(cout) x 32(pixels of one output row).  Workgroup tile = (WCO*MT*32) couts x
+// (WPX*NT) rows x 32 columns.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace apamd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kMaxTaps = 49;
+constexpr int kMaxSeg = 3;
+
+struct SrcSeg {
+    const float* data;
+    const float* mean;
+    const float* rstd;
+    int C;            // real channels
+    int act;          // 0 none, 1 relu, 2 lrelu(0.2)
+    int chunk_begin;  // first chunk index of this segment
+    int pad_;
+};
+
+struct ConvKParams {
+    SrcSeg seg[kMaxSeg];
+    int nseg;
+    int N, H, W;          // input dims
+    int Cout;
+    int OH, OW;           // output grid iterated by this launch (per-phase grid for transposed)
+    int dy0, dx0;         // input coordinate of LDS-tile origin for output (0,0): iy = oy*S + dy0 + ly
+    int pad_mode;         // 0 zero, 1 reflect
+    float* y;
+    long long o_nstride;  // output strides (elements)
+    long long o_cstride;
+    int o_rstride;
+    int osy, osx, oy_off, ox_off;   // output pixel = (oy*osy + oy_off, ox*osx + ox_off)
+    const float* wp;      // packed weights of this launch: [co_tile][chunk][tap][ci][CO_TILE]
+    const float* bias;    // Cout or null
+    int act;              // epilogue: 0 none, 1 relu, 2 lrelu, 3 tanh
+    float* stats;         // [N][Cout][stat_tiles][2] or null
+    int stat_tiles;
+    int stat_tile_off;
+    int ntaps;
+    int nchunks;
+    int tiles_x, tiles_y, co_tiles;
+    int cin_pad;          // nchunks * CI
+    int wfloats;          // floats of one packed (co_tile, chunk) weight block, padded to 256
+    int tap_off[kMaxTaps];  // LDS offset (ly*IW + lx) of each tap
+};
+
+template <int CI_, int S_, int EXT_, int WCO_, int MT_, int WPX_, int NT_>
+struct ConvCfg {
+    static constexpr int CI = CI_, S = S_, EXT = EXT_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
+    static constexpr int TH = WPX * NT;
+    static constexpr int CO_TILE = WCO * MT * 32;
+    static constexpr int IH = (TH - 1) * S + EXT + 1;
+    static constexpr int IW = 31 * S + EXT + 1;
+    static constexpr int PLANE = IH * IW;
+    static constexpr int XE = CI * PLANE;
+    static constexpr int NE = (XE + 255) / 256;
+    static_assert(WCO * WPX == 4, "4 waves per workgroup");
+    static_assert(CI % 2 == 0, "channel chunk must hold whole (ci, ci+1) pairs");
+    // dynamic LDS floats for `ntaps` taps, `nbuf` (1 or 2) pipeline buffers, cin_pad channels
+    static int wfloats(int ntaps) { return (ntaps * CI * CO_TILE + 255) / 256 * 256; }
+    static size_t lds_floats(int ntaps, int nbuf, int cin_pad) {
+        size_t f = (size_t)nbuf * ((size_t)wfloats(ntaps) + XE) + 2 * (size_t)cin_pad;
+        size_t red = (size_t)WPX * CO_TILE * 2;
+        return f > red ? f : red;
+    }
+};
+
+__device__ __forceinline__ int reflect_clamp(int i, int n) {
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    // masked-out rows/cols of ragged tiles can land further out; keep the address legal
+    i = i < 0 ? 0 : (i >= n ? n - 1 : i);
+    return i;
+}
+
+__device__ __forceinline__ void glds16(const float* gsrc, float* ldst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)ldst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return v > 0.f ? v : 0.2f * v;
+    if (act == 3) return tanhf(v);
+    return v;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvKParams p) {
+    constexpr int CI = C::CI, S = C::S, MT = C::MT, NT = C::NT, WCO = C::WCO;
+    constexpr int IW = C::IW, PLANE = C::PLANE, XE = C::XE, NE = C::NE, CO_TILE = C::CO_TILE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int half = lane >> 5;
+    const int l32 = lane & 31;
+    const int wco = wave % WCO;
+    const int wpx = wave / WCO;
+
+    // ---- workgroup -> tile.  Consecutive logical ids share the activation tile (different
+    // cout tiles) and are kept on one XCD (observed dispatch: block b -> XCD b % 8), so the
+    // second reader hits that XCD's L2.  Pure speed: any placement is correct.
+    int logical;
+    {
+        const int nblk = gridDim.x, b = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int cot = logical % p.co_tiles;
+    int t_ = logical / p.co_tiles;
+    const int tx = t_ % p.tiles_x;
+    t_ /= p.tiles_x;
+    const int ty = t_ % p.tiles_y;
+    const int n = t_ / p.tiles_y;
+
+    const int oy0 = ty * C::TH, ox0 = tx * 32;
+    const int iy0 = oy0 * S + p.dy0, ix0 = ox0 * S + p.dx0;
+    const int H = p.H, W = p.W, HW = H * W;
+
+    const int wfloats = p.wfloats;
+    const int nbuf = p.nchunks > 1 ? 2 : 1;
+    float* const wbuf = smem;
+    float* const xbuf = smem + nbuf * wfloats;
+    float* const s_mean = xbuf + nbuf * XE;
+    float* const s_rstd = s_mean + p.cin_pad;
+
+    // ---- per-(n, channel) normalisation constants of the producer layers -> LDS (once)
+    for (int c = tid; c < p.cin_pad; c += 256) {
+        const int chunk = c / CI;
+        int s = 0;
+        if (p.nseg > 1 && chunk >= p.seg[1].chunk_begin) s = 1;
+        if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
+        const int cs = c - p.seg[s].chunk_begin * CI;
+        float m = 0.f, r = 1.f;
+        if (p.seg[s].mean != nullptr && cs < p.seg[s].C) {
+            m = p.seg[s].mean[n * p.seg[s].C + cs];
+            r = p.seg[s].rstd[n * p.seg[s].C + cs];
+        }
+        s_mean[c] = m;
+        s_rstd[c] = r;
+    }
+
+    // ---- loader geometry (identical for every chunk): element e of the [CI][IH][IW] tile
+    int goff[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = tid + k * 256;
+        const int ci = e / PLANE;
+        const int r = e - ci * PLANE;
+        const int ly = r / IW;
+        const int lx = r - ly * IW;
+        int gy = iy0 + ly, gx = ix0 + lx;
+        bool ok = e < XE;
+        if (p.pad_mode == 1) {
+            gy = reflect_clamp(gy, H);
+            gx = reflect_clamp(gx, W);
+        } else {
+            ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        }
+        goff[k] = ok ? ci * HW + gy * W + gx : -1;
+    }
+
+    float xr[NE];
+    auto seg_of = [&](int chunk) {
+        int s = 0;
+        if (p.nseg > 1 && chunk >= p.seg[1].chunk_begin) s = 1;
+        if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
+        return s;
+    };
+    auto issue_x = [&](int chunk) {
+        const int s = seg_of(chunk);
+        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
+        const float* base = p.seg[s].data + ((long long)n * p.seg[s].C + cbase) * HW;
+        const int cleft = p.seg[s].C - cbase;  // valid channels in this chunk (may exceed CI)
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + k * 256;
+            const int ci = e / PLANE;
+            const bool ok = goff[k] >= 0 && ci < cleft;
+            xr[k] = ok ? base[goff[k]] : 0.f;
+        }
+    };
+    auto commit_x = [&](int chunk, float* dst) {
+        const int s = seg_of(chunk);
+        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
+        const int cleft = p.seg[s].C - cbase;
+        const int act = p.seg[s].act;
+        const bool norm = p.seg[s].mean != nullptr;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + k * 256;
+            if (e < XE) {
+                const int ci = e / PLANE;
+                float v = xr[k];
+                if (norm) v = (v - s_mean[chunk * CI + ci]) * s_rstd[chunk * CI + ci];
+                if (act == 1) v = v > 0.f ? v : 0.f;
+                else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+                // padding zeros are zeros of the NORMALISED tensor
+                if (!(goff[k] >= 0 && ci < cleft)) v = 0.f;
+                dst[e] = v;
+            }
+        }
+    };
+    // weights of one chunk are one contiguous block in the packed buffer: async copy to LDS
+    const float* wsrc0 = p.wp + (long long)cot * p.nchunks * wfloats;
+    // (global_load_lds: each wave instruction moves 64 lanes x 16 B to a wave-uniform LDS base)
+    auto issue_w = [&](int chunk, float* dst) {
+        const float* src = wsrc0 + (long long)chunk * wfloats;
+        for (int j = wave; j < (wfloats >> 8); j += 4) glds16(src + j * 256 + lane * 4, dst + j * 256);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    // ---- prologue
+    __syncthreads();  // s_mean/s_rstd visible
+    issue_x(0);
+    issue_w(0, wbuf);
+    commit_x(0, xbuf);
+    __syncthreads();
+
+    const int a_lane = half * CO_TILE + wco * MT * 32 + l32;
+    const int b_lane = half * PLANE + (wpx * NT) * S * IW + l32 * S;
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < p.nchunks;
+        if (more) {
+            issue_x(chunk + 1);
+            issue_w(chunk + 1, wbuf + (cur ^ 1) * wfloats);
+        }
+        const float* Wc = wbuf + cur * wfloats + a_lane;
+        const float* Xc = xbuf + cur * XE + b_lane;
+
+        // software-pipelined operand fetch: operands of step s+1 are read before the MFMAs of step s
+        float a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
+        {
+            const int toff = p.tap_off[0];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a_cur[m] = Wc[m * 32];
+#pragma unroll
+            for (int q = 0; q < NT; ++q) b_cur[q] = Xc[toff + q * S * IW];
+        }
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = p.tap_off[t];
+            const int tn = t + 1 < p.ntaps ? t + 1 : t;
+            const int toff_n = p.tap_off[tn];
+            const float* wt = Wc + t * (CI * CO_TILE);
+            const float* wtn = Wc + tn * (CI * CO_TILE);
+#pragma unroll
+            for (int cp = 0; cp < CI / 2; ++cp) {
+                if (cp + 1 < CI / 2) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) a_nxt[m] = wt[(cp + 1) * 2 * CO_TILE + m * 32];
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) b_nxt[q] = Xc[toff + (cp + 1) * 2 * PLANE + q * S * IW];
+                } else {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) a_nxt[m] = wtn[m * 32];
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) b_nxt[q] = Xc[toff_n + q * S * IW];
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m], b_cur[q], acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+#pragma unroll
+                for (int q = 0; q < NT; ++q) b_cur[q] = b_nxt[q];
+            }
+        }
+        if (more) commit_x(chunk + 1, xbuf + (cur ^ 1) * XE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, statistics, activation, store.
+    // MFMA 32x32 C/D layout: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * half.
+    float* sred = smem;  // [WPX][CO_TILE][2], safe: all waves passed the final barrier
+    const int co_base = cot * CO_TILE + wco * MT * 32;
+    const int ox = ox0 + l32;
+    const bool want_stats = p.stats != nullptr;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = co_base + m * 32 + i;
+            const bool cok = co < p.Cout;
+            const float bv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+            float s = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NT; ++q) {
+                const int oy = oy0 + wpx * NT + q;
+                const float v = acc[m][q][r] + bv;
+                if (cok && oy < p.OH && ox < p.OW) {
+                    s += v;
+                    q2 += v * v;
+                    p.y[(long long)n * p.o_nstride + (long long)co * p.o_cstride +
+                        (long long)(oy * p.osy + p.oy_off) * p.o_rstride + (ox * p.osx + p.ox_off)] =
+                        apply_act(v, p.act);
+                }
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int sh = 1; sh < 32; sh <<= 1) {
+                    s += __shfl_xor(s, sh, 64);
+                    q2 += __shfl_xor(q2, sh, 64);
+                }
+                if (l32 == 0) {
+                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + i) * 2;
+                    d[0] = s;
+                    d[1] = q2;
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (tid < CO_TILE) {
+            const int co = cot * CO_TILE + tid;
+            if (co < p.Cout) {
+                float s = 0.f, q2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < C::WPX; ++w) {
+                    s += sred[(w * CO_TILE + tid) * 2];
+                    q2 += sred[(w * CO_TILE + tid) * 2 + 1];
+                }
+                float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + p.stat_tile_off +
+                                      ty * p.tiles_x + tx) * 2;
+                d[0] = s;
+                d[1] = q2;
+            }
+        }
+    }
+}
+
+typedef void (*ConvKernelFn)(const ConvKParams);
+
+struct ConvKernelInfo {
+    int CI, S, EXT, WCO, MT, WPX, NT;
+    int TH, CO_TILE, XE;
+    const void* fn;
+    size_t (*lds_floats)(int, int, int);
+    int (*wfloats)(int);
+};
+
+template <class C>
+ConvKernelInfo make_info() {
+    ConvKernelInfo k;
+    k.CI = C::CI; k.S = C::S; k.EXT = C::EXT; k.WCO = C::WCO; k.MT = C::MT; k.WPX = C::WPX; k.NT = C::NT;
+    k.TH = C::TH; k.CO_TILE = C::CO_TILE; k.XE = C::XE;
+    k.fn = reinterpret_cast<const void*>(&conv_igemm_f32<C>);
+    k.lds_floats = &C::lds_floats;
+    k.wfloats = &C::wfloats;
+    return k;
+}
+
+}  // namespace apamd

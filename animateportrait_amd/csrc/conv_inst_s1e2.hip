@@ -1,0 +1,5 @@
+// conv_igemm_f32 instantiations: stride 1, tap-window extent 2 (see conv_registry.h)
+#include "conv_registry.h"
+namespace apamd {
+void register_s1e2(std::vector<ConvKernelInfo>& v) { APAMD_REGISTER_ALL(1, 2) }
+}  // namespace apamd

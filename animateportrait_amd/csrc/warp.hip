@@ -1,0 +1,154 @@
+// warp.hip -- fused double_feature_warping (reference: Module2/models/networks.py:1298-1313 and
+// warp_acc_flow, Module2/intrinsic_flow_models/modules.py:596-625).
+//
+// One pass produces the 2C-channel concat the next convolution reads:
+//   out[:, 0:C ] = grid_sample(x, motion_L)                       bilinear / zeros / align_corners=False
+//   out[:, C:2C] = where(mask_L > 0.5, grid_sample(x, grid(flow_L)), -1)
+// motion_L, flow_L, mask_L are the align_corners=True bilinear resizes of the full-resolution inputs
+// to the feature resolution, evaluated per output pixel instead of being materialised, and x may be a
+// raw conv output whose InstanceNorm+ReLU is applied per gathered tap.
+//
+// HBM-bound gather: one lane per output pixel (consecutive lanes = consecutive x, so the two stores
+// per channel are coalesced 256-B rows); sample coordinates and the 2x4 tap offsets/weights are
+// computed once per pixel and reused for CG channels.
+#include "common.h"
+
+namespace apamd {
+
+struct Taps {
+    int off[4];     // offset inside a channel plane, or -1 when the tap is out of range (contributes 0)
+    float w[4];
+};
+
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
+    // grid_sampler_unnormalize, align_corners=False: ((g + 1) * size - 1) / 2
+    float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);   // everything beyond is all-zero taps anyway
+    iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ex = fx + 1.f, ey = fy + 1.f;
+    Taps t;
+    t.w[0] = (ex - ix) * (ey - iy);   // nw
+    t.w[1] = (ix - fx) * (ey - iy);   // ne
+    t.w[2] = (ex - ix) * (iy - fy);   // sw
+    t.w[3] = (ix - fx) * (iy - fy);   // se
+    const bool xin0 = x0 >= 0 && x0 < W, xin1 = x1 >= 0 && x1 < W;
+    const bool yin0 = y0 >= 0 && y0 < H, yin1 = y1 >= 0 && y1 < H;
+    t.off[0] = (xin0 && yin0) ? y0 * W + x0 : -1;
+    t.off[1] = (xin1 && yin0) ? y0 * W + x1 : -1;
+    t.off[2] = (xin0 && yin1) ? y1 * W + x0 : -1;
+    t.off[3] = (xin1 && yin1) ? y1 * W + x1 : -1;
+    return t;
+}
+
+struct Lerp { int i0, i1; float l0, l1; };
+
+// F.interpolate(mode='bilinear', align_corners=True): src = dst * (S-1)/(H-1)
+__device__ __forceinline__ Lerp make_lerp(int dst, int S, int H) {
+    const float scale = H > 1 ? (float)(S - 1) / (float)(H - 1) : 0.f;
+    const float src = scale * (float)dst;
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > S - 1) l.i0 = S - 1;
+    l.i1 = l.i0 + (l.i0 < S - 1 ? 1 : 0);
+    l.l1 = src - (float)l.i0;
+    l.l0 = 1.f - l.l1;
+    return l;
+}
+
+__device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v11, const Lerp& ly, const Lerp& lx) {
+    return ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+}
+
+__device__ __forceinline__ float tap_val(const float* plane, int off, float m, float r, int act) {
+    if (off < 0) return 0.f;
+    float v = (plane[off] - m) * r;
+    if (act == 1) v = v > 0.f ? v : 0.f;
+    else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+    return v;
+}
+
+constexpr int kWarpCG = 8;   // channels per thread
+
+// grid: (ceil(H*W/256), ceil(C/CG), N)
+__global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
+                                                          const float* __restrict__ x_rstd, int x_act,
+                                                          const float* __restrict__ motion,
+                                                          const float* __restrict__ flow,
+                                                          const float* __restrict__ ifmask, float* __restrict__ out,
+                                                          int C, int H, int W, int S, float flow_scale) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int n = blockIdx.z;
+    const int oy = pix / W, ox = pix - oy * W;
+    const long long SS = (long long)S * S;
+
+    float gx, gy, fx, fy, mk;
+    if (H == S && W == S) {
+        const float2 g = reinterpret_cast<const float2*>(motion)[n * SS + pix];
+        gx = g.x; gy = g.y;
+        fx = flow[(n * 2 + 0) * SS + pix] * flow_scale;
+        fy = flow[(n * 2 + 1) * SS + pix] * flow_scale;
+        mk = ifmask[n * SS + pix];
+    } else {
+        const Lerp ly = make_lerp(oy, S, H), lx = make_lerp(ox, S, W);
+        const int o00 = ly.i0 * S + lx.i0, o01 = ly.i0 * S + lx.i1, o10 = ly.i1 * S + lx.i0, o11 = ly.i1 * S + lx.i1;
+        const float2* mo = reinterpret_cast<const float2*>(motion) + n * SS;
+        const float2 a = mo[o00], b = mo[o01], c = mo[o10], d = mo[o11];
+        gx = bilerp(a.x, b.x, c.x, d.x, ly, lx);
+        gy = bilerp(a.y, b.y, c.y, d.y, ly, lx);
+        const float* f0 = flow + (n * 2 + 0) * SS;
+        const float* f1 = flow + (n * 2 + 1) * SS;
+        // the reference resizes flow / 2^level; the scale is a power of two, so scaling taps is exact
+        fx = bilerp(f0[o00] * flow_scale, f0[o01] * flow_scale, f0[o10] * flow_scale, f0[o11] * flow_scale, ly, lx);
+        fy = bilerp(f1[o00] * flow_scale, f1[o01] * flow_scale, f1[o10] * flow_scale, f1[o11] * flow_scale, ly, lx);
+        const float* mp = ifmask + n * SS;
+        mk = bilerp(mp[o00], mp[o01], mp[o10], mp[o11], ly, lx);
+    }
+    const Taps tm = make_taps(gx, gy, H, W);
+    // warp_acc_flow: grid = 2 * (pixel + flow) / max(size - 1, 1) - 1
+    const float wgx = 2.0f * ((float)ox + fx) / (float)(W - 1 > 1 ? W - 1 : 1) - 1.0f;
+    const float wgy = 2.0f * ((float)oy + fy) / (float)(H - 1 > 1 ? H - 1 : 1) - 1.0f;
+    const Taps tf = make_taps(wgx, wgy, H, W);
+    const bool keep = mk > 0.5f;
+
+    const int HW = H * W;
+    const int c0 = blockIdx.y * kWarpCG;
+    const int c1 = c0 + kWarpCG < C ? c0 + kWarpCG : C;
+    for (int c = c0; c < c1; ++c) {
+        const float* plane = x + ((long long)n * C + c) * HW;
+        float m = 0.f, r = 1.f;
+        if (x_mean != nullptr) { m = x_mean[n * C + c]; r = x_rstd[n * C + c]; }
+        float v1 = 0.f, v2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v1 += tap_val(plane, tm.off[k], m, r, x_act) * tm.w[k];
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v2 += tap_val(plane, tf.off[k], m, r, x_act) * tf.w[k];
+        } else {
+            v2 = -1.f;
+        }
+        out[((long long)n * 2 * C + c) * HW + pix] = v1;
+        out[((long long)n * 2 * C + C + c) * HW + pix] = v2;
+    }
+}
+
+}  // namespace apamd
+
+using namespace apamd;
+
+extern "C" int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                                  const float* motion, const float* flow, const float* ifmask, float* out, int32_t N,
+                                  int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale, ap_stream_t stream) {
+    if (!x || !motion || !flow || !ifmask || !out) return fail(AP_ERR_INVALID, "warp_concat_fwd: null pointer");
+    if ((x_mean == nullptr) != (x_rstd == nullptr)) return fail(AP_ERR_INVALID, "warp_concat_fwd: mean/rstd mismatch");
+    if (N < 1 || C < 1 || H < 1 || W < 1 || S < 1) return fail(AP_ERR_INVALID, "warp_concat_fwd: bad sizes");
+    if (x_act < 0 || x_act > 2) return fail(AP_ERR_INVALID, "warp_concat_fwd: act %d", x_act);
+    if (N > 65535) return fail(AP_ERR_UNSUPPORTED, "warp_concat_fwd: N too large");
+    dim3 grid((H * W + 255) / 256, (C + kWarpCG - 1) / kWarpCG, N);
+    hipLaunchKernelGGL(warp_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
+                       flow, ifmask, out, C, H, W, S, flow_scale);
+    return check_launch("warp_concat_kernel");
+}

@@ -1,0 +1,326 @@
+"""Host-side mirror of the reference's network registry for the hot path.
+
+Same entry points, argument meaning and error behaviour as Module2/models/networks.py:
+``define_G`` (:123-201), ``define_D`` (:204-247), ``init_weights`` (:71-102), ``get_scheduler``
+(:42-68), ``GANLoss`` (:407-473); same ``state_dict`` keys as
+``ResnetConditionTriGenerator32_full_ifw`` (:1190-1340) and ``NLayerDiscriminator`` (:2602-2647)
+so reference checkpoints (``<epoch>_net_G_A.pth`` ...) load with ``strict=True``.
+
+The modules own their parameters as ordinary ``nn.Parameter``s; ``forward`` never touches a
+torch operator for the math -- every layer is a call into libapamd.so (HIP, gfx950).
+"""
+import functools
+
+import torch
+import torch.nn as nn
+from torch.optim import lr_scheduler
+
+from . import ops
+from .ops import (Feat, ConvSpec, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT,
+                  W_OIHW, W_IOHW)
+
+GENERATOR_NAMES = ('resnet_9blocks_rcatland32_full_ifw',)
+# names the reference registry knows (networks.py:152-199) but that are outside this build's hot path
+_REFERENCE_ONLY_G = (
+    'resnet_9blocks', 'resnet_style2_9blocks', 'resnet_9blocks_rcatland', 'resnet_9blocks_rcatland3',
+    'resnet_9blocks_rcatland32', 'resnet_10blocks_rcatland32', 'resnet_9blocks_rcatland4',
+    'resnet_9blocks_rcatland32_fw', 'resnet_9blocks_rcatland32_fw2', 'resnet_9blocks_rcatland32_ifw',
+    'resnet_9blocks_rcatland32_ifw_single2', 'resnet_9blocks_rcatland32_full_ifw_colorcoded',
+    'resnet_9blocks_rcatland32_full_ifw2', 'resnet_9blocks_rcatland32_full_ifw_single',
+    'resnet_9blocks_rcatland32_full_ifw_single2', 'resnet_9blocks_rcatland32_full_ifw_single3', 'regressor',
+    'combiner', 'resnet_9blocks_rcatland2', 'resnet_6blocks', 'unet_128', 'unet_256')
+
+
+class ConvLayer(nn.Module):
+    """Parameters of one nn.Conv2d / nn.ConvTranspose2d plus the kernel-side spec.
+    state_dict: ``weight`` (OIHW, or IOHW when transposed) and ``bias`` -- as the reference layer."""
+
+    def __init__(self, cin_segments, cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed=False,
+                 output_padding=0):
+        super().__init__()
+        cin = sum(cin_segments)
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.zeros(cout, dtype=torch.float32))
+        self.spec = ConvSpec(cin_segments, cout, k, stride, pad, pad_mode, transposed, output_padding,
+                             W_IOHW if transposed else W_OIHW)
+        self._packed = None
+        self._packed_key = None
+
+    def packed(self):
+        w = self.weight
+        key = (w._version, w.data_ptr())
+        if self._packed is None or self._packed_key != key:
+            self._packed = ops.pack_weights(self.spec, w.detach())
+            self._packed_key = key
+        return self._packed
+
+    def run(self, srcs, norm_act=None, act=ACT_NONE):
+        """norm_act=None: plain conv + bias + act.  norm_act=ACT_*: conv followed by InstanceNorm
+        (bias skipped -- it cancels exactly under the mean subtraction) and that activation,
+        both deferred to the consumer."""
+        if not isinstance(srcs, (list, tuple)):
+            srcs = [srcs]
+        if norm_act is None:
+            return ops.conv2d(self.spec, srcs, self.packed(), self.bias.detach(), act=act)
+        return ops.conv2d(self.spec, srcs, self.packed(), None, want_stats=True, out_act=norm_act)
+
+
+def _seq(**children):
+    """Container whose children are registered under the numeric names of the reference's nn.Sequential."""
+    return nn.ModuleDict({k.lstrip('_'): v for k, v in children.items()})
+
+
+class ResnetBlock(nn.Module):
+    """networks.py:2303-2361 (reflect padding, no dropout): x + IN(conv(ReLU(IN(conv(x)))))."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_block = _seq(_1=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT),
+                               _5=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT))
+
+    def run(self, x):
+        y = self.conv_block['1'].run(x, norm_act=ACT_RELU)
+        y = self.conv_block['5'].run(y, norm_act=ACT_NONE)
+        return ops.materialize(y, residual=x)
+
+
+class ResnetBlock2(nn.Module):
+    """networks.py:2363-2421: main branch reflect-padded, shortcut conv zero-padded, both on cat[x,l1,l2]."""
+
+    def __init__(self, segs, dim_out):
+        super().__init__()
+        self.conv_block = _seq(_1=ConvLayer(segs, dim_out, 3, 1, 1, PAD_REFLECT),
+                               _5=ConvLayer([dim_out], dim_out, 3, 1, 1, PAD_REFLECT))
+        self.shortcut = _seq(_0=ConvLayer(segs, dim_out, 3, 1, 1, PAD_ZERO))
+
+    def run(self, srcs):
+        y = self.conv_block['1'].run(srcs, norm_act=ACT_RELU)
+        y = self.conv_block['5'].run(y, norm_act=ACT_NONE)
+        s = self.shortcut['0'].run(srcs, norm_act=ACT_NONE)
+        return ops.materialize(y, residual=s)
+
+
+class ResnetConditionTriGenerator32_full_ifw(nn.Module):
+    """networks.py:1190-1340.  ``norm_layer`` must be instance norm (the only one the model uses,
+    geomgm_ifw_fore_model.py:161-209 / base_options.py norm default)."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, norm='instance', use_dropout=False, n_blocks=9,
+                 padding_type='reflect', div=3, disp=1):
+        super().__init__()
+        if norm != 'instance':
+            raise NotImplementedError('normalization layer [%s] is not available on the HIP path' % norm)
+        if use_dropout:
+            raise NotImplementedError('dropout is not available on the HIP path (the model sets no_dropout)')
+        if padding_type != 'reflect':
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        assert n_blocks >= 0
+        self.n_blocks, self.div, self.disp = n_blocks, div, disp
+        self.input_nc, self.output_nc, self.ngf = input_nc, output_nc, ngf
+        h = ngf // 2
+        con_dim = 16
+        dim = ngf * 4
+        # registration order == reference state_dict order (model_tri_merge is assigned first, :1251)
+        self.model_tri_merge = ConvLayer([ngf * 4, ngf * 4, ngf * 4], dim, 3, 1, 1)
+        self.model_tri00 = _seq(_1=ConvLayer([input_nc], h, 7, 1, 3, PAD_REFLECT))
+        self.model_tri01 = _seq(_0=ConvLayer([ngf], ngf * 2, 3, 2, 1))
+        self.model_tri02 = _seq(_0=ConvLayer([ngf * 2], ngf * 4, 3, 2, 1))
+        self.model_tri10 = _seq(_1=ConvLayer([input_nc], ngf, 7, 1, 3, PAD_REFLECT))
+        self.model_tri11 = _seq(_0=ConvLayer([ngf], ngf, 3, 2, 1))
+        self.model_tri12 = _seq(_0=ConvLayer([ngf * 2], ngf * 4, 3, 2, 1))
+        self.model_tri20 = _seq(_1=ConvLayer([input_nc], ngf, 7, 1, 3, PAD_REFLECT))
+        self.model_tri21 = _seq(_0=ConvLayer([ngf], ngf * 2, 3, 2, 1))
+        self.model_tri22 = _seq(_0=ConvLayer([ngf * 2], ngf * 2, 3, 2, 1))
+        blocks = {}
+        for i in range(n_blocks):
+            if (i + disp) % div == 0:
+                blocks[str(i)] = ResnetBlock2([dim, con_dim, con_dim], dim)
+            else:
+                blocks[str(i)] = ResnetBlock(dim)
+        self.model2 = nn.ModuleDict(blocks)
+        self.model3 = _seq(_0=ConvLayer([ngf * 4], ngf * 2, 3, 2, 1, transposed=True, output_padding=1),
+                           _3=ConvLayer([ngf * 2], ngf, 3, 2, 1, transposed=True, output_padding=1),
+                           _7=ConvLayer([ngf], output_nc, 7, 1, 3, PAD_REFLECT))
+        self.model_landmark_trans = _seq(_0=ConvLayer([1], 8, 3, 1, 1), _3=ConvLayer([8], con_dim, 3, 2, 1),
+                                         _6=ConvLayer([con_dim], con_dim, 3, 2, 1))
+
+    def is_block2(self, i):
+        return (i + self.disp) % self.div == 0
+
+    def double_feature_warping(self, x, motion, flow, ifmask, level):
+        return ops.warp_concat(x, motion, flow, ifmask, level)
+
+    def forward(self, input, land1, land2, motion, flow, ifmask):
+        """G(input, land1, land2, motion, flow, ifmask) -> (B, output_nc, S, S)   (networks.py:1315)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .autograd import generator_apply
+            return generator_apply(self, input, land1, land2, motion, flow, ifmask)
+        return self.forward_inference(input, land1, land2, motion, flow, ifmask)
+
+    def forward_inference(self, input, land1, land2, motion, flow, ifmask):
+        b = input.shape[0]
+        inp = Feat(input.contiguous())
+        motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
+        x1 = self.model_tri00['1'].run(inp, norm_act=ACT_RELU)
+        x1 = self.double_feature_warping(x1, motion, flow, ifmask, 0)
+        x1 = self.model_tri01['0'].run(x1, norm_act=ACT_RELU)
+        x1 = self.model_tri02['0'].run(x1, norm_act=ACT_RELU)
+        x2 = self.model_tri10['1'].run(inp, norm_act=ACT_RELU)
+        x2 = self.model_tri11['0'].run(x2, norm_act=ACT_RELU)
+        x2 = self.double_feature_warping(x2, motion, flow, ifmask, 1)
+        x2 = self.model_tri12['0'].run(x2, norm_act=ACT_RELU)
+        x3 = self.model_tri20['1'].run(inp, norm_act=ACT_RELU)
+        x3 = self.model_tri21['0'].run(x3, norm_act=ACT_RELU)
+        x3 = self.model_tri22['0'].run(x3, norm_act=ACT_RELU)
+        x3 = self.double_feature_warping(x3, motion, flow, ifmask, 2)
+        x = self.model_tri_merge.run([x1, x2, x3])
+        # land1 / land2 share the encoder weights: one pass over the 2B batch
+        lands = Feat(torch.cat([land1, land2], 0).contiguous())
+        l = self.model_landmark_trans['0'].run(lands, norm_act=ACT_RELU)
+        l = self.model_landmark_trans['3'].run(l, norm_act=ACT_RELU)
+        l = self.model_landmark_trans['6'].run(l, norm_act=ACT_NONE)
+        l1, l2 = l.batch_slice(0, b), l.batch_slice(b, 2 * b)
+        for i in range(self.n_blocks):
+            blk = self.model2[str(i)]
+            x = blk.run([x, l1, l2]) if self.is_block2(i) else blk.run(x)
+        x = self.model3['0'].run(x, norm_act=ACT_RELU)
+        x = self.model3['3'].run(x, norm_act=ACT_RELU)
+        return self.model3['7'].run(x, act=ACT_TANH).data
+
+
+class NLayerDiscriminator(nn.Module):
+    """70x70 PatchGAN, networks.py:2602-2647 (n_layers=3, instance norm)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm='instance'):
+        super().__init__()
+        if norm != 'instance':
+            raise NotImplementedError('normalization layer [%s] is not available on the HIP path' % norm)
+        if n_layers != 3:
+            raise NotImplementedError('only the 3-layer PatchGAN (netD=basic) is on the HIP path')
+        self.input_nc, self.ndf = input_nc, ndf
+        self.model = _seq(_0=ConvLayer([input_nc], ndf, 4, 2, 1), _2=ConvLayer([ndf], ndf * 2, 4, 2, 1),
+                          _5=ConvLayer([ndf * 2], ndf * 4, 4, 2, 1), _8=ConvLayer([ndf * 4], ndf * 8, 4, 1, 1),
+                          _11=ConvLayer([ndf * 8], 1, 4, 1, 1))
+
+    def forward(self, input):
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
+            from .autograd import discriminator_apply
+            return discriminator_apply(self, input)
+        return self.forward_inference(input)
+
+    def forward_inference(self, input):
+        x = self.model['0'].run(Feat(input.contiguous()), act=ACT_LRELU)
+        x = self.model['2'].run(x, norm_act=ACT_LRELU)
+        x = self.model['5'].run(x, norm_act=ACT_LRELU)
+        x = self.model['8'].run(x, norm_act=ACT_LRELU)
+        return self.model['11'].run(x).data
+
+
+# --------------------------------------------------------------------------- registry
+def get_norm_layer(norm_type='instance'):
+    """networks.py:22-39.  Returned token is what the HIP modules accept as ``norm``."""
+    if norm_type in ('batch', 'none'):
+        raise NotImplementedError('normalization layer [%s] is not available on the HIP path' % norm_type)
+    if norm_type != 'instance':
+        raise NotImplementedError('normalization layer [%s] is not found' % norm_type)
+    return 'instance'
+
+
+def get_scheduler(optimizer, opt):
+    """networks.py:42-68."""
+    if opt.lr_policy == 'linear':
+        def lambda_rule(epoch):
+            return 1.0 - max(0, epoch + opt.epoch_count - opt.niter) / float(opt.niter_decay + 1)
+        return lr_scheduler.LambdaLR(optimizer, lr_lambda=lambda_rule)
+    if opt.lr_policy == 'step':
+        return lr_scheduler.StepLR(optimizer, step_size=opt.lr_decay_iters, gamma=0.1)
+    if opt.lr_policy == 'plateau':
+        return lr_scheduler.ReduceLROnPlateau(optimizer, mode='min', factor=0.2, threshold=0.01, patience=5)
+    if opt.lr_policy == 'cosine':
+        return lr_scheduler.CosineAnnealingLR(optimizer, T_max=opt.niter, eta_min=0)
+    raise NotImplementedError('learning rate policy [%s] is not implemented' % opt.lr_policy)
+
+
+def init_weights(net, init_type='normal', init_gain=0.02):
+    """networks.py:71-102: conv weights by ``init_type``, biases 0."""
+    for m in net.modules():
+        if isinstance(m, ConvLayer):
+            if init_type == 'normal':
+                nn.init.normal_(m.weight.data, 0.0, init_gain)
+            elif init_type == 'xavier':
+                nn.init.xavier_normal_(m.weight.data, gain=init_gain)
+            elif init_type == 'kaiming':
+                nn.init.kaiming_normal_(m.weight.data, a=0, mode='fan_in')
+            elif init_type == 'orthogonal':
+                nn.init.orthogonal_(m.weight.data, gain=init_gain)
+            else:
+                raise NotImplementedError('initialization method [%s] is not implemented' % init_type)
+            nn.init.constant_(m.bias.data, 0.0)
+    print('initialize network with %s' % init_type)
+
+
+def init_net(net, init_type='normal', init_gain=0.02, gpu_ids=[]):
+    """networks.py:105-120.  The reference wraps in nn.DataParallel; here multi-GPU is one process
+    per GPU (animateportrait_amd.parallel), so the net goes to gpu_ids[0] unwrapped -- its state_dict
+    equals what the reference saves (base_model.py:152-163 saves ``net.module``)."""
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        net.to(gpu_ids[0])
+    init_weights(net, init_type, init_gain=init_gain)
+    return net
+
+
+def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, init_type='normal', init_gain=0.02,
+             gpu_ids=[], model0_res=0, model1_res=0, extra_channel=3, div=3, disp=1, regarch=4):
+    """networks.py:123-201."""
+    norm = get_norm_layer(norm_type=norm)
+    if netG == 'resnet_9blocks_rcatland32_full_ifw':
+        net = ResnetConditionTriGenerator32_full_ifw(input_nc, output_nc, ngf, norm=norm, use_dropout=use_dropout,
+                                                     n_blocks=9, div=div, disp=disp)
+    elif netG in _REFERENCE_ONLY_G:
+        raise NotImplementedError('Generator model name [%s] is outside the MI355X hot path '
+                                  '(only %s is built)' % (netG, ', '.join(GENERATOR_NAMES)))
+    else:
+        raise NotImplementedError('Generator model name [%s] is not recognized' % netG)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+def define_D(input_nc, ndf, netD, n_layers_D=3, norm='batch', init_type='normal', init_gain=0.02, gpu_ids=[],
+             n_class=3):
+    """networks.py:204-247."""
+    norm = get_norm_layer(norm_type=norm)
+    if netD == 'basic':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm=norm)
+    elif netD == 'n_layers':
+        net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm=norm)
+    elif netD in ('basic_cls', 'pixel'):
+        raise NotImplementedError('Discriminator model name [%s] is outside the MI355X hot path' % netD)
+    else:
+        raise NotImplementedError('Discriminator model name [%s] is not recognized' % netD)
+    return init_net(net, init_type, init_gain, gpu_ids)
+
+
+class GANLoss(nn.Module):
+    """networks.py:407-473.  lsgan: mean((pred - label)^2)."""
+
+    def __init__(self, gan_mode, target_real_label=1.0, target_fake_label=0.0):
+        super().__init__()
+        self.register_buffer('real_label', torch.tensor(target_real_label))
+        self.register_buffer('fake_label', torch.tensor(target_fake_label))
+        self.gan_mode = gan_mode
+        self._labels = (float(target_fake_label), float(target_real_label))   # host copies: no device sync
+        if gan_mode not in ('lsgan', 'vanilla', 'wgangp'):
+            raise NotImplementedError('gan mode %s not implemented' % gan_mode)
+
+    def get_target_tensor(self, prediction, target_is_real):
+        t = self.real_label if target_is_real else self.fake_label
+        return t.expand_as(prediction)
+
+    def __call__(self, prediction, target_is_real):
+        if self.gan_mode == 'lsgan':
+            t = self._labels[1 if target_is_real else 0]
+            return ((prediction - t) ** 2).mean()
+        if self.gan_mode == 'vanilla':
+            return nn.functional.binary_cross_entropy_with_logits(
+                prediction, self.get_target_tensor(prediction, target_is_real))
+        return -prediction.mean() if target_is_real else prediction.mean()

@@ -1,0 +1,195 @@
+"""Operator layer: thin Python wrappers that hand raw device pointers to the HIP kernels.
+
+``Feat`` is the unit the layers exchange: a feature map that may still be *virtual*,
+i.e. a raw convolution output plus the per-(n,c) InstanceNorm statistics and the
+activation that the CONSUMER applies while it stages the tensor into LDS.  This is how
+``Conv2d -> InstanceNorm2d -> ReLU`` chains of the reference
+(Module2/models/networks.py:1218-1282) run as one kernel per convolution.
+"""
+import ctypes
+
+import torch
+
+from . import _capi as C
+from ._capi import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, W_OIHW, W_IOHW  # noqa: F401
+
+EPS = 1e-5  # nn.InstanceNorm2d default (networks.py:33-34)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _require_device(t, name):
+    if not t.is_cuda:
+        raise RuntimeError('animateportrait_amd: %s must live on the MI355X (got a %s tensor); '
+                           'this package has no CPU path' % (name, t.device))
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise RuntimeError('animateportrait_amd: %s must be contiguous fp32' % name)
+
+
+class Feat:
+    """act((data - mean) * rstd) with mean/rstd of shape (N*C,), or a plain tensor when mean is None."""
+    __slots__ = ('data', 'mean', 'rstd', 'act')
+
+    def __init__(self, data, mean=None, rstd=None, act=ACT_NONE):
+        self.data, self.mean, self.rstd, self.act = data, mean, rstd, act
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def batch_slice(self, lo, hi):
+        c = self.data.shape[1]
+        return Feat(self.data[lo:hi], None if self.mean is None else self.mean[lo * c:hi * c],
+                    None if self.rstd is None else self.rstd[lo * c:hi * c], self.act)
+
+
+class ConvSpec:
+    """Static part of one convolution-like operator (everything except N, H, W and pointers)."""
+
+    def __init__(self, cin_segments, cout, k, stride=1, pad=0, pad_mode=PAD_ZERO, transposed=False,
+                 output_padding=0, w_layout=W_OIHW, w_flip=False):
+        self.cin_segments = tuple(cin_segments)
+        self.cout, self.k, self.stride, self.pad, self.pad_mode = cout, k, stride, pad, pad_mode
+        self.transposed, self.output_padding = transposed, output_padding
+        self.w_layout, self.w_flip = w_layout, w_flip
+
+    def desc(self, n, h, w, srcs=None, act=ACT_NONE):
+        d = C.ApConvDesc()
+        d.N, d.H, d.W, d.Cout = n, h, w, self.cout
+        d.KH = d.KW = self.k
+        d.stride, d.pad, d.pad_mode = self.stride, self.pad, self.pad_mode
+        d.transposed, d.output_padding = int(self.transposed), self.output_padding
+        d.w_layout, d.w_flip, d.act = self.w_layout, int(self.w_flip), act
+        d.nsrc = len(self.cin_segments)
+        for i, c in enumerate(self.cin_segments):
+            d.src[i].C = c
+            if srcs is not None:
+                f = srcs[i]
+                d.src[i].data = f.data.data_ptr()
+                d.src[i].mean = f.mean.data_ptr() if f.mean is not None else None
+                d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
+                d.src[i].act = f.act
+        return d
+
+    def out_size(self, h, w):
+        d = self.desc(1, h, w)
+        ho, wo = ctypes.c_int32(), ctypes.c_int32()
+        C.check(C.lib().ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
+        return ho.value, wo.value
+
+
+class LaunchProfiler:
+    """Optional per-launch timing for bench.py: brackets every convolution launch with events on the
+    launch stream (the kernels run on torch's current stream, so torch.cuda.Event is the HIP event on
+    that stream) and records the kernel instantiation and the layer's algorithmic FLOPs."""
+
+    def __init__(self):
+        self.records = []   # (kernel name, flops, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
+            a['launches'] += 1
+            a['ms'] += e0.elapsed_time(e1)
+            a['flops'] += flops
+        return agg
+
+
+PROFILER = None
+
+
+def pack_weights(spec, weight):
+    """Re-lay ``weight`` (nn.Conv2d OIHW or nn.ConvTranspose2d IOHW) into the kernel's LDS image."""
+    _require_device(weight, 'weight')
+    d = spec.desc(1, 64, 64)
+    n = C.check(C.lib().ap_conv2d_packed_floats(ctypes.byref(d)), 'conv2d_packed_floats')
+    packed = torch.empty(n, dtype=torch.float32, device=weight.device)
+    C.check(C.lib().ap_conv2d_pack_weights(ctypes.byref(d), _ptr(weight), _ptr(packed), _stream()), 'pack_weights')
+    return packed
+
+
+def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE):
+    """Run one convolution.  Returns a Feat:
+    * want_stats=False: materialised ``act(conv + bias)``;
+    * want_stats=True : raw conv output with its InstanceNorm statistics, to be consumed as
+      ``out_act(IN(raw))`` by the next layer."""
+    x0 = srcs[0].data
+    n, _, h, w = x0.shape
+    for f, c in zip(srcs, spec.cin_segments):
+        _require_device(f.data, 'conv input')
+        if f.data.shape[1] != c or f.data.shape[0] != n or f.data.shape[2:] != x0.shape[2:]:
+            raise ValueError('conv2d: source of shape %s does not match segment C=%d' % (tuple(f.data.shape), c))
+    d = spec.desc(n, h, w, srcs, act)
+    lib = C.lib()
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
+    y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)
+    partial = None
+    if want_stats:
+        tiles = C.check(lib.ap_conv2d_stat_tiles(ctypes.byref(d)), 'conv2d_stat_tiles')
+        partial = torch.empty((n * spec.cout, tiles, 2), dtype=torch.float32, device=x0.device)
+    if PROFILER is not None:
+        buf = ctypes.create_string_buffer(96)
+        C.check(lib.ap_conv2d_kernel_name(ctypes.byref(d), buf, 96), 'conv2d_kernel_name')
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.check(lib.ap_conv2d_fwd(ctypes.byref(d), _ptr(packed), _ptr(bias), _ptr(y), _ptr(partial), _stream()),
+            'conv2d_fwd')
+    if PROFILER is not None:
+        e1.record()
+        # algorithmic FLOPs = 2 * MACs of the dense operator (transposed: every input pixel x k*k taps)
+        px = h * w if spec.transposed else ho.value * wo.value
+        PROFILER.records.append((buf.value.decode(), 2.0 * n * px * spec.cout * sum(spec.cin_segments) * spec.k ** 2,
+                                 e0, e1))
+    if not want_stats:
+        return Feat(y)
+    mean = torch.empty(n * spec.cout, dtype=torch.float32, device=x0.device)
+    rstd = torch.empty_like(mean)
+    C.check(lib.ap_instnorm_finalize(_ptr(partial), n * spec.cout, tiles, ho.value * wo.value, EPS,
+                                     _ptr(mean), _ptr(rstd), _stream()), 'instnorm_finalize')
+    return Feat(y, mean, rstd, out_act)
+
+
+def materialize(f, residual=None):
+    """out = act(IN(f.data)) [+ residual]; residual may itself be a virtual Feat (act must be NONE)."""
+    if f.mean is None:
+        raise ValueError('materialize: feature is already plain')
+    x = f.data
+    n, c, h, w = x.shape
+    out = torch.empty_like(x)
+    res = rm = rr = None
+    if residual is not None:
+        if residual.act != ACT_NONE and residual.mean is not None:
+            raise ValueError('materialize: a normalised residual cannot carry an activation')
+        res, rm, rr = residual.data, residual.mean, residual.rstd
+        if res.shape != x.shape:
+            raise ValueError('materialize: residual shape mismatch')
+    C.check(C.lib().ap_instnorm_apply(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(res), _ptr(rm), _ptr(rr),
+                                      _ptr(out), n * c, h * w, _stream()), 'instnorm_apply')
+    return Feat(out)
+
+
+def warp_concat(f, motion, flow, ifmask, level):
+    """double_feature_warping (networks.py:1298-1313) on a (possibly virtual) feature map."""
+    x = f.data
+    n, c, h, w = x.shape
+    for t, name in ((x, 'x'), (motion, 'motion'), (flow, 'flow'), (ifmask, 'ifmask')):
+        _require_device(t, name)
+    s = motion.shape[1]
+    if motion.shape != (n, s, s, 2) or flow.shape != (n, 2, s, s) or ifmask.shape != (n, 1, s, s):
+        raise ValueError('warp_concat: motion/flow/ifmask shapes %s %s %s' % (motion.shape, flow.shape, ifmask.shape))
+    if h != s >> level or w != s >> level:
+        raise ValueError('warp_concat: level %d expects %d px features, got %dx%d' % (level, s >> level, h, w))
+    out = torch.empty((n, 2 * c, h, w), dtype=torch.float32, device=x.device)
+    C.check(C.lib().ap_warp_concat_fwd(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
+                                       _ptr(ifmask), _ptr(out), n, c, h, w, s, 1.0 / (1 << level), _stream()),
+            'warp_concat_fwd')
+    return Feat(out)

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- generator frames/s @256x256, bs=16 per GPU (BASELINE.json metric), MI355X.
+
+One "step" = one forward pass of the full-width generator (ngf=64, fp32,
+resnet_9blocks_rcatland32_full_ifw, disp=div=3) over a batch of 16 synthetic 256x256 frames that is
+already resident in HBM (BASELINE config 2).  N > 1: one process per GPU (launched by
+torch.distributed.run), frame batches shard by sample with no data-path collective
+(InstanceNorm makes samples independent) -> weak scaling; only the timing uses a collective.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying also
+  "roofline":     dominant kernel (conv_igemm_f32 instantiation with the largest total time),
+                  algorithmic FLOPs / HIP-event time on the launch stream vs the fp32 MFMA peak;
+  "cpu_baseline": the oracle (CPU restatement, kind "port") timed on this box's host cores on a
+                  bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GFLOP_PER_FRAME = 140.125          # 70.063 GMAC conv + conv-transpose
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
+BATCH = 16
+
+
+def build_generator(dev, ngf=64):
+    from animateportrait_amd import networks
+    torch.manual_seed(1234)
+    g = networks.define_G(3, 1, ngf, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02,
+                          [dev.index], div=3, disp=3)
+    return g.eval()
+
+
+def cpu_baseline(budget_s=15.0):
+    """Oracle generator forward on the host cores: bounded sample (B=4 batches until ~budget_s)."""
+    from oracle import generator as og
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
+    b = 4
+    args = generator_args(make_generator_inputs(b, seed=1234))
+    with torch.no_grad():
+        og.generator_forward(sd, *args, div=3, disp=3)          # warm-up (oneDNN primitive creation)
+        t0 = time.time()
+        n = 0
+        while True:
+            og.generator_forward(sd, *args, div=3, disp=3)
+            n += b
+            if time.time() - t0 > budget_s or n >= 64:
+                break
+        dt = time.time() - t0
+    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'sample': 'oracle.generator_forward ngf=64 fp32, %d frames in batches of %d (%.1f s), torch CPU %d threads'
+                      % (n, b, dt, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    from animateportrait_amd import ops
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    G = build_generator(dev)
+    args = [t.to(dev) for t in generator_args(make_generator_inputs(BATCH, seed=1234, rank=rank))]
+
+    def step():
+        with torch.no_grad():
+            return G(*args)
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        y = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(y).all())
+
+    # ---- per-kernel attribution: every conv launch bracketed by events on the launch stream
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    psteps = min(a.steps, 5)
+    for _ in range(psteps):
+        step()
+    ops.PROFILER = None
+    agg = prof.summary()
+    dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
+    dname, dk = dom
+    ach = dk['flops'] / (dk['ms'] * 1e-3) / 1e12
+    roofline = {'bound': 'mfma', 'kernel': 'conv_igemm_f32<%s>' % dname,
+                'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                'launches_per_step': dk['launches'] // psteps,
+                'avg_launch_us': round(dk['ms'] * 1e3 / dk['launches'], 2),
+                'gflop_per_launch': round(dk['flops'] / dk['launches'] / 1e9, 3),
+                'conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / psteps, 3),
+                'traffic': None}
+    tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            roofline['traffic'] = json.load(open(tpath)).get(dname)
+        except Exception:
+            pass
+
+    if rank == 0:
+        fps = world * BATCH * a.steps / dt
+        out = {'metric': 'generator frames/sec @256x256 bs=16', 'value': round(fps, 2), 'unit': 'frames/s',
+               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+               'data': 'synthetic',
+               'config': {'workload': 'Module2 generator resnet_9blocks_rcatland32_full_ifw fwd-only, ngf=64, '
+                                      'bs=16/GPU, 256x256, fp32 (BASELINE configs[1])',
+                          'global_batch': BATCH * world, 'parallelism': 'dp%d (frame batches sharded, no collective)' % world,
+                          'weights': 'random init N(0,0.02), seed 1234'},
+               'conv_roofline_frac': round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+               'roofline': roofline}
+        if not a.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline()
+            out['speedup_vs_cpu'] = round(fps / out['cpu_baseline']['value'], 1)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,128 @@
+/*
+ * animateportrait_amd.h -- C ABI of the MI355X (gfx950) kernels behind the
+ * Module2 generator / discriminator hot path of AnimatePortrait.
+ *
+ * The reference has no FFI of its own (it is pure Python on stock PyTorch
+ * ops); the seam is the set of ATen ops its nn.Modules
+ * launch.  Each entry point below names the reference call it stands in for
+ * (paths relative to /root/reference/).  The Python host side
+ * (animateportrait_amd/_capi.py, ops.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous fp32 NCHW tensors unless
+ *     stated otherwise; the CALLER allocates and owns every buffer, including
+ *     packed weights, statistics partials and workspaces;
+ *   - every function only enqueues work on `stream` (a hipStream_t passed as
+ *     void*); nothing synchronises, nothing allocates;
+ *   - return value: 0 = ok, negative = error (message: ap_last_error(),
+ *     thread-local); no C++ exception crosses the boundary;
+ *   - no global mutable state apart from one-time kernel attribute setup,
+ *     so calls on distinct streams are thread-safe.
+ */
+#ifndef ANIMATEPORTRAIT_AMD_H
+#define ANIMATEPORTRAIT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* ap_stream_t; /* hipStream_t */
+
+enum { AP_OK = 0, AP_ERR_INVALID = -1, AP_ERR_UNSUPPORTED = -2, AP_ERR_LAUNCH = -3 };
+enum { AP_ACT_NONE = 0, AP_ACT_RELU = 1, AP_ACT_LRELU = 2 /* slope 0.2 */, AP_ACT_TANH = 3 };
+enum { AP_PAD_ZERO = 0, AP_PAD_REFLECT = 1 };
+enum { AP_W_OIHW = 0 /* nn.Conv2d weight */, AP_W_IOHW = 1 /* nn.ConvTranspose2d weight */ };
+
+/* One channel segment of a (virtually concatenated) convolution input.  The
+ * loader applies, per element, x := act((x - mean[n,c]) * rstd[n,c]) when
+ * mean/rstd are given: this is how InstanceNorm2d+ReLU/LeakyReLU of the
+ * PRODUCER layer is fused into the CONSUMER convolution, and how torch.cat
+ * (Module2/models/networks.py:1330,1335) is executed without a copy. */
+typedef struct ap_src {
+    const float* data;  /* N x C x H x W */
+    const float* mean;  /* N*C, or NULL */
+    const float* rstd;  /* N*C, or NULL */
+    int32_t C;
+    int32_t act;        /* AP_ACT_NONE / RELU / LRELU, applied after the normalisation */
+} ap_src;
+
+/* Descriptor of one convolution-like operator.
+ *   transposed = 0: nn.Conv2d(Cin, Cout, (KH,KW), stride, pad) with zero or
+ *                   reflection padding (nn.ReflectionPad2d fused);
+ *   transposed = 1: nn.ConvTranspose2d(Cin, Cout, k, stride=2, pad, output_padding).
+ * Cin is the sum of the segments' C.  w_layout / w_flip describe how the
+ * operator's taps index the caller's weight tensor, which lets the same kernel
+ * run the data-gradient of a convolution (swap roles, flip taps). */
+typedef struct ap_conv_desc {
+    int32_t N, H, W;      /* input batch / height / width */
+    int32_t Cout;
+    int32_t KH, KW;
+    int32_t stride;       /* 1 or 2 */
+    int32_t pad;
+    int32_t pad_mode;     /* AP_PAD_* (reflect only for transposed = 0) */
+    int32_t transposed;
+    int32_t output_padding;
+    int32_t w_layout;     /* AP_W_* : memory layout of the weight passed to ap_conv2d_pack_weights */
+    int32_t w_flip;       /* 1: use tap (KH-1-ky, KW-1-kx) */
+    int32_t act;          /* epilogue activation after bias: AP_ACT_NONE / LRELU / TANH / RELU */
+    int32_t nsrc;         /* 1..3 */
+    int32_t reserved;
+    ap_src src[3];
+} ap_conv_desc;
+
+const char* ap_version(void);
+const char* ap_last_error(void);
+
+/* ---- convolution: nn.Conv2d / nn.ConvTranspose2d (+ fused pad, bias, act, IN statistics)
+ * replaces F.conv2d / F.conv_transpose2d / F.pad(reflect) launched by
+ *   Module2/models/networks.py:1218-1282 (generator layers),
+ *   :2329-2361, :2390-2421 (ResnetBlock, ResnetBlock2),
+ *   :2620-2643 (NLayerDiscriminator). */
+int ap_conv2d_out_size(const ap_conv_desc* d, int32_t* Hout, int32_t* Wout);
+/* number of floats of the packed-weight buffer the caller must provide */
+int64_t ap_conv2d_packed_floats(const ap_conv_desc* d);
+/* number of partial (sum, sumsq) tiles per (n, cout) written by ap_conv2d_fwd: stats buffer
+ * is N * Cout * tiles * 2 floats */
+int32_t ap_conv2d_stat_tiles(const ap_conv_desc* d);
+/* re-lay the weight (layout d->w_layout, Cout/Cin/KH/KW from d) for the kernel's LDS image */
+int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* packed, ap_stream_t stream);
+/* y = act(conv(src...) + bias); bias may be NULL; stat_partials may be NULL.
+ * When stat_partials != NULL the epilogue also writes per-tile sum / sum of squares of the
+ * pre-activation output for every (n, cout) (InstanceNorm2d statistics, networks.py:33-34). */
+int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
+                  float* stat_partials, ap_stream_t stream);
+
+/* name of the conv_igemm_f32 instantiation the plan selects for `d` (as it appears, demangled, in a
+ * rocprofv3 kernel trace), e.g. "ci4_s1_e2_co128_th4"; used by bench.py to attribute time per kernel */
+int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen);
+
+/* ---- InstanceNorm2d(affine=False, eps) : networks.py:33-34 (F.instance_norm)
+ * finalize: partial tiles -> mean[n,c], rstd[n,c] (biased variance); count = Hout*Wout */
+int ap_instnorm_finalize(const float* stat_partials, int32_t NC, int32_t tiles, int32_t count,
+                         float eps, float* mean, float* rstd, ap_stream_t stream);
+/* out = act((x - mean) * rstd) + residual, where residual is
+ *   NULL, a plain tensor (res_mean == NULL), or itself normalised: (res - res_mean) * res_rstd.
+ * Covers `x + conv_block(x)` (networks.py:2358-2360) and `shortcut(x) + conv_block(x)` (:2418-2420).
+ * HW = H*W, NC = N*C. */
+int ap_instnorm_apply(const float* x, const float* mean, const float* rstd, int32_t act,
+                      const float* res, const float* res_mean, const float* res_rstd,
+                      float* out, int32_t NC, int32_t HW, ap_stream_t stream);
+
+/* ---- double_feature_warping : networks.py:1298-1313 + intrinsic_flow_models/modules.py:596-625
+ * out[:, 0:C]  = grid_sample(x, motion_L)                         (bilinear, zeros, align_corners=False)
+ * out[:, C:2C] = where(mask_L > 0.5, grid_sample(x, grid(flow_L)), -1)
+ * with motion_L / flow_L / mask_L the align_corners=True bilinear resizes of the full-resolution
+ * motion (N,S,S,2) / flow/2^level (N,2,S,S) / ifmask (N,1,S,S) to x's H x W, computed on the fly.
+ * x may be a raw conv output with (mean, rstd, act) applied per tap (act(IN(x)) is what is sampled). */
+int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                       const float* motion, const float* flow, const float* ifmask,
+                       float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
+                       float flow_scale, ap_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
