@@ -37,15 +37,36 @@ def build_generator(dev, ngf=64):
     return g.eval()
 
 
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota, and counted as
+    physical cores (one thread per core: oneDNN convolutions do not gain from SMT siblings)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    try:
+        import subprocess
+        out = subprocess.run(['lscpu', '-p=CORE,SOCKET'], capture_output=True, text=True, timeout=5).stdout
+        phys = len({l for l in out.splitlines() if l and not l.startswith('#')})
+        if phys:
+            n = min(n, phys)
+    except Exception:
+        pass
+    forced = os.environ.get('APAMD_CPU_THREADS')
+    return int(forced) if forced else n
+
+
 def cpu_baseline(budget_s=15.0):
     """Oracle generator forward on the host cores: bounded sample (B=4 batches until ~budget_s)."""
     from oracle import generator as og
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
     b = 4
@@ -125,6 +146,11 @@ def main():
         step()
     ops.PROFILER = None
     agg = prof.summary()
+    if rank == 0 and os.environ.get('APAMD_BENCH_VERBOSE'):
+        for name, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
+            print('  %-34s launches/step %3d  ms/step %7.3f  TFLOP/s %6.1f' % (
+                name, v['launches'] // psteps, v['ms'] / psteps, v['flops'] / (v['ms'] * 1e-3) / 1e12),
+                file=sys.stderr)
     dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
     dname, dk = dom
     ach = dk['flops'] / (dk['ms'] * 1e-3) / 1e12
