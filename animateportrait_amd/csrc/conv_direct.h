@@ -1,0 +1,215 @@
+// conv_direct.h -- direct (VALU) convolution for layers with 1..4 output channels.
+//
+// The generator ends in ReflectionPad2d(3) + Conv2d(ngf, output_nc, 7) + Tanh with output_nc = 1
+// (drawing) or 3 (cartoon) (reference: Module2/models/networks.py:1277-1279).  With a single output
+// channel an MFMA tile would be 31/32 padding, so this layer runs on the vector ALUs instead: every
+// lane owns a 1 x 4 strip of output pixels, the input tile (with halo) is staged through LDS once per
+// channel chunk with the same fused loader as the implicit-GEMM kernel (concat segments,
+// InstanceNorm + ReLU of the producer, reflection / zero padding), window rows are read as aligned
+// ds_read_b128 and the weights are wave-uniform scalars (s_load -> SGPR operands of v_fmac).
+#pragma once
+#include "conv_igemm.h"
+
+namespace apamd {
+
+struct DirectKParams {
+    SrcSeg seg[kMaxSeg];
+    int nseg;
+    int N, H, W, Cout, OH, OW, pad, pad_mode;
+    float* y;
+    const float* wp;     // [cin_pad][K][K][COP]
+    const float* bias;
+    int act;
+    float* stats;        // [N][Cout][stat_tiles][2] or null
+    int stat_tiles;
+    int nchunks, cin_pad, tiles_x, tiles_y;
+};
+
+template <int K_, int COP_>
+struct DirectCfg {
+    static constexpr int K = K_, COP = COP_;
+    static constexpr int CI = 4;
+    static constexpr int TH = 16, TW = 64;
+    static constexpr int R = K / 2;                      // halo (pad == R is required: 'same' convolution)
+    static constexpr int LPAD = (4 - R % 4) % 4;         // left padding so every strip window is 16-B aligned
+    static constexpr int IH = TH + K - 1;
+    static constexpr int IWS = ((LPAD + TW + K - 1) + 3) / 4 * 4;   // LDS row stride (floats)
+    static constexpr int PLANE = IH * IWS;
+    static constexpr int XE = CI * PLANE;
+    static constexpr int NV = (LPAD + 4 + K - 1 + 3) / 4;           // float4 reads per window row
+    static size_t lds_floats(int nbuf, int cin_pad) { return (size_t)nbuf * XE + 2 * (size_t)cin_pad + 64 * COP; }
+};
+
+template <class C>
+__global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
+    constexpr int K = C::K, COP = C::COP, CI = C::CI, IWS = C::IWS, PLANE = C::PLANE, XE = C::XE, NV = C::NV;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    int b = blockIdx.x;
+    const int tix = b % p.tiles_x; b /= p.tiles_x;
+    const int tiy = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int oy0 = tiy * C::TH, ox0 = tix * C::TW;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int nbuf = p.nchunks > 1 ? 2 : 1;
+    float* const xbuf = smem;
+    float* const s_mean = smem + nbuf * XE;
+    float* const s_rstd = s_mean + p.cin_pad;
+    float* const s_red = s_rstd + p.cin_pad;
+
+    auto seg_of = [&](int chunk) {
+        int s = 0;
+        if (p.nseg > 1 && chunk >= p.seg[1].chunk_begin) s = 1;
+        if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
+        return s;
+    };
+    for (int c = tid; c < p.cin_pad; c += 256) {
+        const int s = seg_of(c / CI);
+        const int cs = c - p.seg[s].chunk_begin * CI;
+        float m = 0.f, r = 1.f;
+        if (p.seg[s].mean != nullptr && cs < p.seg[s].C) {
+            m = p.seg[s].mean[n * p.seg[s].C + cs];
+            r = p.seg[s].rstd[n * p.seg[s].C + cs];
+        }
+        s_mean[c] = m;
+        s_rstd[c] = r;
+    }
+    __syncthreads();
+
+    // loader geometry, identical for every chunk: element e of [CI][IH][IWS]; column c <-> x = ox0 - pad - LPAD + c
+    constexpr int NE = (XE + 255) / 256;
+    int goff[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = tid + k * 256;
+        const int ci = e / PLANE;
+        const int r = e - ci * PLANE;
+        const int ly = r / IWS, lx = r - ly * IWS;
+        int gy = oy0 - p.pad + ly, gx = ox0 - p.pad - C::LPAD + lx;
+        bool ok = e < XE;
+        if (p.pad_mode == 1) {
+            gy = reflect_clamp(gy, H);
+            gx = reflect_clamp(gx, W);
+        } else {
+            ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        }
+        goff[k] = ok ? ci * HW + gy * W + gx : -1;
+    }
+    float xr[NE];
+    auto issue = [&](int chunk) {
+        const int s = seg_of(chunk);
+        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
+        const int cleft = p.seg[s].C - cbase;
+        const float* base = p.seg[s].data + ((long long)n * p.seg[s].C + cbase) * HW;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int ci = (tid + k * 256) / PLANE;
+            // unconditional load from a clamped (always legal) address: no branch, no per-element wait
+            const bool ok = goff[k] >= 0 && ci < cleft;
+            xr[k] = base[ok ? goff[k] : 0];
+        }
+    };
+    auto commit = [&](int chunk, float* dst) {
+        const int s = seg_of(chunk);
+        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
+        const int cleft = p.seg[s].C - cbase;
+        const bool norm = p.seg[s].mean != nullptr;
+        const int act = p.seg[s].act;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int e = tid + k * 256;
+            const int ci = e / PLANE;
+            float v = xr[k];
+            if (norm) v = (v - s_mean[chunk * CI + ci]) * s_rstd[chunk * CI + ci];
+            v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+            v = (goff[k] >= 0 && ci < cleft) ? v : 0.f;
+            if (e < XE) dst[e] = v;
+        }
+    };
+
+    float acc[COP][4];
+#pragma unroll
+    for (int c = 0; c < COP; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[c][j] = 0.f;
+
+    issue(0);
+    commit(0, xbuf);
+    __syncthreads();
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int cur = chunk & 1;
+        const bool more = chunk + 1 < p.nchunks;
+        if (more) issue(chunk + 1);
+        const float* X = xbuf + cur * XE + ty * IWS + tx * 4;
+        const float* wc = p.wp + (long long)chunk * CI * K * K * COP;
+#pragma unroll 1
+        for (int ci = 0; ci < CI; ++ci) {   // rolled: 49 weights per channel fit the SGPR file, 196 do not
+#pragma unroll
+            for (int ky = 0; ky < K; ++ky) {
+                float win[NV * 4];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(X + ci * PLANE + ky * IWS + v * 4);
+                    win[v * 4 + 0] = q.x; win[v * 4 + 1] = q.y; win[v * 4 + 2] = q.z; win[v * 4 + 3] = q.w;
+                }
+#pragma unroll
+                for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+                    for (int c = 0; c < COP; ++c) {
+                        const float w = wc[((ci * K + ky) * K + kx) * COP + c];   // wave-uniform -> SGPR
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w, win[C::LPAD + j + kx], acc[c][j]);
+                    }
+                }
+            }
+        }
+        if (more) commit(chunk + 1, xbuf + (cur ^ 1) * XE);
+        __syncthreads();
+    }
+
+    const int oy = oy0 + ty, ox = ox0 + tx * 4;
+#pragma unroll
+    for (int c = 0; c < COP; ++c) {
+        float s = 0.f, q2 = 0.f;
+        if (c < p.Cout) {
+            const float bv = p.bias ? p.bias[c] : 0.f;
+            float* dst = p.y + (((long long)n * p.Cout + c) * p.OH + oy) * p.OW + ox;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[c][j] + bv;
+                if (oy < p.OH && ox + j < p.OW) {
+                    s += v;
+                    q2 += v * v;
+                    dst[j] = apply_act(v, p.act);
+                }
+            }
+        }
+        if (p.stats != nullptr) {
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                s += __shfl_xor(s, sh, 64);
+                q2 += __shfl_xor(q2, sh, 64);
+            }
+            if ((tid & 63) == 0) {
+                s_red[((tid >> 6) * COP + c) * 2] = s;
+                s_red[((tid >> 6) * COP + c) * 2 + 1] = q2;
+            }
+        }
+    }
+    if (p.stats != nullptr) {
+        __syncthreads();
+        if (tid < p.Cout) {
+            float s = 0.f, q2 = 0.f;
+            for (int w = 0; w < 4; ++w) {
+                s += s_red[(w * COP + tid) * 2];
+                q2 += s_red[(w * COP + tid) * 2 + 1];
+            }
+            float* d = p.stats + (((long long)n * p.Cout + tid) * p.stat_tiles + tiy * p.tiles_x + tix) * 2;
+            d[0] = s;
+            d[1] = q2;
+        }
+    }
+}
+
+}  // namespace apamd

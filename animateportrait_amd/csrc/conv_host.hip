@@ -5,6 +5,7 @@
 // the weight packer so that the packed image and the kernel always agree.
 #include "common.h"
 #include "conv_registry.h"
+#include "conv_direct.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -27,19 +28,19 @@ static const std::vector<ConvKernelInfo>& registry() {
     static std::vector<ConvKernelInfo> v;
     static std::once_flag once;
     std::call_once(once, [] {
-        register_s1e1(v);
-        register_s1e2(v);
-        register_s1e3(v);
-        register_s1e6(v);
-        register_s2e2(v);
-        register_s2e3(v);
+        register_s1k0(v);
+        register_s1k3(v);
+        register_s1k4(v);
+        register_s1k7(v);
+        register_s2k3(v);
+        register_s2k4(v);
     });
     return v;
 }
 
-static const ConvKernelInfo* find_kernel(int CI, int S, int EXT, int CO_TILE) {
+static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
     for (const auto& k : registry())
-        if (k.CI == CI && k.S == S && k.EXT == EXT && k.CO_TILE == CO_TILE) return &k;
+        if (k.CI == CI && k.S == S && k.K == K && k.CO_TILE == CO_TILE) return &k;
     return nullptr;
 }
 
@@ -56,6 +57,7 @@ struct Launch {
 
 struct Plan {
     const ConvKernelInfo* k = nullptr;
+    int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
     std::vector<Launch> launches;
     int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
     int chunk_begin[kMaxSeg] = {0, 0, 0};
@@ -74,11 +76,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     if (d->N < 1 || d->H < 1 || d->W < 1 || d->Cout < 1) return fail(AP_ERR_INVALID, "bad dims");
     if (d->KH != d->KW || d->KH < 1 || d->KH > 7) return fail(AP_ERR_UNSUPPORTED, "kernel %dx%d", d->KH, d->KW);
     const int K = d->KH;
-    int S, EXT;
+    int S, KT;   // kernel family: stride and dense tap count (0 = run-time taps)
     if (!d->transposed) {
         if (d->stride != 1 && d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "stride %d", d->stride);
         S = d->stride;
-        EXT = K - 1;
+        KT = K;
+        if (K != 3 && K != 4 && K != 7) return fail(AP_ERR_UNSUPPORTED, "kernel size %d (built: 3, 4, 7)", K);
         pl.Hout = (d->H + 2 * d->pad - K) / S + 1;
         pl.Wout = (d->W + 2 * d->pad - K) / S + 1;
         if (d->pad_mode == AP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
@@ -87,7 +90,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         if (d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "transposed conv needs stride 2");
         if (d->pad_mode != AP_PAD_ZERO) return fail(AP_ERR_UNSUPPORTED, "transposed conv with reflection pad");
         S = 1;
-        EXT = 1;
+        KT = 0;
         pl.Hout = (d->H - 1) * 2 - 2 * d->pad + K + d->output_padding;
         pl.Wout = (d->W - 1) * 2 - 2 * d->pad + K + d->output_padding;
     }
@@ -100,6 +103,20 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.Cin += d->src[s].C;
         if (d->src[s].C < minC) minC = d->src[s].C;
     }
+    // 1..4 output channels, 7x7 'same' convolution: vector-ALU direct kernel (conv_direct.h)
+    if (!d->transposed && d->stride == 1 && K == 7 && d->pad == 3 && d->Cout <= 4 && !env_int("APAMD_NO_DIRECT", 0)) {
+        pl.direct_cop = d->Cout == 1 ? 1 : 4;
+        const int ci = 4;
+        pl.nchunks = 0;
+        for (int s = 0; s < d->nsrc; ++s) {
+            pl.chunk_begin[s] = pl.nchunks;
+            pl.nchunks += (d->src[s].C + ci - 1) / ci;
+        }
+        pl.cin_pad = pl.nchunks * ci;
+        pl.packed_floats = (long long)pl.cin_pad * K * K * pl.direct_cop;
+        pl.stat_tiles = ((pl.Hout + 15) / 16) * ((pl.Wout + 63) / 64);
+        return AP_OK;
+    }
     // tile configuration by output width
     int co_tile = d->Cout >= 96 ? 128 : (d->Cout >= 48 ? 64 : 32);
     co_tile = env_int("APAMD_CONV_COTILE", co_tile);
@@ -111,8 +128,8 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     int ntaps_max = d->transposed ? ((K + 1) / 2) * ((K + 1) / 2) : K * K;
     const size_t lds_target = (size_t)env_int("APAMD_CONV_LDS_TARGET", 72 * 1024);
     for (;;) {
-        const ConvKernelInfo* k = find_kernel(ci, S, EXT, co_tile);
-        if (!k) return fail(AP_ERR_UNSUPPORTED, "no kernel for CI=%d S=%d EXT=%d CO_TILE=%d", ci, S, EXT, co_tile);
+        const ConvKernelInfo* k = find_kernel(ci, S, KT, co_tile);
+        if (!k) return fail(AP_ERR_UNSUPPORTED, "no kernel for CI=%d S=%d K=%d CO_TILE=%d", ci, S, KT, co_tile);
         int nch = 0;
         for (int s = 0; s < d->nsrc; ++s) nch += (d->src[s].C + ci - 1) / ci;
         size_t bytes = 4 * k->lds_floats(ntaps_max, nch > 1 ? 2 : 1, nch * ci);
@@ -126,7 +143,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     {
         int forced = env_int("APAMD_CONV_CI", 0);
         if (forced) {
-            const ConvKernelInfo* k = find_kernel(forced, S, EXT, co_tile);
+            const ConvKernelInfo* k = find_kernel(forced, S, KT, co_tile);
             if (k) { pl.k = k; ci = forced; }
         }
     }
@@ -240,16 +257,60 @@ __global__ void pack_weights_kernel(const PackParams p) {
     }
 }
 
+struct PackDirectParams {
+    const float* w;
+    float* out;
+    int Cin, Cout, K, layout, flip, COP, CI, nchunks;
+    int nseg, segC[kMaxSeg], chunk_begin[kMaxSeg];
+};
+
+// out[cin_pad][K][K][COP]
+__global__ void pack_direct_kernel(const PackDirectParams p) {
+    const int total = p.nchunks * p.CI * p.K * p.K * p.COP;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int co = idx % p.COP;
+        int t = idx / p.COP;
+        int kx = t % p.K; t /= p.K;
+        int ky = t % p.K; t /= p.K;
+        const int ci = t % p.CI;
+        const int chunk = t / p.CI;
+        int s = 0;
+        if (p.nseg > 1 && chunk >= p.chunk_begin[1]) s = 1;
+        if (p.nseg > 2 && chunk >= p.chunk_begin[2]) s = 2;
+        const int cs = (chunk - p.chunk_begin[s]) * p.CI + ci;
+        float v = 0.f;
+        if (cs < p.segC[s] && co < p.Cout) {
+            int cin = cs;
+            for (int j = 0; j < s; ++j) cin += p.segC[j];
+            if (p.flip) { ky = p.K - 1 - ky; kx = p.K - 1 - kx; }
+            const long long off = p.layout == AP_W_OIHW ? (((long long)co * p.Cin + cin) * p.K + ky) * p.K + kx
+                                                        : (((long long)cin * p.Cout + co) * p.K + ky) * p.K + kx;
+            v = p.w[off];
+        }
+        p.out[idx] = v;
+    }
+}
+
+static const void* direct_fn(int K, int cop) {
+    if (K == 7 && cop == 1) return reinterpret_cast<const void*>(&conv_direct_f32<DirectCfg<7, 1>>);
+    if (K == 7 && cop == 4) return reinterpret_cast<const void*>(&conv_direct_f32<DirectCfg<7, 4>>);
+    return nullptr;
+}
+static size_t direct_lds_bytes(int K, int cop, int nbuf, int cin_pad) {
+    if (cop == 1) return 4 * DirectCfg<7, 1>::lds_floats(nbuf, cin_pad);
+    return 4 * DirectCfg<7, 4>::lds_floats(nbuf, cin_pad);
+}
+
 static std::mutex g_attr_mu;
 static std::vector<const void*> g_attr_done;
 
-static int ensure_lds_attr(const ConvKernelInfo* k) {
+static int ensure_lds_attr(const void* fn) {
     std::lock_guard<std::mutex> lk(g_attr_mu);
     for (auto f : g_attr_done)
-        if (f == k->fn) return AP_OK;
-    hipError_t e = hipFuncSetAttribute(k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (f == fn) return AP_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    g_attr_done.push_back(k->fn);
+    g_attr_done.push_back(fn);
     return AP_OK;
 }
 
@@ -288,7 +349,11 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!buf || buflen < 1) return fail(AP_ERR_INVALID, "kernel_name: bad buffer");
-    snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->EXT, pl.k->WCO, pl.k->MT,
+    if (pl.direct_cop) {
+        snprintf(buf, buflen, "DirectCfg<%d, %d>", d->KH, pl.direct_cop);
+        return AP_OK;
+    }
+    snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->K, pl.k->WCO, pl.k->MT,
              pl.k->WPX, pl.k->NT);
     return AP_OK;
 }
@@ -298,6 +363,16 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!weight || !packed) return fail(AP_ERR_INVALID, "null weight/packed pointer");
+    if (pl.direct_cop) {
+        PackDirectParams p;
+        memset(&p, 0, sizeof(p));
+        p.w = weight; p.out = packed;
+        p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout; p.flip = d->w_flip;
+        p.COP = pl.direct_cop; p.CI = 4; p.nchunks = pl.nchunks; p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
+        hipLaunchKernelGGL(pack_direct_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("pack_direct_kernel");
+    }
     for (const auto& L : pl.launches) {
         PackParams p;
         memset(&p, 0, sizeof(p));
@@ -331,8 +406,29 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
     }
-    rc = ensure_lds_attr(pl.k);
+    rc = ensure_lds_attr(pl.direct_cop ? direct_fn(d->KH, pl.direct_cop) : pl.k->fn);
     if (rc) return rc;
+    if (pl.direct_cop) {
+        DirectKParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) {
+            p.seg[s].data = d->src[s].data; p.seg[s].mean = d->src[s].mean; p.seg[s].rstd = d->src[s].rstd;
+            p.seg[s].C = d->src[s].C; p.seg[s].act = d->src[s].act; p.seg[s].chunk_begin = pl.chunk_begin[s];
+        }
+        p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout; p.OH = pl.Hout; p.OW = pl.Wout;
+        p.pad = d->pad; p.pad_mode = d->pad_mode;
+        p.y = y; p.wp = packed; p.bias = bias; p.act = d->act;
+        p.stats = stat_partials; p.stat_tiles = pl.stat_tiles;
+        p.nchunks = pl.nchunks; p.cin_pad = pl.cin_pad;
+        p.tiles_x = (pl.Wout + 63) / 64; p.tiles_y = (pl.Hout + 15) / 16;
+        const size_t lds = direct_lds_bytes(d->KH, pl.direct_cop, p.nchunks > 1 ? 2 : 1, p.cin_pad);
+        void* args[] = {&p};
+        hipError_t e = hipLaunchKernel(direct_fn(d->KH, pl.direct_cop), dim3((unsigned)(d->N * p.tiles_y * p.tiles_x)),
+                                       dim3(256), args, lds, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_direct_f32 launch: %s", hipGetErrorString(e));
+        return AP_OK;
+    }
     for (const auto& L : pl.launches) {
         ConvKParams p;
         memset(&p, 0, sizeof(p));
@@ -364,8 +460,13 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         p.tiles_x = L.tiles_x; p.tiles_y = L.tiles_y; p.co_tiles = pl.co_tiles;
         p.cin_pad = pl.cin_pad;
         p.wfloats = pl.k->wfloats(p.ntaps);
-        const int IW = 31 * pl.k->S + pl.k->EXT + 1;
-        for (int t = 0; t < p.ntaps; ++t) p.tap_off[t] = L.taps[t].ly * IW + L.taps[t].lx;
+        p.ablate = env_int("APAMD_ABLATE", 0);
+        p.tap_bits = 0;
+        if (pl.k->K == 0) {
+            if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);
+            for (int t = 0; t < p.ntaps; ++t)
+                p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
+        }
         const size_t lds = 4 * pl.k->lds_floats(p.ntaps, p.nchunks > 1 ? 2 : 1, p.cin_pad);
         const long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
         if (nblk > 0x7fffffffLL) return fail(AP_ERR_UNSUPPORTED, "grid too large");

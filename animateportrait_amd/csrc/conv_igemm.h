@@ -64,12 +64,16 @@ struct ConvKParams {
     int tiles_x, tiles_y, co_tiles;
     int cin_pad;          // nchunks * CI
     int wfloats;          // floats of one packed (co_tile, chunk) weight block, padded to 256
-    int tap_off[kMaxTaps];  // LDS offset (ly*IW + lx) of each tap
+    int ablate;           // debugging/ablation only (APAMD_ABLATE): 1 no refill, 2 no barrier, 4 MFMA-only, 8 no epilogue
+    unsigned tap_bits;    // K == 0 kernels only (sub-pixel phases, <= 4 taps): bit 2t = ly, bit 2t+1 = lx of tap t
 };
 
-template <int CI_, int S_, int EXT_, int WCO_, int MT_, int WPX_, int NT_>
+// K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a
+// 2 x 2 window given at run time (the sub-pixel phases of a stride-2 transposed convolution).
+template <int CI_, int S_, int K_, int WCO_, int MT_, int WPX_, int NT_>
 struct ConvCfg {
-    static constexpr int CI = CI_, S = S_, EXT = EXT_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
+    static constexpr int CI = CI_, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
+    static constexpr int EXT = K_ > 0 ? K_ - 1 : 1;
     static constexpr int TH = WPX * NT;
     static constexpr int CO_TILE = WCO * MT * 32;
     static constexpr int IH = (TH - 1) * S + EXT + 1;
@@ -77,6 +81,9 @@ struct ConvCfg {
     static constexpr int PLANE = IH * IW;
     static constexpr int XE = CI * PLANE;
     static constexpr int NE = (XE + 255) / 256;
+    // waves per SIMD the register allocator must leave room for (3 x 4-wave workgroups per CU when the
+    // accumulator tile is 4 x 16 registers; LDS is sized on the host to match)
+    static constexpr int MINW = (MT * NT <= 4 && NE <= 6) ? 3 : (NE <= 24 ? 2 : 1);
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(CI % 2 == 0, "channel chunk must hold whole (ci, ci+1) pairs");
     // dynamic LDS floats for `ntaps` taps, `nbuf` (1 or 2) pipeline buffers, cin_pad channels
@@ -109,7 +116,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 template <class C>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvKParams p) {
+__global__ __launch_bounds__(256, C::MINW) void conv_igemm_f32(const ConvKParams p) {
     constexpr int CI = C::CI, S = C::S, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, XE = C::XE, NE = C::NE, CO_TILE = C::CO_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -255,56 +262,93 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvKParams p) {
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int cur = chunk & 1;
         const bool more = chunk + 1 < p.nchunks;
-        if (more) {
+        // Refill of the other pipeline buffer.  On the dense path both halves are placed INSIDE the MFMA
+        // stream (loads right after the first step, normalise + ds_write three quarters through), so
+        // their VALU/VMEM/DS issue slots hide under the 64-cycle MFMAs instead of serialising with them.
+        const bool refill = more && !(p.ablate & 1);
+        if (C::K == 0 && refill) {
             issue_x(chunk + 1);
             issue_w(chunk + 1, wbuf + (cur ^ 1) * wfloats);
         }
         const float* Wc = wbuf + cur * wfloats + a_lane;
         const float* Xc = xbuf + cur * XE + b_lane;
 
-        // software-pipelined operand fetch: operands of step s+1 are read before the MFMAs of step s
-        float a_cur[MT], b_cur[NT], a_nxt[MT], b_nxt[NT];
-        {
-            const int toff = p.tap_off[0];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a_cur[m] = Wc[m * 32];
-#pragma unroll
-            for (int q = 0; q < NT; ++q) b_cur[q] = Xc[toff + q * S * IW];
-        }
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = p.tap_off[t];
-            const int tn = t + 1 < p.ntaps ? t + 1 : t;
-            const int toff_n = p.tap_off[tn];
-            const float* wt = Wc + t * (CI * CO_TILE);
-            const float* wtn = Wc + tn * (CI * CO_TILE);
-#pragma unroll
-            for (int cp = 0; cp < CI / 2; ++cp) {
-                if (cp + 1 < CI / 2) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) a_nxt[m] = wt[(cp + 1) * 2 * CO_TILE + m * 32];
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) b_nxt[q] = Xc[toff + (cp + 1) * 2 * PLANE + q * S * IW];
-                } else {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) a_nxt[m] = wtn[m * 32];
-#pragma unroll
-                    for (int q = 0; q < NT; ++q) b_nxt[q] = Xc[toff_n + q * S * IW];
-                }
+        if (p.ablate & 4) {
+            float a0 = Wc[0], b0 = Xc[0];
+            for (int s = 0; s < p.ntaps * (CI / 2); ++s) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m], b_cur[q], acc[m][q], 0, 0, 0);
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[m][q], 0, 0, 0);
+            }
+        } else if constexpr (C::K > 0) {
+            // Dense taps: fully unrolled, LDS offsets are instruction immediates.  Operands of step s+1
+            // are fetched into the other register set BEFORE the MFMAs of step s are issued, and the
+            // interleave {MT+NT ds_reads, MT*NT MFMAs} is pinned, so that one wave alone keeps its
+            // SIMD's matrix pipe busy (fp32 MFMA: 64 cycles each, LDS latency < one step).
+            // Large kernels (7x7) keep the row loop rolled: one row of taps = K * CI/2 pipelined steps.
+            constexpr int ROWS_UNROLLED = (C::K <= 4) ? C::K : 1;
+            constexpr int NS = ROWS_UNROLLED * C::K * (CI / 2);
+            for (int ky0 = 0; ky0 < C::K; ky0 += ROWS_UNROLLED) {
+                const float* Wr = Wc + ky0 * (C::K * CI * CO_TILE);
+                const float* Xr = Xc + ky0 * IW;
+                float a[2][MT], b[2][NT];
+                auto fetch = [&](int s, float* av, float* bv) {
+                    const int t = s / (CI / 2), cp = s % (CI / 2);
+                    const int toff = (t / C::K) * IW + (t % C::K);
 #pragma unroll
-                for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+                    for (int m = 0; m < MT; ++m) av[m] = Wr[(t * CI + cp * 2) * CO_TILE + m * 32];
 #pragma unroll
-                for (int q = 0; q < NT; ++q) b_cur[q] = b_nxt[q];
+                    for (int q = 0; q < NT; ++q) bv[q] = Xr[toff + cp * 2 * PLANE + q * S * IW];
+                };
+                fetch(0, a[0], b[0]);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s + 1 < NS) fetch(s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][m], b[s & 1][q], acc[m][q], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);   // DS reads of step s+1
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NT, 0);   // MFMAs of step s
+                    if (s == 0 && ky0 == 0 && refill) {
+                        issue_x(chunk + 1);
+                        issue_w(chunk + 1, wbuf + (cur ^ 1) * wfloats);
+                    }
+                    if (s == (C::K <= 4 ? (NS * 3) / 4 : NS - 1) && ky0 == (C::K <= 4 ? 0 : C::K - 2) && refill)
+                        commit_x(chunk + 1, xbuf + (cur ^ 1) * XE);
+                }
+            }
+        } else {
+            for (int t = 0; t < p.ntaps; ++t) {
+                const unsigned tb = p.tap_bits >> (2 * t);
+                const int toff = (int)(tb & 1u) * IW + (int)((tb >> 1) & 1u);
+                const float* wt = Wc + t * (CI * CO_TILE);
+#pragma unroll
+                for (int cp = 0; cp < CI / 2; ++cp) {
+                    float a[MT], b[NT];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) a[m] = wt[cp * 2 * CO_TILE + m * 32];
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) b[q] = Xc[toff + cp * 2 * PLANE + q * S * IW];
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int q = 0; q < NT; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[q], acc[m][q], 0, 0, 0);
+                }
             }
         }
-        if (more) commit_x(chunk + 1, xbuf + (cur ^ 1) * XE);
-        __syncthreads();
+        if (C::K == 0 && refill) commit_x(chunk + 1, xbuf + (cur ^ 1) * XE);
+        if (!(p.ablate & 2)) __syncthreads();
     }
 
+    if (p.ablate & 8) {
+        if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
+        return;
+    }
     // ---- epilogue: bias, statistics, activation, store.
     // MFMA 32x32 C/D layout: column j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * half.
     float* sred = smem;  // [WPX][CO_TILE][2], safe: all waves passed the final barrier
@@ -369,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvKParams p) {
 typedef void (*ConvKernelFn)(const ConvKParams);
 
 struct ConvKernelInfo {
-    int CI, S, EXT, WCO, MT, WPX, NT;
+    int CI, S, K, EXT, WCO, MT, WPX, NT;
     int TH, CO_TILE, XE;
     const void* fn;
     size_t (*lds_floats)(int, int, int);
@@ -379,7 +423,7 @@ struct ConvKernelInfo {
 template <class C>
 ConvKernelInfo make_info() {
     ConvKernelInfo k;
-    k.CI = C::CI; k.S = C::S; k.EXT = C::EXT; k.WCO = C::WCO; k.MT = C::MT; k.WPX = C::WPX; k.NT = C::NT;
+    k.CI = C::CI; k.S = C::S; k.K = C::K; k.EXT = C::EXT; k.WCO = C::WCO; k.MT = C::MT; k.WPX = C::WPX; k.NT = C::NT;
     k.TH = C::TH; k.CO_TILE = C::CO_TILE; k.XE = C::XE;
     k.fn = reinterpret_cast<const void*>(&conv_igemm_f32<C>);
     k.lds_floats = &C::lds_floats;

@@ -1,0 +1,5 @@
+// conv_igemm_f32 instantiations: stride 2, 3x3 taps (see conv_registry.h)
+#include "conv_registry.h"
+namespace apamd {
+void register_s2k3(std::vector<ConvKernelInfo>& v) { APAMD_REGISTER_ALL(2, 3) }
+}  // namespace apamd

@@ -12,21 +12,21 @@ namespace apamd {
 #define APAMD_CFG_B 1, 2, 4, 2
 #define APAMD_CFG_C 1, 1, 4, 2
 
-void register_s1e1(std::vector<ConvKernelInfo>&);
-void register_s1e2(std::vector<ConvKernelInfo>&);
-void register_s1e3(std::vector<ConvKernelInfo>&);
-void register_s1e6(std::vector<ConvKernelInfo>&);
-void register_s2e2(std::vector<ConvKernelInfo>&);
-void register_s2e3(std::vector<ConvKernelInfo>&);
+void register_s1k0(std::vector<ConvKernelInfo>&);
+void register_s1k3(std::vector<ConvKernelInfo>&);
+void register_s1k4(std::vector<ConvKernelInfo>&);
+void register_s1k7(std::vector<ConvKernelInfo>&);
+void register_s2k3(std::vector<ConvKernelInfo>&);
+void register_s2k4(std::vector<ConvKernelInfo>&);
 
-#define APAMD_REGISTER_ALL(S, EXT)                                            \
-    v.push_back(make_info<ConvCfg<2, S, EXT, APAMD_CFG_A>>());                \
-    v.push_back(make_info<ConvCfg<4, S, EXT, APAMD_CFG_A>>());                \
-    v.push_back(make_info<ConvCfg<8, S, EXT, APAMD_CFG_A>>());                \
-    v.push_back(make_info<ConvCfg<2, S, EXT, APAMD_CFG_B>>());                \
-    v.push_back(make_info<ConvCfg<4, S, EXT, APAMD_CFG_B>>());                \
-    v.push_back(make_info<ConvCfg<8, S, EXT, APAMD_CFG_B>>());                \
-    v.push_back(make_info<ConvCfg<2, S, EXT, APAMD_CFG_C>>());                \
-    v.push_back(make_info<ConvCfg<4, S, EXT, APAMD_CFG_C>>());                \
-    v.push_back(make_info<ConvCfg<8, S, EXT, APAMD_CFG_C>>());
+#define APAMD_REGISTER_ALL(S, K)                                            \
+    v.push_back(make_info<ConvCfg<2, S, K, APAMD_CFG_A>>());                \
+    v.push_back(make_info<ConvCfg<4, S, K, APAMD_CFG_A>>());                \
+    v.push_back(make_info<ConvCfg<8, S, K, APAMD_CFG_A>>());                \
+    v.push_back(make_info<ConvCfg<2, S, K, APAMD_CFG_B>>());                \
+    v.push_back(make_info<ConvCfg<4, S, K, APAMD_CFG_B>>());                \
+    v.push_back(make_info<ConvCfg<8, S, K, APAMD_CFG_B>>());                \
+    v.push_back(make_info<ConvCfg<2, S, K, APAMD_CFG_C>>());                \
+    v.push_back(make_info<ConvCfg<4, S, K, APAMD_CFG_C>>());                \
+    v.push_back(make_info<ConvCfg<8, S, K, APAMD_CFG_C>>());
 }  // namespace apamd

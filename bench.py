@@ -165,7 +165,9 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tpath):
         try:
-            roofline['traffic'] = json.load(open(tpath)).get(dname)
+            ent = json.load(open(tpath)).get(dname)
+            roofline['traffic'] = ent and ent.get('hbm_bytes_per_launch')
+            roofline['traffic_unit'] = 'bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/)'
         except Exception:
             pass
 

@@ -96,7 +96,7 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
                   float* stat_partials, ap_stream_t stream);
 
 /* name of the conv_igemm_f32 instantiation the plan selects for `d` (as it appears, demangled, in a
- * rocprofv3 kernel trace), e.g. "ci4_s1_e2_co128_th4"; used by bench.py to attribute time per kernel */
+ * rocprofv3 kernel trace), e.g. "ConvCfg<4, 1, 3, 2, 2, 2, 2>"; used by bench.py to attribute time per kernel */
 int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen);
 
 /* ---- InstanceNorm2d(affine=False, eps) : networks.py:33-34 (F.instance_norm)

@@ -171,6 +171,8 @@ CONV_CASES = [
     ([8, 16, 8], 130, 3, 1, 1, 'zero', False, 12, 70),
     ([3], 64, 7, 1, 3, 'reflect', False, 40, 40),
     ([16], 1, 7, 1, 3, 'reflect', False, 20, 50),
+    ([10, 6], 3, 7, 1, 3, 'reflect', False, 70, 33),
+    ([5], 2, 7, 1, 3, 'zero', False, 16, 130),
     ([12], 20, 3, 2, 1, 'zero', False, 37, 41),
     ([2], 64, 4, 2, 1, 'zero', False, 64, 64),
     ([24], 96, 4, 2, 1, 'zero', False, 30, 34),
