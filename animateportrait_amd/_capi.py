@@ -33,6 +33,13 @@ class ApConvDesc(ctypes.Structure):
                 ('src', ApSrc * 3)]
 
 
+class ApWgradDesc(ctypes.Structure):
+    _fields_ = [('N', ctypes.c_int32), ('M', ctypes.c_int32), ('GH', ctypes.c_int32), ('GW', ctypes.c_int32),
+                ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('K', ctypes.c_int32), ('stride', ctypes.c_int32),
+                ('pad', ctypes.c_int32), ('pad_mode', ctypes.c_int32), ('nsrc', ctypes.c_int32),
+                ('reserved', ctypes.c_int32), ('g', ApSrc), ('src', ApSrc * 3)]
+
+
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
 SIGNATURES = {
     'ap_version': (ctypes.c_char_p, []),
@@ -51,6 +58,17 @@ SIGNATURES = {
     'ap_warp_concat_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
+    'ap_conv2d_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.POINTER(ApWgradDesc)]),
+    'ap_conv2d_wgrad': (ctypes.c_int, [ctypes.POINTER(ApWgradDesc), c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_instnorm_bwd': (ctypes.c_int, [c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32,
+                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p,
+                                       ctypes.c_void_p]),
+    'ap_act_bwd': (ctypes.c_int, [c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
+                                  ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_bias_grad': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_warp_concat_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                          ctypes.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,199 @@
+"""Reverse pass of the generator / discriminator as an explicit schedule of HIP launches.
+
+The reference relies on torch.autograd over ATen ops (``loss.backward()``,
+Module2/models/geomgm_ifw_fore_model.py:586,610,634,780).  Here each network is ONE
+``torch.autograd.Function`` to PyTorch; inside, the forward records a tape of layer closures and the
+backward replays it in reverse, launching the data-gradient (the forward conv kernel with swapped
+roles), weight-gradient, InstanceNorm/activation-backward and warp-backward kernels of libapamd.so.
+PyTorch only carries the resulting tensors to the optimiser / the collective.
+"""
+import torch
+
+from . import ops
+from .ops import Feat, ConvSpec, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, W_OIHW, W_IOHW
+
+
+class Tape:
+    def __init__(self):
+        self.steps = []
+        self.grads = {}          # id(Feat) -> list of (tensor, pad)
+        self.keep = []           # keep Feats alive so ids stay unique
+        self.param_grads = {}    # Parameter -> tensor
+
+    def track(self, f):
+        self.grads[id(f)] = []
+        self.keep.append(f)
+        return f
+
+    def tracked(self, f):
+        return id(f) in self.grads
+
+    def add(self, f, tensor, pad=0):
+        if id(f) in self.grads:
+            self.grads[id(f)].append((tensor, pad))
+
+    def take(self, f):
+        return self.grads.pop(id(f), [])
+
+    def add_param(self, p, g):
+        if p in self.param_grads:
+            self.param_grads[p] = self.param_grads[p] + g
+        else:
+            self.param_grads[p] = g
+
+    def backward(self):
+        for fn in reversed(self.steps):
+            fn()
+        self.steps = []
+
+
+# ------------------------------------------------------------------------------ conv layer
+def _dgrad_spec(layer, seg_c):
+    """ConvSpec of the operator that computes the data gradient for one input segment."""
+    s = layer.spec
+    k = s.k
+    if s.transposed:      # ConvTranspose2d(k, s=2, p): gradient is a stride-2 convolution, weight read as OIHW
+        return ConvSpec([s.cout], seg_c, k, 2, s.pad, PAD_ZERO, False, 0, W_OIHW, False), 0
+    if s.stride == 1:     # full correlation with flipped taps; reflection-padded layers stay in padded coords
+        if s.pad_mode == PAD_REFLECT:
+            return ConvSpec([s.cout], seg_c, k, 1, k - 1, PAD_ZERO, False, 0, W_IOHW, True), s.pad
+        return ConvSpec([s.cout], seg_c, k, 1, k - 1 - s.pad, PAD_ZERO, False, 0, W_IOHW, True), 0
+    # stride 2: transposed convolution; output_padding restores the input size
+    return ConvSpec([s.cout], seg_c, k, 2, s.pad, PAD_ZERO, True, 1 if k == 3 else 0, W_IOHW, False), 0
+
+
+def conv_backward(tape, layer, srcs, out, norm, act):
+    """out: Feat produced by layer.run(srcs).  Consumes out's gradient contributions."""
+    contribs = tape.take(out)
+    if not contribs:
+        return
+    dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
+    s = layer.spec
+    gfeat = Feat(dy)
+    # ---- weight gradient
+    if layer.weight.requires_grad:
+        if s.transposed:
+            # dW[ci][co*k*k]: M-role = the layer input (virtual allowed), shifted tensor = dy (stride 2)
+            dw = ops.wgrad(s.k, 2, s.pad, PAD_ZERO, srcs[0], [gfeat], layer.weight.shape)
+        else:
+            dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape)
+        tape.add_param(layer.weight, dw)
+    if layer.bias.requires_grad:
+        # a bias in front of InstanceNorm has an exactly-zero gradient (it is removed by the mean subtraction)
+        tape.add_param(layer.bias, torch.zeros_like(layer.bias) if norm else ops.bias_grad(dy))
+    # ---- data gradients, one launch per input segment that needs one
+    c0 = 0
+    for i, f in enumerate(srcs):
+        c = s.cin_segments[i]
+        if tape.tracked(f):
+            spec, fold_pad = _dgrad_spec(layer, c)
+            w = layer.weight.detach()
+            if len(srcs) > 1:
+                w = (w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]).contiguous()
+            packed = layer.packed_dgrad(i, spec, w)
+            g = ops.conv2d(spec, [gfeat], packed, None).data
+            tape.add(f, g, fold_pad)
+        c0 += c
+
+
+def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE):
+    if not isinstance(srcs, (list, tuple)):
+        srcs = [srcs]
+    out = layer.run(srcs, norm_act=norm_act, act=act)
+    if tape is not None:
+        tape.track(out)
+        norm = norm_act is not None
+        tape.steps.append(lambda: conv_backward(tape, layer, srcs, out, norm, act))
+    return out
+
+
+def materialize_forward(tape, f, residual=None):
+    out = ops.materialize(f, residual=residual)
+    if tape is not None:
+        tape.track(out)
+
+        def bwd():
+            contribs = tape.take(out)
+            if not contribs:
+                return
+            g1, pad, g2 = ops._split_contribs(contribs)
+            g = g1 if (pad == 0 and g2 is None) else ops.fold_add(g1, pad, g2)
+            tape.add(f, g, 0)
+            if residual is not None:
+                tape.add(residual, g, 0)
+        tape.steps.append(bwd)
+    return out
+
+
+def warp_forward(tape, f, motion, flow, ifmask, level):
+    out = ops.warp_concat(f, motion, flow, ifmask, level)
+    if tape is not None:
+        tape.track(out)
+
+        def bwd():
+            contribs = tape.take(out)
+            if not contribs or not tape.tracked(f):
+                return
+            g1, pad, g2 = ops._split_contribs(contribs)
+            g = g1 if (pad == 0 and g2 is None) else ops.fold_add(g1, pad, g2)
+            tape.add(f, ops.warp_concat_bwd(g, motion, flow, ifmask, level), 0)
+        tape.steps.append(bwd)
+    return out
+
+
+def batch_split_forward(tape, f, b):
+    """l -> (l[:b], l[b:]) for the shared landmark encoder run on the stacked 2B batch."""
+    l1, l2 = f.batch_slice(0, b), f.batch_slice(b, 2 * b)
+    if tape is not None:
+        tape.track(l1)
+        tape.track(l2)
+
+        def bwd():
+            parts = []
+            for part in (l1, l2):
+                contribs = tape.take(part)
+                g1, pad, g2 = ops._split_contribs(contribs)
+                parts.append(g1 if (pad == 0 and g2 is None) else ops.fold_add(g1, pad, g2))
+            tape.add(f, torch.cat(parts, 0), 0)
+        tape.steps.append(bwd)
+    return l1, l2
+
+
+# ------------------------------------------------------------------------------ autograd.Function wrappers
+class _NetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, n_inputs, input_needs_grad, *tensors):
+        inputs, params = tensors[:n_inputs], tensors[n_inputs:]
+        tape = Tape()
+        with torch.no_grad():
+            out = net._run(tape, input_needs_grad, *inputs)
+        ctx.tape, ctx.net, ctx.out_feat = tape, net, out
+        ctx.n_inputs, ctx.params = n_inputs, params
+        ctx.in_feat = getattr(net, '_last_input_feat', None)
+        return out.data
+
+    @staticmethod
+    def backward(ctx, gout):
+        tape = ctx.tape
+        with torch.no_grad():
+            tape.add(ctx.out_feat, gout.contiguous(), 0)
+            tape.backward()
+            gin = [None] * ctx.n_inputs
+            if ctx.in_feat is not None and tape.tracked(ctx.in_feat):
+                contribs = tape.take(ctx.in_feat)
+                if contribs:
+                    g1, pad, g2 = ops._split_contribs(contribs)
+                    gin[0] = g1 if (pad == 0 and g2 is None) else ops.fold_add(g1, pad, g2)
+            gp = [tape.param_grads.get(p) for p in ctx.params]
+        ctx.tape = None
+        return (None, None, None, *gin, *gp)
+
+
+def generator_apply(net, input, land1, land2, motion, flow, ifmask):
+    params = [p for p in net.parameters()]
+    return _NetFn.apply(net, 6, False, input, land1, land2, motion, flow, ifmask, *params)
+
+
+def discriminator_apply(net, input):
+    params = [p for p in net.parameters()]
+    return _NetFn.apply(net, 1, bool(input.requires_grad), input, *params)

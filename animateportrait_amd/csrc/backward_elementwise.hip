@@ -1,0 +1,199 @@
+// backward_elementwise.hip -- the HBM-bound pieces of the backward pass.
+//
+// What autograd would launch for the reference's layers (Module2/models/networks.py:1218-1282,
+// 2329-2421, 2620-2643) as separate ATen kernels is fused here into four streaming kernels:
+//   * instnorm_bwd_reduce / instnorm_bwd_apply: backward of  a = act(IN(y))  w.r.t. y, where the
+//     incoming gradient may be (i) the data-gradient of a reflection-padded convolution, still in
+//     PADDED coordinates (the fold of nn.ReflectionPad2d's backward is done while reading), plus
+//     (ii) a second plain gradient (residual branch);
+//   * act_bwd: backward of a plain activation (LeakyReLU / tanh) for layers without normalisation;
+//   * bias_grad: per-channel sum of a gradient (layers whose bias is live: no InstanceNorm after them);
+//   * grad_fold_add: out = fold(a) + b  (residual stream accumulation).
+#include "common.h"
+
+namespace apamd {
+
+// gradient read with optional reflection fold: g has spatial (H+2p) x (W+2p)
+struct FoldReader {
+    const float* g;   // plane base
+    int H, W, p, Wp;
+    __device__ __forceinline__ float at(int y, int x) const {
+        if (p == 0) return g[y * W + x];
+        int ys[3], xs[3], ny = 0, nx = 0;
+        ys[ny++] = y + p;
+        if (y >= 1 && y <= p) ys[ny++] = p - y;
+        if (y >= H - 1 - p && y <= H - 2) ys[ny++] = 2 * (H - 1) - y + p;
+        xs[nx++] = x + p;
+        if (x >= 1 && x <= p) xs[nx++] = p - x;
+        if (x >= W - 1 - p && x <= W - 2) xs[nx++] = 2 * (W - 1) - x + p;
+        float s = 0.f;
+        for (int i = 0; i < ny; ++i)
+            for (int j = 0; j < nx; ++j) s += g[ys[i] * Wp + xs[j]];
+        return s;
+    }
+};
+
+__device__ __forceinline__ float act_grad_from_xhat(float xh, int act) {
+    if (act == 1) return xh > 0.f ? 1.f : 0.f;
+    if (act == 2) return xh > 0.f ? 1.f : 0.2f;
+    return 1.f;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) v += __shfl_xor(v, sh, 64);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    __syncthreads();
+    return s;
+}
+
+// grid: (N*C).  sums[nc] = (sum g', sum g' * xhat), g' = (fold(g1) + g2) * act'(xhat)
+__global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* __restrict__ g1, int p1,
+                                                                  const float* __restrict__ g2,
+                                                                  const float* __restrict__ y,
+                                                                  const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, int act, int H, int W,
+                                                                  float* __restrict__ sums) {
+    __shared__ float red[8];
+    const int nc = blockIdx.x;
+    const int HW = H * W;
+    const float m = mean[nc], r = rstd[nc];
+    FoldReader fr{g1 + (long long)nc * (H + 2 * p1) * (W + 2 * p1), H, W, p1, W + 2 * p1};
+    const float* yp = y + (long long)nc * HW;
+    const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const int yy = i / W, xx = i - yy * W;
+        const float xh = (yp[i] - m) * r;
+        float g = fr.at(yy, xx);
+        if (g2p) g += g2p[i];
+        g *= act_grad_from_xhat(xh, act);
+        s1 += g;
+        s2 += g * xh;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        sums[nc * 2] = s1;
+        sums[nc * 2 + 1] = s2;
+    }
+}
+
+// grid: (ceil(HW/256/4), N*C).  dy = rstd * (g' - S1/HW - xhat * S2/HW)
+__global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __restrict__ g1, int p1,
+                                                                 const float* __restrict__ g2,
+                                                                 const float* __restrict__ y,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, int act, int H, int W,
+                                                                 const float* __restrict__ sums,
+                                                                 float* __restrict__ dy) {
+    const int nc = blockIdx.y;
+    const int HW = H * W;
+    const float m = mean[nc], r = rstd[nc];
+    const float inv = 1.f / (float)HW;
+    const float a1 = sums[nc * 2] * inv, a2 = sums[nc * 2 + 1] * inv;
+    FoldReader fr{g1 + (long long)nc * (H + 2 * p1) * (W + 2 * p1), H, W, p1, W + 2 * p1};
+    const float* yp = y + (long long)nc * HW;
+    const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
+    float* out = dy + (long long)nc * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const int yy = i / W, xx = i - yy * W;
+        const float xh = (yp[i] - m) * r;
+        float g = fr.at(yy, xx);
+        if (g2p) g += g2p[i];
+        g *= act_grad_from_xhat(xh, act);
+        out[i] = r * (g - a1 - xh * a2);
+    }
+}
+
+// dy = (fold(g1) + g2) * act'(out): act 1 relu / 2 lrelu (sign of the ACTIVATED output) / 3 tanh (1 - out^2)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g1, int p1, const float* __restrict__ g2,
+                                                      const float* __restrict__ outv, int act, int H, int W,
+                                                      float* __restrict__ dy) {
+    const int nc = blockIdx.y;
+    const int HW = H * W;
+    FoldReader fr{g1 + (long long)nc * (H + 2 * p1) * (W + 2 * p1), H, W, p1, W + 2 * p1};
+    const float* op = outv ? outv + (long long)nc * HW : nullptr;
+    const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
+    float* out = dy + (long long)nc * HW;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const int yy = i / W, xx = i - yy * W;
+        float g = fr.at(yy, xx);
+        if (g2p) g += g2p[i];
+        if (act == 1) g = op[i] > 0.f ? g : 0.f;
+        else if (act == 2) g = op[i] > 0.f ? g : 0.2f * g;
+        else if (act == 3) g *= 1.f - op[i] * op[i];
+        out[i] = g;
+    }
+}
+
+// grid: (C).  db[c] = sum_{n, pix} dy[n, c, pix]
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ dy, int N, int C, int HW,
+                                                        float* __restrict__ db) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int n = 0; n < N; ++n) {
+        const float* p = dy + ((long long)n * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) db[c] = s;
+}
+
+}  // namespace apamd
+
+using namespace apamd;
+
+static int fold_args_ok(const float* g1, int p1, int H, int W, const char* who) {
+    if (!g1) return fail(AP_ERR_INVALID, "%s: null gradient", who);
+    if (p1 < 0 || (p1 > 0 && (p1 >= H || p1 >= W))) return fail(AP_ERR_INVALID, "%s: fold pad %d vs %dx%d", who, p1, H, W);
+    return AP_OK;
+}
+
+extern "C" {
+
+int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean,
+                    const float* rstd, int32_t act, int32_t NC, int32_t H, int32_t W, float* sums_ws, float* dy,
+                    ap_stream_t stream) {
+    int rc = fold_args_ok(g1, g1_pad, H, W, "instnorm_bwd");
+    if (rc) return rc;
+    if (!y || !mean || !rstd || !sums_ws || !dy) return fail(AP_ERR_INVALID, "instnorm_bwd: null pointer");
+    if (act < 0 || act > 2) return fail(AP_ERR_INVALID, "instnorm_bwd: act %d", act);
+    if (NC < 1 || NC > 65535) return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: N*C=%d", NC);
+    hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, y,
+                       mean, rstd, act, H, W, sums_ws);
+    rc = check_launch("instnorm_bwd_reduce_kernel");
+    if (rc) return rc;
+    int bx = (H * W + 1023) / 1024;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, y,
+                       mean, rstd, act, H, W, sums_ws, dy);
+    return check_launch("instnorm_bwd_apply_kernel");
+}
+
+int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,
+               int32_t H, int32_t W, float* dy, ap_stream_t stream) {
+    int rc = fold_args_ok(g1, g1_pad, H, W, "act_bwd");
+    if (rc) return rc;
+    if (!dy || (act != AP_ACT_NONE && !out)) return fail(AP_ERR_INVALID, "act_bwd: null pointer");
+    if (act < 0 || act > 3) return fail(AP_ERR_INVALID, "act_bwd: act %d", act);
+    if (NC < 1 || NC > 65535) return fail(AP_ERR_UNSUPPORTED, "act_bwd: N*C=%d", NC);
+    int bx = (H * W + 1023) / 1024;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, out, act, H, W,
+                       dy);
+    return check_launch("act_bwd_kernel");
+}
+
+int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, ap_stream_t stream) {
+    if (!dy || !db || N < 1 || C < 1 || HW < 1) return fail(AP_ERR_INVALID, "bias_grad: bad arguments");
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, N, C, HW, db);
+    return check_launch("bias_grad_kernel");
+}
+
+}  // extern "C"

@@ -135,9 +135,78 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
     }
 }
 
+// backward w.r.t. x only (motion / flow / mask carry no gradient: geomgm_ifw_fore_model.py:443-505 feeds
+// them as data).  dx must be zero on entry; taps are scattered with fp32 atomics (L2).
+__global__ __launch_bounds__(256) void warp_concat_bwd_kernel(const float* __restrict__ gout,
+                                                              const float* __restrict__ motion,
+                                                              const float* __restrict__ flow,
+                                                              const float* __restrict__ ifmask, float* __restrict__ dx,
+                                                              int C, int H, int W, int S, float flow_scale) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int n = blockIdx.z;
+    const int oy = pix / W, ox = pix - oy * W;
+    const long long SS = (long long)S * S;
+    float gx, gy, fx, fy, mk;
+    if (H == S && W == S) {
+        const float2 g = reinterpret_cast<const float2*>(motion)[n * SS + pix];
+        gx = g.x; gy = g.y;
+        fx = flow[(n * 2 + 0) * SS + pix] * flow_scale;
+        fy = flow[(n * 2 + 1) * SS + pix] * flow_scale;
+        mk = ifmask[n * SS + pix];
+    } else {
+        const Lerp ly = make_lerp(oy, S, H), lx = make_lerp(ox, S, W);
+        const int o00 = ly.i0 * S + lx.i0, o01 = ly.i0 * S + lx.i1, o10 = ly.i1 * S + lx.i0, o11 = ly.i1 * S + lx.i1;
+        const float2* mo = reinterpret_cast<const float2*>(motion) + n * SS;
+        const float2 a = mo[o00], b = mo[o01], c = mo[o10], d = mo[o11];
+        gx = bilerp(a.x, b.x, c.x, d.x, ly, lx);
+        gy = bilerp(a.y, b.y, c.y, d.y, ly, lx);
+        const float* f0 = flow + (n * 2 + 0) * SS;
+        const float* f1 = flow + (n * 2 + 1) * SS;
+        fx = bilerp(f0[o00] * flow_scale, f0[o01] * flow_scale, f0[o10] * flow_scale, f0[o11] * flow_scale, ly, lx);
+        fy = bilerp(f1[o00] * flow_scale, f1[o01] * flow_scale, f1[o10] * flow_scale, f1[o11] * flow_scale, ly, lx);
+        const float* mp = ifmask + n * SS;
+        mk = bilerp(mp[o00], mp[o01], mp[o10], mp[o11], ly, lx);
+    }
+    const Taps tm = make_taps(gx, gy, H, W);
+    const float wgx = 2.0f * ((float)ox + fx) / (float)(W - 1 > 1 ? W - 1 : 1) - 1.0f;
+    const float wgy = 2.0f * ((float)oy + fy) / (float)(H - 1 > 1 ? H - 1 : 1) - 1.0f;
+    const Taps tf = make_taps(wgx, wgy, H, W);
+    const bool keep = mk > 0.5f;
+    const int HW = H * W;
+    const int c0 = blockIdx.y * kWarpCG;
+    const int c1 = c0 + kWarpCG < C ? c0 + kWarpCG : C;
+    for (int c = c0; c < c1; ++c) {
+        float* plane = dx + ((long long)n * C + c) * HW;
+        const float g1 = gout[((long long)n * 2 * C + c) * HW + pix];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (tm.off[k] >= 0) atomicAdd(plane + tm.off[k], g1 * tm.w[k]);
+        if (keep) {
+            const float g2 = gout[((long long)n * 2 * C + C + c) * HW + pix];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (tf.off[k] >= 0) atomicAdd(plane + tf.off[k], g2 * tf.w[k]);
+        }
+    }
+}
+
 }  // namespace apamd
 
 using namespace apamd;
+
+extern "C" int ap_warp_concat_bwd(const float* gout, const float* motion, const float* flow, const float* ifmask,
+                                  float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale,
+                                  ap_stream_t stream) {
+    if (!gout || !motion || !flow || !ifmask || !dx) return fail(AP_ERR_INVALID, "warp_concat_bwd: null pointer");
+    if (N < 1 || C < 1 || H < 1 || W < 1 || S < 1 || N > 65535) return fail(AP_ERR_INVALID, "warp_concat_bwd: bad sizes");
+    hipError_t e = hipMemsetAsync(dx, 0, (size_t)N * C * H * W * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "warp_concat_bwd memset: %s", hipGetErrorString(e));
+    dim3 grid((H * W + 255) / 256, (C + kWarpCG - 1) / kWarpCG, N);
+    hipLaunchKernelGGL(warp_concat_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, gout, motion, flow, ifmask, dx,
+                       C, H, W, S, flow_scale);
+    return check_launch("warp_concat_bwd_kernel");
+}
 
 extern "C" int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
                                   const float* motion, const float* flow, const float* ifmask, float* out, int32_t N,

@@ -1,0 +1,220 @@
+// wgrad_igemm.h -- weight gradient of a convolution as an implicit GEMM over pixels (exact fp32 MFMA).
+//
+//   dW[m][q] = sum_{n, oy, ox} G[n][m][oy][ox] * A[n][ci][oy*S + ky - pad][ox*S + kx - pad],   q = ci*K*K + ky*K + kx
+//
+// For nn.Conv2d: G = gradient w.r.t. the conv output (m = cout), A = the conv's (virtual, possibly
+// concatenated) input, and dW[m][q] is exactly the OIHW weight-gradient tensor.  For
+// nn.ConvTranspose2d(k, s=2): G = the layer INPUT (m = cin), A = the gradient w.r.t. its output, S = 2, and
+// dW[m][q] is the IOHW tensor.  (What autograd computes for the layers of
+// Module2/models/networks.py:1218-1282, 2329-2421, 2620-2643.)
+//
+// GEMM mapping: M = m (lane = channel), N = q (lane = (ci, tap) with a per-lane precomputed LDS offset, so
+// any Cin / kernel size packs densely: the 7x7 stems with Cin = 3 use 147 of 160 columns), K = pixels:
+// the two half-waves hold two x-adjacent pixels.  Both operands are staged through LDS once per pixel
+// tile (PR rows x 32 columns); the shifted taps are reads of the same A tile (no im2col buffer).
+// Workgroup = 4 waves as 2 (m) x 2 (q), each wave MT x NT tiles of 32 x 32.  The pixel range is split
+// over P workgroups per (m, q) tile; partial results go to a workspace and are summed by a second
+// kernel in a fixed order (deterministic, no atomics).
+#pragma once
+#include "conv_igemm.h"
+
+namespace apamd {
+
+struct WgradKParams {
+    SrcSeg g;                 // M-role tensor (chunk_begin unused)
+    SrcSeg seg[kMaxSeg];      // N-role (shifted) tensor segments; chunk_begin = first concat channel
+    int nseg;
+    int N, M, Cin, Q;         // Q = Cin * K * K
+    int GH, GW;               // spatial size of the M-role tensor (grid that is iterated)
+    int H, W;                 // spatial size of the N-role tensor
+    int pad, pad_mode;
+    int tiles_x, tiles_y;     // pixel tiles per image
+    int nstages, P;           // total pixel tiles (N * tiles_y * tiles_x), number of splits
+    int m_tiles, q_tiles;
+    float* partial;           // [P][M][Q]
+};
+
+template <int S_, int K_, int MT_, int NT_, int PR_>
+struct WgradCfg {
+    static constexpr int S = S_, K = K_, MT = MT_, NT = NT_, PR = PR_;
+    static constexpr int T = K * K;
+    static constexpr int M_TILE = 2 * MT * 32, Q_TILE = 2 * NT * 32;
+    static constexpr int NPIX = PR * 32;
+    static constexpr int GS = NPIX + 1;                  // odd row stride of the G tile: conflict-free A reads
+    static constexpr int IH = (PR - 1) * S + K, IW = 31 * S + K;
+    static constexpr int PLANE = (IH * IW) | 1;          // odd plane stride
+    static constexpr int NCI = Q_TILE / T + 2;           // channels a q-tile can touch
+    static constexpr int GE = M_TILE * NPIX, AE = NCI * PLANE;
+    static constexpr int NG = (GE + 255) / 256, NA = (AE + 255) / 256;
+    static size_t lds_floats() { return 2 * ((size_t)M_TILE * GS + (size_t)NCI * PLANE); }
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void wgrad_igemm_f32(const WgradKParams p) {
+    constexpr int S = C::S, K = C::K, T = C::T, MT = C::MT, NT = C::NT, PR = C::PR;
+    constexpr int GS = C::GS, IW = C::IW, PLANE = C::PLANE, NCI = C::NCI, NG = C::NG, NA = C::NA;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const gbuf = smem;                                   // [2][M_TILE][GS]
+    float* const abuf = smem + 2 * C::M_TILE * GS;              // [2][NCI][PLANE]
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wm = wave & 1, wq = wave >> 1;
+    int b = blockIdx.x;
+    const int split = b % p.P; b /= p.P;
+    const int qt = b % p.q_tiles;
+    const int mt_ = b / p.q_tiles;
+    const int m0 = mt_ * C::M_TILE, q0 = qt * C::Q_TILE;
+    const int ci_lo = q0 / T;
+    int ci_hi = (q0 + C::Q_TILE - 1) / T;
+    if (ci_hi > p.Cin - 1) ci_hi = p.Cin - 1;
+    const int nci = ci_hi - ci_lo + 1;
+    const int st0 = (int)((long long)p.nstages * split / p.P), st1 = (int)((long long)p.nstages * (split + 1) / p.P);
+    const int GHW = p.GH * p.GW, HW = p.H * p.W;
+
+    // per-lane LDS offsets of this lane's NT columns (q -> channel plane + tap shift)
+    int boff[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int q = q0 + (wq * NT + t) * 32 + l32;
+        if (q >= p.Q) q = q0;                     // masked at the store; keep the address legal
+        const int ci = q / T, tap = q - ci * T;
+        boff[t] = (ci - ci_lo) * PLANE + (tap / K) * IW + (tap % K) + half * S;
+    }
+    const int aoff = (wm * MT * 32 + l32) * GS + half;
+
+    auto seg_of = [&](int c) {
+        int s = 0;
+        if (p.nseg > 1 && c >= p.seg[1].chunk_begin) s = 1;
+        if (p.nseg > 2 && c >= p.seg[2].chunk_begin) s = 2;
+        return s;
+    };
+
+    float gr[NG], ar[NA];
+    auto issue = [&](int st) {
+        const int tx = st % p.tiles_x;
+        int t2 = st / p.tiles_x;
+        const int ty = t2 % p.tiles_y;
+        const int n = t2 / p.tiles_y;
+        const int oy0 = ty * PR, ox0 = tx * 32;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {                         // G tile: [m][py][px]
+            const int e = tid + k * 256;
+            const int m = e / C::NPIX, r = e - m * C::NPIX;
+            const int oy = oy0 + r / 32, ox = ox0 + (r & 31);
+            const bool ok = e < C::GE && m0 + m < p.M && oy < p.GH && ox < p.GW;
+            const long long off = ((long long)n * p.M + (m0 + m)) * GHW + oy * p.GW + ox;
+            float v = p.g.data[ok ? off : 0];
+            if (p.g.mean != nullptr) {
+                const int mc = ok ? n * p.M + m0 + m : 0;
+                v = (v - p.g.mean[mc]) * p.g.rstd[mc];
+                v = p.g.act == 1 ? fmaxf(v, 0.f) : (p.g.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+            }
+            gr[k] = ok ? v : 0.f;
+        }
+        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {                         // A tile: [ci_local][ly][lx]
+            const int e = tid + k * 256;
+            const int cl = e / PLANE, r = e - cl * PLANE;
+            const int ly = r / IW, lx = r - ly * IW;
+            int gy = iy0 + ly, gx = ix0 + lx;
+            bool ok = e < C::AE && cl < nci && ly < C::IH;
+            if (p.pad_mode == 1) {
+                gy = reflect_clamp(gy, p.H);
+                gx = reflect_clamp(gx, p.W);
+            } else {
+                ok = ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            }
+            const int c = ci_lo + (cl < nci ? cl : 0);
+            const int s = seg_of(c);
+            const int cs = c - p.seg[s].chunk_begin;
+            const long long off = ((long long)n * p.seg[s].C + cs) * HW + gy * p.W + gx;
+            float v = p.seg[s].data[ok ? off : 0];
+            if (p.seg[s].mean != nullptr) {
+                const int mc = n * p.seg[s].C + cs;
+                v = (v - p.seg[s].mean[mc]) * p.seg[s].rstd[mc];
+            }
+            const int act = p.seg[s].act;
+            v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+            ar[k] = ok ? v : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+        float* gd = gbuf + buf * C::M_TILE * GS;
+        float* ad = abuf + buf * NCI * PLANE;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::GE) gd[(e / C::NPIX) * GS + (e % C::NPIX)] = gr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int e = tid + k * 256;
+            if (e < C::AE) ad[e] = ar[k];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.f;
+
+    if (st0 < st1) {
+        issue(st0);
+        commit(0);
+    }
+    __syncthreads();
+    for (int st = st0; st < st1; ++st) {
+        const int cur = (st - st0) & 1;
+        const bool more = st + 1 < st1;
+        if (more) issue(st + 1);
+        const float* G = gbuf + cur * C::M_TILE * GS + aoff;
+        const float* A = abuf + cur * NCI * PLANE;
+#pragma unroll
+        for (int py = 0; py < PR; ++py) {
+#pragma unroll
+            for (int sx = 0; sx < 16; ++sx) {
+                float a[MT], bb[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = G[m * 32 * GS + py * 32 + 2 * sx];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bb[t] = A[boff[t] + (py * S) * IW + 2 * sx * S];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bb[t], acc[m][t], 0, 0, 0);
+            }
+        }
+        if (more) commit(cur ^ 1);
+        __syncthreads();
+    }
+
+    // partial[split][m][q]: C/D layout col j = lane & 31 (q), row i = (r&3) + 8*(r>>2) + 4*half (m)
+    float* out = p.partial + (long long)split * p.M * p.Q;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int q = q0 + (wq * NT + t) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int mm = m0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (mm < p.M && q < p.Q) out[(long long)mm * p.Q + q] = acc[m][t][r];
+            }
+        }
+}
+
+// dW[i] = sum_s partial[s][i]   (fixed order)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, long long n, float* __restrict__ dw) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < P; ++k) s += partial[(long long)k * n + i];
+        dw[i] = s;
+    }
+}
+
+}  // namespace apamd

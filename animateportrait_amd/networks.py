@@ -16,6 +16,8 @@ import torch.nn as nn
 from torch.optim import lr_scheduler
 
 from . import ops
+from .autograd import (conv_forward, materialize_forward, warp_forward, batch_split_forward,
+                       generator_apply, discriminator_apply)
 from .ops import (Feat, ConvSpec, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT,
                   W_OIHW, W_IOHW)
 
@@ -46,6 +48,16 @@ class ConvLayer(nn.Module):
                              W_IOHW if transposed else W_OIHW)
         self._packed = None
         self._packed_key = None
+        self._packed_dgrad = {}
+
+    def packed_dgrad(self, seg, spec, w):
+        """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
+        key = (self.weight._version, self.weight.data_ptr())
+        hit = self._packed_dgrad.get(seg)
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weights(spec, w))
+            self._packed_dgrad[seg] = hit
+        return hit[1]
 
     def packed(self):
         w = self.weight
@@ -79,10 +91,10 @@ class ResnetBlock(nn.Module):
         self.conv_block = _seq(_1=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT),
                                _5=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT))
 
-    def run(self, x):
-        y = self.conv_block['1'].run(x, norm_act=ACT_RELU)
-        y = self.conv_block['5'].run(y, norm_act=ACT_NONE)
-        return ops.materialize(y, residual=x)
+    def run(self, x, tape=None):
+        y = conv_forward(tape, self.conv_block['1'], x, norm_act=ACT_RELU)
+        y = conv_forward(tape, self.conv_block['5'], y, norm_act=ACT_NONE)
+        return materialize_forward(tape, y, residual=x)
 
 
 class ResnetBlock2(nn.Module):
@@ -94,11 +106,11 @@ class ResnetBlock2(nn.Module):
                                _5=ConvLayer([dim_out], dim_out, 3, 1, 1, PAD_REFLECT))
         self.shortcut = _seq(_0=ConvLayer(segs, dim_out, 3, 1, 1, PAD_ZERO))
 
-    def run(self, srcs):
-        y = self.conv_block['1'].run(srcs, norm_act=ACT_RELU)
-        y = self.conv_block['5'].run(y, norm_act=ACT_NONE)
-        s = self.shortcut['0'].run(srcs, norm_act=ACT_NONE)
-        return ops.materialize(y, residual=s)
+    def run(self, srcs, tape=None):
+        y = conv_forward(tape, self.conv_block['1'], srcs, norm_act=ACT_RELU)
+        y = conv_forward(tape, self.conv_block['5'], y, norm_act=ACT_NONE)
+        s = conv_forward(tape, self.shortcut['0'], srcs, norm_act=ACT_NONE)
+        return materialize_forward(tape, y, residual=s)
 
 
 class ResnetConditionTriGenerator32_full_ifw(nn.Module):
@@ -147,45 +159,49 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
     def is_block2(self, i):
         return (i + self.disp) % self.div == 0
 
-    def double_feature_warping(self, x, motion, flow, ifmask, level):
-        return ops.warp_concat(x, motion, flow, ifmask, level)
+    def double_feature_warping(self, x, motion, flow, ifmask, level, tape=None):
+        return warp_forward(tape, x, motion, flow, ifmask, level)
 
     def forward(self, input, land1, land2, motion, flow, ifmask):
         """G(input, land1, land2, motion, flow, ifmask) -> (B, output_nc, S, S)   (networks.py:1315)."""
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .autograd import generator_apply
             return generator_apply(self, input, land1, land2, motion, flow, ifmask)
         return self.forward_inference(input, land1, land2, motion, flow, ifmask)
 
     def forward_inference(self, input, land1, land2, motion, flow, ifmask):
+        return self._run(None, False, input, land1, land2, motion, flow, ifmask).data
+
+    def _run(self, tape, input_needs_grad, input, land1, land2, motion, flow, ifmask):
+        """The layer schedule.  tape=None: inference; otherwise every step also records its backward."""
         b = input.shape[0]
         inp = Feat(input.contiguous())
         motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
-        x1 = self.model_tri00['1'].run(inp, norm_act=ACT_RELU)
-        x1 = self.double_feature_warping(x1, motion, flow, ifmask, 0)
-        x1 = self.model_tri01['0'].run(x1, norm_act=ACT_RELU)
-        x1 = self.model_tri02['0'].run(x1, norm_act=ACT_RELU)
-        x2 = self.model_tri10['1'].run(inp, norm_act=ACT_RELU)
-        x2 = self.model_tri11['0'].run(x2, norm_act=ACT_RELU)
-        x2 = self.double_feature_warping(x2, motion, flow, ifmask, 1)
-        x2 = self.model_tri12['0'].run(x2, norm_act=ACT_RELU)
-        x3 = self.model_tri20['1'].run(inp, norm_act=ACT_RELU)
-        x3 = self.model_tri21['0'].run(x3, norm_act=ACT_RELU)
-        x3 = self.model_tri22['0'].run(x3, norm_act=ACT_RELU)
-        x3 = self.double_feature_warping(x3, motion, flow, ifmask, 2)
-        x = self.model_tri_merge.run([x1, x2, x3])
+        cf, dfw = conv_forward, self.double_feature_warping
+        x1 = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)
+        x1 = dfw(x1, motion, flow, ifmask, 0, tape)
+        x1 = cf(tape, self.model_tri01['0'], x1, norm_act=ACT_RELU)
+        x1 = cf(tape, self.model_tri02['0'], x1, norm_act=ACT_RELU)
+        x2 = cf(tape, self.model_tri10['1'], inp, norm_act=ACT_RELU)
+        x2 = cf(tape, self.model_tri11['0'], x2, norm_act=ACT_RELU)
+        x2 = dfw(x2, motion, flow, ifmask, 1, tape)
+        x2 = cf(tape, self.model_tri12['0'], x2, norm_act=ACT_RELU)
+        x3 = cf(tape, self.model_tri20['1'], inp, norm_act=ACT_RELU)
+        x3 = cf(tape, self.model_tri21['0'], x3, norm_act=ACT_RELU)
+        x3 = cf(tape, self.model_tri22['0'], x3, norm_act=ACT_RELU)
+        x3 = dfw(x3, motion, flow, ifmask, 2, tape)
+        x = cf(tape, self.model_tri_merge, [x1, x2, x3])
         # land1 / land2 share the encoder weights: one pass over the 2B batch
         lands = Feat(torch.cat([land1, land2], 0).contiguous())
-        l = self.model_landmark_trans['0'].run(lands, norm_act=ACT_RELU)
-        l = self.model_landmark_trans['3'].run(l, norm_act=ACT_RELU)
-        l = self.model_landmark_trans['6'].run(l, norm_act=ACT_NONE)
-        l1, l2 = l.batch_slice(0, b), l.batch_slice(b, 2 * b)
+        l = cf(tape, self.model_landmark_trans['0'], lands, norm_act=ACT_RELU)
+        l = cf(tape, self.model_landmark_trans['3'], l, norm_act=ACT_RELU)
+        l = cf(tape, self.model_landmark_trans['6'], l, norm_act=ACT_NONE)
+        l1, l2 = batch_split_forward(tape, l, b)
         for i in range(self.n_blocks):
             blk = self.model2[str(i)]
-            x = blk.run([x, l1, l2]) if self.is_block2(i) else blk.run(x)
-        x = self.model3['0'].run(x, norm_act=ACT_RELU)
-        x = self.model3['3'].run(x, norm_act=ACT_RELU)
-        return self.model3['7'].run(x, act=ACT_TANH).data
+            x = blk.run([x, l1, l2], tape) if self.is_block2(i) else blk.run(x, tape)
+        x = cf(tape, self.model3['0'], x, norm_act=ACT_RELU)
+        x = cf(tape, self.model3['3'], x, norm_act=ACT_RELU)
+        return cf(tape, self.model3['7'], x, act=ACT_TANH)
 
 
 class NLayerDiscriminator(nn.Module):
@@ -204,16 +220,23 @@ class NLayerDiscriminator(nn.Module):
 
     def forward(self, input):
         if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
-            from .autograd import discriminator_apply
             return discriminator_apply(self, input)
         return self.forward_inference(input)
 
     def forward_inference(self, input):
-        x = self.model['0'].run(Feat(input.contiguous()), act=ACT_LRELU)
-        x = self.model['2'].run(x, norm_act=ACT_LRELU)
-        x = self.model['5'].run(x, norm_act=ACT_LRELU)
-        x = self.model['8'].run(x, norm_act=ACT_LRELU)
-        return self.model['11'].run(x).data
+        return self._run(None, False, input).data
+
+    def _run(self, tape, input_needs_grad, input):
+        inp = Feat(input.contiguous())
+        if tape is not None and input_needs_grad:
+            tape.track(inp)
+        self._last_input_feat = inp if tape is not None else None
+        cf = conv_forward
+        x = cf(tape, self.model['0'], inp, act=ACT_LRELU)
+        x = cf(tape, self.model['2'], x, norm_act=ACT_LRELU)
+        x = cf(tape, self.model['5'], x, norm_act=ACT_LRELU)
+        x = cf(tape, self.model['8'], x, norm_act=ACT_LRELU)
+        return cf(tape, self.model['11'], x)
 
 
 # --------------------------------------------------------------------------- registry

@@ -193,3 +193,99 @@ def warp_concat(f, motion, flow, ifmask, level):
                                        _ptr(ifmask), _ptr(out), n, c, h, w, s, 1.0 / (1 << level), _stream()),
             'warp_concat_fwd')
     return Feat(out)
+
+
+# =============================================================================== backward ops
+def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape):
+    """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
+    srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW)."""
+    d = C.ApWgradDesc()
+    n, m, gh, gw = g.data.shape
+    d.N, d.M, d.GH, d.GW = n, m, gh, gw
+    d.H, d.W = srcs[0].data.shape[2], srcs[0].data.shape[3]
+    d.K, d.stride, d.pad, d.pad_mode = k, stride, pad, pad_mode
+    d.nsrc = len(srcs)
+    d.g.data = g.data.data_ptr()
+    d.g.mean = g.mean.data_ptr() if g.mean is not None else None
+    d.g.rstd = g.rstd.data_ptr() if g.rstd is not None else None
+    d.g.C, d.g.act = m, g.act
+    for i, f in enumerate(srcs):
+        _require_device(f.data, 'wgrad source')
+        d.src[i].data = f.data.data_ptr()
+        d.src[i].mean = f.mean.data_ptr() if f.mean is not None else None
+        d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
+        d.src[i].C, d.src[i].act = f.data.shape[1], f.act
+    lib = C.lib()
+    nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
+    ws = torch.empty(nws, dtype=torch.float32, device=g.data.device)
+    dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+    assert dw.numel() == m * sum(f.data.shape[1] for f in srcs) * k * k
+    C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
+    return dw
+
+
+def _split_contribs(contribs):
+    """contribs: list of (tensor, pad).  Reduce to (g1, pad1, g2) with g2 plain, folding the extras."""
+    plain = [t for t, p in contribs if p == 0]
+    padded = [(t, p) for t, p in contribs if p > 0]
+    while True:
+        if len(padded) > 1:
+            t, p = padded.pop()
+            plain.append(fold_add(t, p, plain.pop() if plain else None))
+            continue
+        if len(plain) > (1 if padded else 2):
+            a, b = plain.pop(), plain.pop()
+            plain.append(fold_add(a, 0, b))
+            continue
+        break
+    if padded:
+        return padded[0][0], padded[0][1], (plain[0] if plain else None)
+    return plain[0], 0, (plain[1] if len(plain) > 1 else None)
+
+
+def fold_add(g1, pad, g2):
+    """out = fold(g1) + g2 (reflection-pad backward fused)."""
+    n, c, hp, wp = g1.shape
+    h, w = hp - 2 * pad, wp - 2 * pad
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=g1.device)
+    C.check(C.lib().ap_act_bwd(_ptr(g1), pad, _ptr(g2), None, ACT_NONE, n * c, h, w, _ptr(out), _stream()), 'act_bwd')
+    return out
+
+
+def instnorm_bwd(contribs, f):
+    """Gradient w.r.t. the raw conv output y of the virtual feature f = act(IN(y))."""
+    g1, pad, g2 = _split_contribs(contribs)
+    n, c, h, w = f.data.shape
+    dy = torch.empty_like(f.data)
+    ws = torch.empty(n * c * 2, dtype=torch.float32, device=dy.device)
+    C.check(C.lib().ap_instnorm_bwd(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act,
+                                    n * c, h, w, _ptr(ws), _ptr(dy), _stream()), 'instnorm_bwd')
+    return dy
+
+
+def act_bwd(contribs, out, act):
+    """Gradient w.r.t. the pre-activation of a plain layer output ``out = act(pre)``."""
+    g1, pad, g2 = _split_contribs(contribs)
+    if act == ACT_NONE and pad == 0 and g2 is None:
+        return g1
+    n, c, h, w = out.shape
+    dy = torch.empty_like(out)
+    C.check(C.lib().ap_act_bwd(_ptr(g1), pad, _ptr(g2), _ptr(out), act, n * c, h, w, _ptr(dy), _stream()), 'act_bwd')
+    return dy
+
+
+def bias_grad(dy):
+    n, c, h, w = dy.shape
+    db = torch.empty(c, dtype=torch.float32, device=dy.device)
+    C.check(C.lib().ap_bias_grad(_ptr(dy), n, c, h * w, _ptr(db), _stream()), 'bias_grad')
+    return db
+
+
+def warp_concat_bwd(gout, motion, flow, ifmask, level):
+    n, c2, h, w = gout.shape
+    c = c2 // 2
+    s = motion.shape[1]
+    dx = torch.empty((n, c, h, w), dtype=torch.float32, device=gout.device)
+    C.check(C.lib().ap_warp_concat_bwd(_ptr(gout), _ptr(motion), _ptr(flow), _ptr(ifmask), _ptr(dx), n, c, h, w, s,
+                                       1.0 / (1 << level), _stream()), 'warp_concat_bwd')
+    return dx

@@ -122,6 +122,52 @@ int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd,
                        float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                        float flow_scale, ap_stream_t stream);
 
+/* ======================================================================= backward pass
+ * What torch.autograd launches for the layers above (loss.backward() at
+ * Module2/models/geomgm_ifw_fore_model.py:586,610,634,780).
+ *
+ * Data gradient of a convolution = ap_conv2d_fwd with a descriptor whose roles are swapped
+ * (w_layout / w_flip / transposed), so it has no entry point of its own:
+ *   Conv2d(s=1, pad p, k)          -> conv with IOHW-read weights, w_flip=1, zero pad k-1 (reflect-padded
+ *                                     layers: gradient in PADDED coordinates, folded by the readers below)
+ *   Conv2d(s=2, pad p, k)          -> transposed conv (output_padding chosen to restore the input size)
+ *   ConvTranspose2d(s=2)           -> stride-2 conv with OIHW-read weights
+ */
+
+/* Weight gradient.  dW[m][ci*K*K + ky*K + kx] = sum_{n,oy,ox} G[n,m,oy,ox] * A[n,ci,oy*s+ky-pad,ox*s+kx-pad].
+ *   nn.Conv2d:          g = gradient w.r.t. the conv output (M = Cout, grid GHxGW = output size), src = the
+ *                       conv's input segments (virtual inputs allowed) -> dW is the OIHW tensor;
+ *   nn.ConvTranspose2d: g = the layer's INPUT (M = Cin, virtual allowed), src = gradient w.r.t. its output,
+ *                       stride 2 -> dW is the IOHW tensor. */
+typedef struct ap_wgrad_desc {
+    int32_t N, M;
+    int32_t GH, GW;       /* spatial size of g (the grid that is iterated) */
+    int32_t H, W;         /* spatial size of the src tensors */
+    int32_t K, stride, pad, pad_mode;
+    int32_t nsrc, reserved;
+    ap_src g;             /* g.C is ignored (M is used) */
+    ap_src src[3];
+} ap_wgrad_desc;
+int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);
+int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream);
+
+/* backward of a = act(InstanceNorm(y)) w.r.t. y.  The incoming gradient is fold(g1) + g2 where g1 has spatial
+ * (H+2*g1_pad) x (W+2*g1_pad) (gradient of a reflection-padded consumer, nn.ReflectionPad2d backward fused) and g2
+ * (optional) is plain.  sums_ws: N*C*2 floats of scratch. */
+int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean,
+                    const float* rstd, int32_t act, int32_t NC, int32_t H, int32_t W, float* sums_ws, float* dy,
+                    ap_stream_t stream);
+/* dy = (fold(g1) + g2) * act'(out) for layers without normalisation; act = NONE makes it a fold-and-add
+ * (out may then be NULL).  AP_ACT_TANH: 1 - out^2; RELU / LRELU: from the sign of the activated output. */
+int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,
+               int32_t H, int32_t W, float* dy, ap_stream_t stream);
+/* db[c] = sum over n and pixels of dy (layers whose bias is live) */
+int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, ap_stream_t stream);
+/* backward of ap_warp_concat_fwd w.r.t. x (gout: N x 2C x H x W -> dx: N x C x H x W, zeroed inside) */
+int ap_warp_concat_bwd(const float* gout, const float* motion, const float* flow, const float* ifmask,
+                       float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale,
+                       ap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

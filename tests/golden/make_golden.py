@@ -165,6 +165,21 @@ def main():
               'model2.4.conv_block.5.weight', 'model3.0.weight', 'model3.3.weight', 'model3.7.weight', 'model3.7.bias',
               'model_landmark_trans.0.weight', 'model_landmark_trans.6.weight', 'model_tri12.0.weight'):
         out['grad_' + k] = gsd[k]
+    # fp32 weight gradients of this net are only accurate to ~1e-2 of their scale (cancellation over 131k pixels
+    # after InstanceNorm): store the reference evaluated in fp64 as the truth, plus the fp32 reference's own
+    # distance to it, which is the accuracy bar for the HIP path.
+    G8d = networks.define_G(3, 1, 8, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [], div=3, disp=3)
+    G8d.load_state_dict(sd8, strict=True)
+    G8d = G8d.double()
+    yd = G8d(*[a.double() for a in args])
+    (yd * up.double()).sum().backward()
+    g64 = {k: p.grad for k, p in G8d.named_parameters()}
+    out['grad64_norms'] = np.array([float(g64[k].norm()) for k in sd8.keys()])
+    out['grad32_relerr'] = np.array([float((gsd[k].double() - g64[k]).abs().max() / g64[k].abs().max().clamp_min(1e-30))
+                                     for k in sd8.keys()])
+    for k in list(out.keys()):
+        if k.startswith('grad_model'):
+            out['grad64_' + k[5:]] = g64[k[5:]].float()
     # disp=1 variant (model default, geomgm_ifw_fore_model.py:167): blocks 2,5,8 are ResnetBlock2
     G8b = networks.define_G(3, 1, 8, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [], div=3, disp=1)
     sd8b = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 1), seed=1234)
