@@ -69,6 +69,12 @@ SIGNATURES = {
     'ap_warp_concat_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                           ctypes.c_void_p]),
+    'ap_tps_solve': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p,
+                                    ctypes.c_void_p]),
+    'ap_tps_warp': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                   ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_adam_step': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,122 @@
+"""Model contract of Module2/models/base_model.py: setup / eval / test / get_current_losses /
+save_networks / load_networks / set_requires_grad / masked, with the reference's checkpoint naming
+('%s_net_%s.pth', unwrapped state_dict saved from CPU, :144-163, :179-202)."""
+import os
+from abc import ABC, abstractmethod
+from collections import OrderedDict
+
+import torch
+
+from .. import networks
+
+
+class BaseModel(ABC):
+    def __init__(self, opt):
+        self.opt = opt
+        self.gpu_ids = opt.gpu_ids
+        self.isTrain = opt.isTrain
+        if not self.gpu_ids:
+            raise RuntimeError('animateportrait_amd models need --gpu_ids >= 0: there is no CPU path')
+        self.device = torch.device('cuda:{}'.format(self.gpu_ids[0]))
+        self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
+        self.loss_names, self.model_names, self.visual_names = [], [], []
+        self.optimizers, self.image_paths = [], []
+        self.metric = 0
+
+    @staticmethod
+    def modify_commandline_options(parser, is_train):
+        return parser
+
+    @abstractmethod
+    def set_input(self, input):
+        pass
+
+    @abstractmethod
+    def forward(self):
+        pass
+
+    @abstractmethod
+    def optimize_parameters(self):
+        pass
+
+    def setup(self, opt):                                             # base_model.py:79-90
+        if self.isTrain:
+            self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
+        if not self.isTrain or opt.continue_train:
+            load_suffix = 'iter_%d' % opt.load_iter if opt.load_iter > 0 else opt.epoch
+            self.load_networks(load_suffix)
+        self.print_networks(opt.verbose)
+
+    def eval(self):
+        for name in self.model_names:
+            getattr(self, 'net' + name).eval()
+
+    def test(self):                                                   # :99-107
+        with torch.no_grad():
+            self.forward()
+
+    def get_image_paths(self):
+        return self.image_paths
+
+    def update_learning_rate(self):                                   # :117-126
+        for s in self.schedulers:
+            s.step()
+        lr = self.optimizers[0].param_groups[0]['lr']
+        print('learning rate = %.7f' % lr)
+
+    def get_current_visuals(self):
+        return OrderedDict((n, getattr(self, n)) for n in self.visual_names if hasattr(self, n))
+
+    def get_current_losses(self):                                     # :136-142
+        out = OrderedDict()
+        for name in self.loss_names:
+            v = getattr(self, 'loss_' + name, None)
+            if v is not None:
+                out[name] = float(v)
+        return out
+
+    def save_networks(self, epoch):                                   # :144-163
+        os.makedirs(self.save_dir, exist_ok=True)
+        for name in self.model_names:
+            net = getattr(self, 'net' + name)
+            path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
+            torch.save(OrderedDict((k, v.detach().cpu().clone()) for k, v in net.state_dict().items()), path)
+
+    def load_networks(self, epoch):                                   # :179-202
+        for name in self.model_names:
+            net = getattr(self, 'net' + name)
+            path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch, name))
+            print('loading the model from %s' % path)
+            state = torch.load(path, map_location=str(self.device))
+            state.pop('_metadata', None)
+            net.load_state_dict(state, strict=True)
+
+    def print_networks(self, verbose):
+        print('---------- Networks initialized -------------')
+        for name in self.model_names:
+            net = getattr(self, 'net' + name)
+            n = sum(p.numel() for p in net.parameters())
+            if verbose:
+                print(net)
+            print('[Network %s] Total number of parameters : %.3f M' % (name, n / 1e6))
+        print('-----------------------------------------------')
+
+    def set_requires_grad(self, nets, requires_grad=False):          # :224-235
+        if not isinstance(nets, list):
+            nets = [nets]
+        for net in nets:
+            if net is not None:
+                for p in net.parameters():
+                    p.requires_grad = requires_grad
+
+    def masked(self, A, mask):                                        # :238-247
+        t = self.opt.mask_type
+        if t == 0:
+            return (A / 2 + 0.5) * mask * 2 - 1
+        if t == 1:
+            return ((A / 2 + 0.5) * mask + 1 - mask) * 2 - 1
+        if t == 2:
+            return torch.cat((A, mask), 1)
+        if t == 3:
+            return torch.cat((((A / 2 + 0.5) * mask + 1 - mask) * 2 - 1, mask), 1)
+        raise ValueError('mask_type %r' % t)

@@ -52,7 +52,7 @@ class ConvLayer(nn.Module):
 
     def packed_dgrad(self, seg, spec, w):
         """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
-        key = (self.weight._version, self.weight.data_ptr())
+        key = (self.weight._version, self.weight.data_ptr(), ops.WEIGHTS_EPOCH)
         hit = self._packed_dgrad.get(seg)
         if hit is None or hit[0] != key:
             hit = (key, ops.pack_weights(spec, w))
@@ -61,7 +61,7 @@ class ConvLayer(nn.Module):
 
     def packed(self):
         w = self.weight
-        key = (w._version, w.data_ptr())
+        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
         if self._packed is None or self._packed_key != key:
             self._packed = ops.pack_weights(self.spec, w.detach())
             self._packed_key = key

@@ -15,6 +15,10 @@ from ._capi import ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLEC
 
 EPS = 1e-5  # nn.InstanceNorm2d default (networks.py:33-34)
 
+# bumped by optimisers that update parameters through raw pointers (optim.FlatAdam); part of the key of the
+# per-layer packed-weight caches
+WEIGHTS_EPOCH = 0
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,93 @@
+"""Data parallelism: one process per GPU, gradients averaged with an all-reduce over RCCL (xGMI).
+
+The reference uses single-process ``nn.DataParallel`` (Module2/models/networks.py:115-118); here every rank
+holds G and the D's on its own GPU, runs the step on its shard of the frame batch, and the only exchange is the
+mean of the gradients: once for G between ``backward_G`` and ``optimizer_G.step`` and once for the D's before
+``optimizer_D.step`` (geomgm_ifw_fore_model.py:797-798, 810-819).  With ``FlatAdam`` the gradients of an
+optimiser are one contiguous buffer, so each exchange is ONE collective (63.7 MB for G, 55.3 MB for the D's at
+ngf=ndf=64); otherwise tensors are coalesced into buckets.  Works on any backend (``nccl`` = RCCL on ROCm;
+``gloo`` in the CPU tests).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Initialise from the torch.distributed.run environment.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kw['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_batch(batch, rank, world):
+    """Split every tensor of a batch dict along dim 0 into ``world`` equal shards and return shard ``rank``."""
+    out = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.dim() > 0:
+            if v.shape[0] % world:
+                raise ValueError('batch entry %s of size %d does not divide over %d ranks' % (k, v.shape[0], world))
+            n = v.shape[0] // world
+            out[k] = v[rank * n:(rank + 1) * n]
+        else:
+            out[k] = v
+    return out
+
+
+def allreduce_flat_(flat, async_op=False):
+    """In-place mean of one flat gradient buffer over all ranks."""
+    w = world_size()
+    if w == 1:
+        return None
+    flat.div_(w)
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
+def allreduce_gradients(params, bucket_bytes=32 << 20):
+    """Mean of ``p.grad`` over all ranks for every parameter, coalesced into buckets of ~bucket_bytes."""
+    w = world_size()
+    if w == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    bucket, size = [], 0
+    for g in grads + [None]:
+        if g is not None:
+            bucket.append(g)
+            size += g.numel() * g.element_size()
+        if bucket and (g is None or size >= bucket_bytes):
+            flat = torch.cat([b.reshape(-1) for b in bucket])
+            flat.div_(w)
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            off = 0
+            for b in bucket:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            bucket, size = [], 0
+
+
+def allreduce_optimizer_grads(optimizer, params=None):
+    """One collective when the optimiser keeps a flat gradient buffer, bucketed otherwise."""
+    flat = getattr(optimizer, 'flat_grad', None)
+    if flat is not None:
+        if hasattr(optimizer, '_rebind'):
+            optimizer._rebind()
+        allreduce_flat_(flat)
+    else:
+        allreduce_gradients(params if params is not None else
+                            [p for g in optimizer.param_groups for p in g['params']])

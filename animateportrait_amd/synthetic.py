@@ -32,9 +32,17 @@ def _discs(points, size, radius=3):
 
 
 def make_landmarks(batch, gen, size=256, n_points=68):
-    lo, hi = size // 16, size - size // 16
-    base = torch.randint(lo, hi, (batch, n_points, 2), generator=gen).float()
-    return base
+    # jittered 9 x 8 lattice (first n_points cells): distinct, well separated control points -- coincident
+    # landmarks would make the TPS system of the warp losses singular (sparse_image_warp.py:124-128 drops to pdb)
+    cols, rows = 9, 8
+    assert n_points <= cols * rows
+    step_x, step_y = (size * 0.8) / cols, (size * 0.8) / rows
+    idx = torch.arange(n_points)
+    cx = (idx % cols).float() * step_x + size * 0.1 + step_x / 2
+    cy = (idx // cols).float() * step_y + size * 0.1 + step_y / 2
+    grid = torch.stack([cx, cy], -1).unsqueeze(0).expand(batch, -1, -1)
+    jit = (torch.rand(batch, n_points, 2, generator=gen) - 0.5) * torch.tensor([step_x, step_y]) * 0.5
+    return (grid + jit).round()
 
 
 def jitter_landmarks(base, gen, sigma=2.0, size=256):

@@ -168,6 +168,21 @@ int ap_warp_concat_bwd(const float* gout, const float* motion, const float* flow
                        float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale,
                        ap_stream_t stream);
 
+/* ======================================================================= train-step helpers
+ * sparse_image_warp (Module2/models/sparse_image_warp.py:35-58): order-2 polyharmonic spline through n control
+ * points (src -> dst, (row, col) order), dense flow, bilinear warp with edge clamping.  Batched (the reference is
+ * b=1 only).  ap_tps_solve: coef = B x (n+3) x 2 (spline weights w then affine v); *status (optional device int) is
+ * set to 1 if a system is singular (the reference drops into pdb there, :124-128).  ap_tps_warp: img / out are
+ * B x C x H x W (the reference passes NHWC; for its C=1 use both layouts coincide); flow_out (optional) B x H x W x 2. */
+int ap_tps_solve(const float* src, const float* dst, int32_t B, int32_t n, float* coef, int32_t* status,
+                 ap_stream_t stream);
+int ap_tps_warp(const float* img, const float* dst, const float* coef, int32_t B, int32_t n, int32_t C, int32_t H,
+                int32_t W, float* out, float* flow_out, ap_stream_t stream);
+/* torch.optim.Adam(lr, betas=(beta1, beta2), eps) single step over a flat buffer
+ * (Module2/models/geomgm_ifw_fore_model.py:346-360); step counts from 1. */
+int ap_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, ap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

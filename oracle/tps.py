@@ -42,10 +42,9 @@ def apply_interpolation(q, c, w, v):
     return rbf + torch.bmm(qp, v)
 
 
-def flat_grid(h, w):
+def flat_grid(h, w, dtype=torch.float32):
     """:71-75: (row, col) of every pixel, row-major."""
-    yy, xx = torch.meshgrid(torch.arange(h, dtype=torch.float32),
-                            torch.arange(w, dtype=torch.float32), indexing='ij')
+    yy, xx = torch.meshgrid(torch.arange(h, dtype=dtype), torch.arange(w, dtype=dtype), indexing='ij')
     return torch.stack([yy, xx], -1).reshape(h * w, 2)
 
 
@@ -77,7 +76,7 @@ def interpolate_bilinear(img, q):
 def dense_image_warp(img, flow):
     """:220-264: out(q) = bilinear(img, q - flow(q))."""
     b, h, w, ch = img.shape
-    q = flat_grid(h, w).unsqueeze(0) - flow.reshape(b, h * w, 2)
+    q = flat_grid(h, w, img.dtype).unsqueeze(0) - flow.reshape(b, h * w, 2)
     return interpolate_bilinear(img, q).reshape(b, h, w, ch)
 
 
@@ -86,6 +85,6 @@ def sparse_image_warp(img, src, dst):
     Returns (warped (b,h,w,c), dense_flow (b,h,w,2))."""
     b, h, w, _ = img.shape
     wts, v = solve_interpolation(dst, dst - src)
-    q = flat_grid(h, w).unsqueeze(0).expand(b, -1, -1)
+    q = flat_grid(h, w, img.dtype).unsqueeze(0).expand(b, -1, -1)
     flow = apply_interpolation(q, dst, wts, v).reshape(b, h, w, 2)
     return dense_image_warp(img, flow), flow

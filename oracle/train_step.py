@@ -1,0 +1,123 @@
+"""Oracle (test infrastructure): one ``geomgm_ifw_fore`` train step, restated on CPU PyTorch.
+
+Follows Module2/models/geomgm_ifw_fore_model.py: forward :517-565, backward_G :677-780,
+backward_D_basic3 :613-635, backward_D_basic2 :589-611, with the batched semantics the build defines
+("reference b=1 applied per sample, mean-reduced losses averaged over the batch").  The frozen auxiliary
+networks (MODNet / MobileFaceNet / Sphere20a / FlowUnet) are not in the reference tree; their outputs are part
+of the batch (``mask``, ``iw_flow``, ``if_mask`` ...) and the geometry / identity terms are left out, exactly as
+the product model does when no aux callable is registered.
+
+The reference model class itself cannot be instantiated here (cv2, .cuda(), absent checkpoints -- SURVEY.md
+section 8c); the pieces this composition is made of (G, D, GANLoss, masked, sparse_image_warp) are each pinned to
+goldens captured from the reference.
+"""
+import torch
+import torch.nn.functional as F
+
+from . import generator as og, discriminator as od, losses as ol, tps as ot
+
+
+class Opt:
+    """README training values (readme.md:65) on top of the model defaults (:161-209)."""
+    use_mask = use_eye_mask = use_lip_mask = 1
+    mask_type = 3
+    blendbg = 1
+    coherent = 1
+    coh_use_more = 2
+    check_fakeb2_in_backwardD = 1
+    warp_loss = 2
+    lambda_G_A_l = 0.5
+    lambda_G_A_coh = 0.5
+    lambda_geom_lipline = 50.0
+    lambda_warp = 5.0
+    lambda_warp_inter = 10.0
+    crop_size = 256
+    div, disp = 3, 3
+    thickness = 2
+
+
+LIP_SEGMENTS = [(i, i + 1) for i in range(48, 59)] + [(59, 48)] + [(i, i + 1) for i in range(60, 67)] + [(67, 60)]
+
+
+def lipline(lands, size, thickness):
+    """getlipline (:507-515): union of the 20 lip segments drawn with cv2.line(thickness) -- restated as a
+    distance-to-segment test (pixels within thickness/2 + 0.5 of a segment)."""
+    yy = torch.arange(size, dtype=torch.float32).view(1, 1, size, 1)
+    xx = torch.arange(size, dtype=torch.float32).view(1, 1, 1, size)
+    i0 = torch.tensor([a for a, _ in LIP_SEGMENTS])
+    i1 = torch.tensor([b for _, b in LIP_SEGMENTS])
+    p0, p1 = lands[:, i0].float(), lands[:, i1].float()
+    ax, ay = p0[..., 0, None, None], p0[..., 1, None, None]
+    dx, dy = (p1 - p0)[..., 0, None, None], (p1 - p0)[..., 1, None, None]
+    t = (((xx - ax) * dx + (yy - ay) * dy) / (dx * dx + dy * dy).clamp_min(1e-6)).clamp(0, 1)
+    d2 = (xx - ax - t * dx) ** 2 + (yy - ay - t * dy) ** 2
+    return (d2 <= (thickness / 2.0 + 0.5) ** 2).any(dim=1, keepdim=True).float()
+
+
+def warp_nchw(img, src_xy, dst_xy):
+    """sparse_image_warp with (x,y) landmarks -> (row,col) as the model passes them (lm[:,:,[1,0]], :537)."""
+    w, _ = ot.sparse_image_warp(img.permute(0, 2, 3, 1), src_xy[:, :, [1, 0]], dst_xy[:, :, [1, 0]])
+    return w.permute(0, 3, 1, 2)
+
+
+def forward(sdG, batch, opt=Opt):
+    """:517-565 -> dict of tensors (fake_B, fake_B2, local crops, warped static drawing ...)."""
+    o = {}
+    mask = (batch['mask'] > 0.5).float()
+    real_A_fore = ol.fore_composite(batch['A'], mask)
+    gen = lambda tlm, mo, fl, im: og.generator_forward(sdG, real_A_fore, batch['A_lm'], tlm, mo, fl, im,  # noqa: E731
+                                                       div=opt.div, disp=opt.disp)
+    fake_B = gen(batch['tB_lm'], batch['warp_motion'], batch['iw_flow'], batch['if_mask'])
+    fake_B2 = gen(batch['tB2_lm'], batch['warp_motion2'], batch['iw_flow2'], batch['if_mask2'])
+    o['fake_B_fore'], o['fake_B2_fore'] = fake_B, fake_B2
+    if opt.blendbg:
+        mask1 = warp_nchw(mask, batch['A_lm_68'], batch['tB_lm_68'])
+        mask2 = warp_nchw(mask, batch['A_lm_68'], batch['tB2_lm_68'])
+        fake_B = ol.bg_blend(fake_B, batch['fakeB_static'], mask1)
+        fake_B2 = ol.bg_blend(fake_B2, batch['fakeB_static'], mask2)
+    o['fake_B'], o['fake_B2'] = fake_B, fake_B2
+    for suf in ('', 'e', 'l'):
+        o['fake_B_l' + suf] = ol.masked(fake_B, batch['B_mask' + suf], opt.mask_type)
+        o['fake_B2_l' + suf] = ol.masked(fake_B2, batch['B2_mask' + suf], opt.mask_type)
+        o['real_B_l' + suf] = ol.masked(batch['B'], batch['Br_mask' + suf], opt.mask_type)
+    # blendbg=1: real_A_lm_681 is the plain 68-point set (no edge points), :534-536 then :558-565
+    o['fakeB_static_warp'] = warp_nchw(batch['fakeB_static'], batch['A_lm_68'], batch['tB_lm_68'])
+    return o
+
+
+def g_loss(sdD, o, batch, opt=Opt):
+    """:677-780 without the geometry / identity terms.  sdD: dict name -> discriminator params."""
+    gan = ol.gan_loss_lsgan
+    D = od.patchgan_forward
+    terms = {}
+    terms['G_A'] = gan(D(sdD['D_A'], o['fake_B']), True) + gan(D(sdD['D_A'], o['fake_B2']), True)
+    for name, suf in (('D_A_l', ''), ('D_A_le', 'e'), ('D_A_ll', 'l')):
+        terms['G_A_l' + suf] = (gan(D(sdD[name], o['fake_B_l' + suf]), True)
+                                + gan(D(sdD[name], o['fake_B2_l' + suf]), True)) * opt.lambda_G_A_l
+    terms['G_A_coh'] = gan(D(sdD['D_A_coh'], torch.cat((o['fake_B'], o['fake_B2']), 1)), True) * opt.lambda_G_A_coh
+    m1 = lipline(batch['tB_lm_68'], opt.crop_size, opt.thickness)
+    m2 = lipline(batch['tB2_lm_68'], opt.crop_size, opt.thickness)
+    terms['geom_B_lipline'] = (torch.mean((o['fake_B'] + 1) * m1) + torch.mean((o['fake_B2'] + 1) * m2)) * opt.lambda_geom_lipline
+    terms['warp_B'] = F.l1_loss(o['fake_B'], o['fakeB_static_warp']) * opt.lambda_warp
+    fake_B_warp = warp_nchw(o['fake_B'].detach(), batch['tB_lm_68'], batch['tB2_lm_68'])
+    terms['warp_inter1'] = F.l1_loss(o['fake_B2'], fake_B_warp) * opt.lambda_warp_inter
+    terms['G'] = sum(terms.values())
+    return terms
+
+
+def d_losses(sdD, o, batch, opt=Opt):
+    """backward_D_A / _l / _le / _ll (basic3) and _coh (basic2) with an empty image pool (query returns its input)."""
+    gan = ol.gan_loss_lsgan
+    D = od.patchgan_forward
+    out = {}
+
+    def basic3(name, real, f1, f2):
+        return ol.d_loss_basic3(D(sdD[name], real), D(sdD[name], f1.detach()), D(sdD[name], f2.detach()))
+    out['D_A'] = basic3('D_A', batch['B'], o['fake_B'], o['fake_B2'])
+    for name, suf in (('D_A_l', ''), ('D_A_le', 'e'), ('D_A_ll', 'l')):
+        out[name] = basic3(name, o['real_B_l' + suf], o['fake_B_l' + suf], o['fake_B2_l' + suf])
+    real = torch.cat((batch['B1'], batch['B2']), 1)
+    fake = torch.cat((o['fake_B'], o['fake_B2']), 1).detach()
+    other = torch.cat((batch['B3'], batch['B4']), 1)
+    out['D_A_coh'] = ol.d_loss_basic2(D(sdD['D_A_coh'], real), D(sdD['D_A_coh'], fake), D(sdD['D_A_coh'], other))
+    return out
