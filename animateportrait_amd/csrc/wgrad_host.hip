@@ -1,4 +1,8 @@
-// wgrad_host.hip -- C ABI of the weight-gradient kernel (wgrad_igemm.h).
+// wgrad_host.hip -- C ABI of the weight-gradient operator (wgrad_igemm.h).
+//
+// ap_conv2d_wgrad = [pad_materialize A] (+ [pad_materialize G] unless g is plain and tile-aligned)
+//                   -> wgrad_igemm_f32 (split over pixels) -> wgrad_reduce_kernel.
+// The caller provides ONE workspace; its layout is  [A padded][G padded (optional)][partials].
 #include "common.h"
 #include "wgrad_igemm.h"
 
@@ -23,7 +27,7 @@ static WgradKernel wk() {
 
 static const std::vector<WgradKernel>& wgrad_registry() {
     static std::vector<WgradKernel> v = {
-        wk<WgradCfg<1, 3, 2, 4, 1>>(), wk<WgradCfg<1, 4, 2, 4, 1>>(), wk<WgradCfg<1, 7, 2, 4, 1>>(),
+        wk<WgradCfg<1, 3, 2, 4, 2>>(), wk<WgradCfg<1, 4, 2, 4, 2>>(), wk<WgradCfg<1, 7, 2, 4, 2>>(),
         wk<WgradCfg<2, 3, 2, 4, 1>>(), wk<WgradCfg<2, 4, 2, 4, 1>>(),
     };
     return v;
@@ -32,7 +36,12 @@ static const std::vector<WgradKernel>& wgrad_registry() {
 struct WgradPlan {
     const WgradKernel* k = nullptr;
     int Cin = 0, Q = 0, tiles_x = 0, tiles_y = 0, nstages = 0, P = 0, m_tiles = 0, q_tiles = 0;
+    int GHp = 0, GWp = 0, Hp = 0, Wp = 0;
+    bool g_direct = false;
+    long long a_floats = 0, g_floats = 0, part_floats = 0;
 };
+
+static long long round4(long long x) { return (x + 3) / 4 * 4; }
 
 static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     if (!d) return fail(AP_ERR_INVALID, "wgrad: null descriptor");
@@ -52,9 +61,10 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         if (d->src[s].C < 1) return fail(AP_ERR_INVALID, "wgrad: segment %d has C=%d", s, d->src[s].C);
         pl.Cin += d->src[s].C;
     }
-    pl.Q = pl.Cin * d->K * d->K;
+    const int S = d->stride, K = d->K, PR = pl.k->PR;
+    pl.Q = pl.Cin * K * K;
     pl.tiles_x = (d->GW + 31) / 32;
-    pl.tiles_y = (d->GH + pl.k->PR - 1) / pl.k->PR;
+    pl.tiles_y = (d->GH + PR - 1) / PR;
     pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
     pl.m_tiles = (d->M + pl.k->M_TILE - 1) / pl.k->M_TILE;
     pl.q_tiles = (pl.Q + pl.k->Q_TILE - 1) / pl.k->Q_TILE;
@@ -64,7 +74,37 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     if (P > pl.nstages) P = pl.nstages;
     if (P < 1) P = 1;
     pl.P = P;
+    pl.GHp = pl.tiles_y * PR;
+    pl.GWp = pl.tiles_x * 32;
+    pl.Hp = (pl.GHp - 1) * S + K;
+    pl.Wp = (int)round4((long long)(pl.GWp - 1) * S + K);
+    // every padded row/plane the kernel can touch must exist
+    if (pl.Hp < d->H + 2 * d->pad) pl.Hp = d->H + 2 * d->pad;
+    if (pl.Wp < d->W + 2 * d->pad) pl.Wp = (int)round4(d->W + 2 * d->pad);
+    pl.g_direct = d->g.mean == nullptr && d->g.act == AP_ACT_NONE && pl.GHp == d->GH && pl.GWp == d->GW;
+    pl.a_floats = round4((long long)d->N * pl.Cin * pl.Hp * pl.Wp);
+    pl.g_floats = pl.g_direct ? 0 : round4((long long)d->N * d->M * pl.GHp * pl.GWp);
+    pl.part_floats = (long long)pl.P * d->M * pl.Q;
     return AP_OK;
+}
+
+static int launch_pad(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode, int Hp, int Wp,
+                      float* out, hipStream_t stream) {
+    PadParams p;
+    memset(&p, 0, sizeof(p));
+    p.nseg = nseg;
+    int cbeg = 0;
+    for (int s = 0; s < nseg; ++s) {
+        p.seg[s].data = segs[s].data; p.seg[s].mean = segs[s].mean; p.seg[s].rstd = segs[s].rstd;
+        p.seg[s].C = segs[s].C; p.seg[s].act = segs[s].act; p.seg[s].chunk_begin = cbeg;
+        cbeg += segs[s].C;
+    }
+    p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.Wp = Wp; p.out = out;
+    if (N > 65535 || C > 65535) return fail(AP_ERR_UNSUPPORTED, "pad_materialize: N=%d C=%d", N, C);
+    int bx = (Hp * Wp + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(pad_materialize_kernel, dim3(bx, C, N), dim3(256), 0, stream, p);
+    return check_launch("pad_materialize_kernel");
 }
 
 static std::mutex g_wattr_mu;
@@ -76,19 +116,39 @@ using namespace apamd;
 
 extern "C" {
 
+int ap_pad_materialize(const ap_src* src, int32_t nsrc, int32_t N, int32_t H, int32_t W, int32_t pad, int32_t pad_mode,
+                       int32_t Hp, int32_t Wp, float* out, ap_stream_t stream) {
+    if (!src || !out || nsrc < 1 || nsrc > kMaxSeg) return fail(AP_ERR_INVALID, "pad_materialize: bad arguments");
+    if (Hp < H + 2 * pad || Wp < W + 2 * pad) return fail(AP_ERR_INVALID, "pad_materialize: output smaller than padded input");
+    if (pad_mode == AP_PAD_REFLECT && (pad >= H || pad >= W)) return fail(AP_ERR_INVALID, "pad_materialize: reflection pad too large");
+    int C = 0;
+    for (int s = 0; s < nsrc; ++s) {
+        if (!src[s].data || src[s].C < 1) return fail(AP_ERR_INVALID, "pad_materialize: segment %d", s);
+        if ((src[s].mean == nullptr) != (src[s].rstd == nullptr)) return fail(AP_ERR_INVALID, "pad_materialize: mean/rstd mismatch");
+        C += src[s].C;
+    }
+    return launch_pad(src, nsrc, N, C, H, W, pad, pad_mode, Hp, Wp, out, (hipStream_t)stream);
+}
+
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {
     WgradPlan pl;
     int rc = make_wgrad_plan(d, pl);
     if (rc) return rc;
-    return (int64_t)pl.P * d->M * pl.Q;
+    return pl.a_floats + pl.g_floats + pl.part_floats;
 }
 
-int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream) {
+int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream_) {
     WgradPlan pl;
     int rc = make_wgrad_plan(d, pl);
     if (rc) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
     if (!workspace || !dw || !d->g.data) return fail(AP_ERR_INVALID, "wgrad: null pointer");
     if ((d->g.mean == nullptr) != (d->g.rstd == nullptr)) return fail(AP_ERR_INVALID, "wgrad: g mean/rstd mismatch");
+    for (int s = 0; s < d->nsrc; ++s) {
+        if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
+        if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
+            return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
+    }
     {
         std::lock_guard<std::mutex> lk(g_wattr_mu);
         bool done = false;
@@ -99,31 +159,37 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
             g_wattr_done.push_back(pl.k->fn);
         }
     }
+    float* a_pad = workspace;
+    float* g_pad = workspace + pl.a_floats;
+    float* partial = g_pad + pl.g_floats;
+    rc = launch_pad(d->src, d->nsrc, d->N, pl.Cin, d->H, d->W, d->pad, d->pad_mode, pl.Hp, pl.Wp, a_pad, stream);
+    if (rc) return rc;
+    if (!pl.g_direct) {
+        ap_src g = d->g;
+        g.C = d->M;
+        rc = launch_pad(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GWp, g_pad, stream);
+        if (rc) return rc;
+    }
     WgradKParams p;
     memset(&p, 0, sizeof(p));
-    p.g.data = d->g.data; p.g.mean = d->g.mean; p.g.rstd = d->g.rstd; p.g.C = d->M; p.g.act = d->g.act;
-    p.nseg = d->nsrc;
-    int cbeg = 0;
-    for (int s = 0; s < d->nsrc; ++s) {
-        if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
-        if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
-            return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
-        p.seg[s].data = d->src[s].data; p.seg[s].mean = d->src[s].mean; p.seg[s].rstd = d->src[s].rstd;
-        p.seg[s].C = d->src[s].C; p.seg[s].act = d->src[s].act; p.seg[s].chunk_begin = cbeg;
-        cbeg += d->src[s].C;
-    }
-    p.N = d->N; p.M = d->M; p.Cin = pl.Cin; p.Q = pl.Q; p.GH = d->GH; p.GW = d->GW; p.H = d->H; p.W = d->W;
-    p.pad = d->pad; p.pad_mode = d->pad_mode;
+    p.g = pl.g_direct ? d->g.data : g_pad;
+    p.a = a_pad;
+    p.N = d->N; p.M = d->M; p.Cin = pl.Cin; p.Q = pl.Q;
+    p.GHp = pl.GHp; p.GWp = pl.GWp; p.Hp = pl.Hp; p.Wp = pl.Wp;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P;
     p.m_tiles = pl.m_tiles; p.q_tiles = pl.q_tiles;
-    p.partial = workspace;
+    p.partial = partial;
+    {
+        const char* ab = getenv("APAMD_ABLATE");
+        p.ablate = ab ? atoi(ab) : 0;
+    }
     void* args[] = {&p};
     const unsigned nblk = (unsigned)(pl.m_tiles * pl.q_tiles * pl.P);
-    hipError_t e = hipLaunchKernel(pl.k->fn, dim3(nblk), dim3(256), args, pl.k->lds_bytes, (hipStream_t)stream);
+    hipError_t e = hipLaunchKernel(pl.k->fn, dim3(nblk), dim3(256), args, pl.k->lds_bytes, stream);
     if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_igemm_f32 launch: %s", hipGetErrorString(e));
     const long long n = (long long)d->M * pl.Q;
     int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, pl.P, n, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, n, dw);
     return check_launch("wgrad_reduce_kernel");
 }
 

@@ -2,11 +2,15 @@
 //
 //   dW[m][q] = sum_{n, oy, ox} G[n][m][oy][ox] * A[n][ci][oy*S + ky - pad][ox*S + kx - pad],   q = ci*K*K + ky*K + kx
 //
-// For nn.Conv2d: G = gradient w.r.t. the conv output (m = cout), A = the conv's (virtual, possibly
-// concatenated) input, and dW[m][q] is exactly the OIHW weight-gradient tensor.  For
-// nn.ConvTranspose2d(k, s=2): G = the layer INPUT (m = cin), A = the gradient w.r.t. its output, S = 2, and
-// dW[m][q] is the IOHW tensor.  (What autograd computes for the layers of
-// Module2/models/networks.py:1218-1282, 2329-2421, 2620-2643.)
+// For nn.Conv2d: G = gradient w.r.t. the conv output (m = cout), A = the conv's input, and dW[m][q] is
+// exactly the OIHW weight-gradient tensor.  For nn.ConvTranspose2d(k, s=2): G = the layer INPUT (m = cin),
+// A = the gradient w.r.t. its output, S = 2, and dW[m][q] is the IOHW tensor.  (What autograd computes for
+// the layers of Module2/models/networks.py:1218-1282, 2329-2421, 2620-2643.)
+//
+// Both operands arrive as PLAIN, PADDED tensors produced by pad_materialize_kernel (one streaming pass per
+// layer): A already carries the producer's InstanceNorm + activation, the concatenation of its source
+// segments and the convolution's zero / reflection padding, and both are zero-filled out to the tile grid.
+// The GEMM kernel therefore stages its tiles with unconditional, branch-free loads.
 //
 // GEMM mapping: M = m (lane = channel), N = q (lane = (ci, tap) with a per-lane precomputed LDS offset, so
 // any Cin / kernel size packs densely: the 7x7 stems with Cin = 3 use 147 of 160 columns), K = pixels:
@@ -21,17 +25,15 @@
 namespace apamd {
 
 struct WgradKParams {
-    SrcSeg g;                 // M-role tensor (chunk_begin unused)
-    SrcSeg seg[kMaxSeg];      // N-role (shifted) tensor segments; chunk_begin = first concat channel
-    int nseg;
+    const float* g;           // [N][M][GHp][GWp]   (GWp = tiles_x * 32, GHp = tiles_y * PR; zero padded)
+    const float* a;           // [N][Cin][Hp][Wp]   (origin = padded coordinate (0,0) = input (-pad,-pad); zero filled)
     int N, M, Cin, Q;         // Q = Cin * K * K
-    int GH, GW;               // spatial size of the M-role tensor (grid that is iterated)
-    int H, W;                 // spatial size of the N-role tensor
-    int pad, pad_mode;
+    int GHp, GWp, Hp, Wp;
     int tiles_x, tiles_y;     // pixel tiles per image
     int nstages, P;           // total pixel tiles (N * tiles_y * tiles_x), number of splits
     int m_tiles, q_tiles;
     float* partial;           // [P][M][Q]
+    int ablate;               // debugging only (APAMD_ABLATE): 1 = no refill of the pipeline buffers
 };
 
 template <int S_, int K_, int MT_, int NT_, int PR_>
@@ -45,17 +47,17 @@ struct WgradCfg {
     static constexpr int PLANE = (IH * IW) | 1;          // odd plane stride
     static constexpr int NCI = Q_TILE / T + 2;           // channels a q-tile can touch
     static constexpr int GE = M_TILE * NPIX, AE = NCI * PLANE;
-    static constexpr int NG = (GE + 255) / 256, NA = (AE + 255) / 256;
+    static constexpr int NG4 = (GE / 4 + 255) / 256, NA = (AE + 255) / 256;
     static size_t lds_floats() { return 2 * ((size_t)M_TILE * GS + (size_t)NCI * PLANE); }
 };
 
 template <class C>
-__global__ __launch_bounds__(256, 2) void wgrad_igemm_f32(const WgradKParams p) {
+__global__ __launch_bounds__(256, C::NA <= 20 ? 2 : 1) void wgrad_igemm_f32(const WgradKParams p) {
     constexpr int S = C::S, K = C::K, T = C::T, MT = C::MT, NT = C::NT, PR = C::PR;
-    constexpr int GS = C::GS, IW = C::IW, PLANE = C::PLANE, NCI = C::NCI, NG = C::NG, NA = C::NA;
+    constexpr int GS = C::GS, IW = C::IW, PLANE = C::PLANE, NCI = C::NCI, NA = C::NA, NG4 = C::NG4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const gbuf = smem;                                   // [2][M_TILE][GS]
-    float* const abuf = smem + 2 * C::M_TILE * GS;              // [2][NCI][PLANE]
+    float* const abuf = gbuf + 2 * C::M_TILE * GS;              // [2][NCI][PLANE]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wm = wave & 1, wq = wave >> 1;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_f32(const WgradKParams p) 
     if (ci_hi > p.Cin - 1) ci_hi = p.Cin - 1;
     const int nci = ci_hi - ci_lo + 1;
     const int st0 = (int)((long long)p.nstages * split / p.P), st1 = (int)((long long)p.nstages * (split + 1) / p.P);
-    const int GHW = p.GH * p.GW, HW = p.H * p.W;
+    const int GHW = p.GHp * p.GWp, HW = p.Hp * p.Wp;
 
     // per-lane LDS offsets of this lane's NT columns (q -> channel plane + tap shift)
     int boff[NT];
@@ -82,70 +84,53 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_f32(const WgradKParams p) 
     }
     const int aoff = (wm * MT * 32 + l32) * GS + half;
 
-    auto seg_of = [&](int c) {
-        int s = 0;
-        if (p.nseg > 1 && c >= p.seg[1].chunk_begin) s = 1;
-        if (p.nseg > 2 && c >= p.seg[2].chunk_begin) s = 2;
-        return s;
-    };
+    // ---- staging geometry, computed once: global offsets relative to the tile origin
+    int g_off[NG4];                 // float4 quads of the G tile: element e4 -> (m, px..px+3)
+#pragma unroll
+    for (int k = 0; k < NG4; ++k) {
+        const int e4 = tid + k * 256;
+        int m = e4 / (C::NPIX / 4);
+        const int px = (e4 % (C::NPIX / 4)) * 4;
+        if (m0 + m >= p.M) m = 0;   // rows beyond M are never stored; any legal address will do
+        g_off[k] = m * GHW + (px / 32) * p.GWp + (px & 31);
+    }
+    int a_off[NA];                  // scalars of the A tile: element e -> (cl, ly, lx)
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int e = tid + k * 256;
+        int cl = e / PLANE;
+        const int r = e - cl * PLANE;
+        int ly = r / IW;
+        const int lx = r - ly * IW;
+        if (cl >= nci) cl = 0;      // unused plane / pad element: harmless duplicate
+        if (ly >= C::IH) ly = 0;
+        a_off[k] = cl * HW + ly * p.Wp + lx;
+    }
 
-    float gr[NG], ar[NA];
-    auto issue = [&](int st) {
+    float4 gr[NG4];
+    float ar[NA];
+    auto issue = [&](int st) __attribute__((always_inline)) {
         const int tx = st % p.tiles_x;
         int t2 = st / p.tiles_x;
         const int ty = t2 % p.tiles_y;
         const int n = t2 / p.tiles_y;
-        const int oy0 = ty * PR, ox0 = tx * 32;
+        const float* gsrc = p.g + ((long long)n * p.M + m0) * GHW + (long long)(ty * PR) * p.GWp + tx * 32;
+        const float* asrc = p.a + ((long long)n * p.Cin + ci_lo) * HW + (long long)(ty * PR * S) * p.Wp + tx * 32 * S;
 #pragma unroll
-        for (int k = 0; k < NG; ++k) {                         // G tile: [m][py][px]
-            const int e = tid + k * 256;
-            const int m = e / C::NPIX, r = e - m * C::NPIX;
-            const int oy = oy0 + r / 32, ox = ox0 + (r & 31);
-            const bool ok = e < C::GE && m0 + m < p.M && oy < p.GH && ox < p.GW;
-            const long long off = ((long long)n * p.M + (m0 + m)) * GHW + oy * p.GW + ox;
-            float v = p.g.data[ok ? off : 0];
-            if (p.g.mean != nullptr) {
-                const int mc = ok ? n * p.M + m0 + m : 0;
-                v = (v - p.g.mean[mc]) * p.g.rstd[mc];
-                v = p.g.act == 1 ? fmaxf(v, 0.f) : (p.g.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-            }
-            gr[k] = ok ? v : 0.f;
-        }
-        const int iy0 = oy0 * S - p.pad, ix0 = ox0 * S - p.pad;
+        for (int k = 0; k < NG4; ++k) gr[k] = *reinterpret_cast<const float4*>(gsrc + g_off[k]);
 #pragma unroll
-        for (int k = 0; k < NA; ++k) {                         // A tile: [ci_local][ly][lx]
-            const int e = tid + k * 256;
-            const int cl = e / PLANE, r = e - cl * PLANE;
-            const int ly = r / IW, lx = r - ly * IW;
-            int gy = iy0 + ly, gx = ix0 + lx;
-            bool ok = e < C::AE && cl < nci && ly < C::IH;
-            if (p.pad_mode == 1) {
-                gy = reflect_clamp(gy, p.H);
-                gx = reflect_clamp(gx, p.W);
-            } else {
-                ok = ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            }
-            const int c = ci_lo + (cl < nci ? cl : 0);
-            const int s = seg_of(c);
-            const int cs = c - p.seg[s].chunk_begin;
-            const long long off = ((long long)n * p.seg[s].C + cs) * HW + gy * p.W + gx;
-            float v = p.seg[s].data[ok ? off : 0];
-            if (p.seg[s].mean != nullptr) {
-                const int mc = n * p.seg[s].C + cs;
-                v = (v - p.seg[s].mean[mc]) * p.seg[s].rstd[mc];
-            }
-            const int act = p.seg[s].act;
-            v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-            ar[k] = ok ? v : 0.f;
-        }
+        for (int k = 0; k < NA; ++k) ar[k] = asrc[a_off[k]];
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int buf) __attribute__((always_inline)) {
         float* gd = gbuf + buf * C::M_TILE * GS;
         float* ad = abuf + buf * NCI * PLANE;
 #pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const int e = tid + k * 256;
-            if (e < C::GE) gd[(e / C::NPIX) * GS + (e % C::NPIX)] = gr[k];
+        for (int k = 0; k < NG4; ++k) {
+            const int e4 = tid + k * 256;
+            if (e4 < C::GE / 4) {
+                float* d = gd + (e4 / (C::NPIX / 4)) * GS + (e4 % (C::NPIX / 4)) * 4;
+                d[0] = gr[k].x; d[1] = gr[k].y; d[2] = gr[k].z; d[3] = gr[k].w;
+            }
         }
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
@@ -169,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_igemm_f32(const WgradKParams p) 
     __syncthreads();
     for (int st = st0; st < st1; ++st) {
         const int cur = (st - st0) & 1;
-        const bool more = st + 1 < st1;
+        const bool more = st + 1 < st1 && !(p.ablate & 1);
         if (more) issue(st + 1);
         const float* G = gbuf + cur * C::M_TILE * GS + aoff;
         const float* A = abuf + cur * NCI * PLANE;
@@ -214,6 +199,50 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, lo
         float s = 0.f;
         for (int k = 0; k < P; ++k) s += partial[(long long)k * n + i];
         dw[i] = s;
+    }
+}
+
+// ---- operand preparation: out[n][c][y][x] (Hp x Wp) = padded view of act(IN(concat(src)))
+//   (y, x) <-> source (y - pad, x - pad); reflection or zero padding inside [0, H+2pad) x [0, W+2pad), zeros beyond.
+struct PadParams {
+    SrcSeg seg[kMaxSeg];      // chunk_begin = first concat channel
+    int nseg;
+    int N, C, H, W, pad, pad_mode, Hp, Wp;
+    float* out;
+};
+
+// grid: (ceil(Hp*Wp/256), C, N)
+__global__ __launch_bounds__(256) void pad_materialize_kernel(const PadParams p) {
+    const int c = blockIdx.y, n = blockIdx.z;
+    int s = 0;
+    if (p.nseg > 1 && c >= p.seg[1].chunk_begin) s = 1;
+    if (p.nseg > 2 && c >= p.seg[2].chunk_begin) s = 2;
+    // block-uniform segment: select once, by value
+    const SrcSeg sg = s == 0 ? p.seg[0] : (s == 1 ? p.seg[1] : p.seg[2]);
+    const int cs = c - sg.chunk_begin;
+    float m = 0.f, r = 1.f;
+    if (sg.mean != nullptr) { m = sg.mean[n * sg.C + cs]; r = sg.rstd[n * sg.C + cs]; }
+    const float* src = sg.data + ((long long)n * sg.C + cs) * p.H * p.W;
+    float* dst = p.out + ((long long)n * p.C + c) * p.Hp * p.Wp;
+    const int He = p.H + 2 * p.pad, We = p.W + 2 * p.pad;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < p.Hp * p.Wp; i += gridDim.x * 256) {
+        const int y = i / p.Wp, x = i - y * p.Wp;
+        float v = 0.f;
+        if (y < He && x < We) {
+            int sy = y - p.pad, sx = x - p.pad;
+            bool ok = true;
+            if (p.pad_mode == 1) {
+                sy = reflect_clamp(sy, p.H);
+                sx = reflect_clamp(sx, p.W);
+            } else {
+                ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+            }
+            if (ok) {
+                v = (src[sy * p.W + sx] - m) * r;
+                v = sg.act == 1 ? fmaxf(v, 0.f) : (sg.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+            }
+        }
+        dst[i] = v;
     }
 }
 

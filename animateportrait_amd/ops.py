@@ -203,8 +203,11 @@ def warp_concat(f, motion, flow, ifmask, level):
 def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
     srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW)."""
-    d = C.ApWgradDesc()
     n, m, gh, gw = g.data.shape
+    cin = sum(f.data.shape[1] for f in srcs)
+    if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
+        return _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
+    d = C.ApWgradDesc()
     d.N, d.M, d.GH, d.GW = n, m, gh, gw
     d.H, d.W = srcs[0].data.shape[2], srcs[0].data.shape[3]
     d.K, d.stride, d.pad, d.pad_mode = k, stride, pad, pad_mode
@@ -223,9 +226,45 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape):
     nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
     ws = torch.empty(nws, dtype=torch.float32, device=g.data.device)
     dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
-    assert dw.numel() == m * sum(f.data.shape[1] for f in srcs) * k * k
+    assert dw.numel() == m * cin * k * k
     C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
     return dw
+
+
+def pad_materialize(srcs, pad, pad_mode, hp=None, wp=None):
+    """Padded, concatenated, normalised + activated copy of the (virtual) sources: (N, sum C, Hp, Wp)."""
+    x0 = srcs[0].data
+    n, _, h, w = x0.shape
+    hp = h + 2 * pad if hp is None else hp
+    wp = w + 2 * pad if wp is None else wp
+    arr = (C.ApSrc * len(srcs))()
+    for i, f in enumerate(srcs):
+        _require_device(f.data, 'pad_materialize source')
+        arr[i].data = f.data.data_ptr()
+        arr[i].mean = f.mean.data_ptr() if f.mean is not None else None
+        arr[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
+        arr[i].C, arr[i].act = f.data.shape[1], f.act
+    out = torch.empty((n, sum(f.data.shape[1] for f in srcs), hp, wp), dtype=torch.float32, device=x0.device)
+    C.check(C.lib().ap_pad_materialize(arr, len(srcs), n, h, w, pad, pad_mode, hp, wp, _ptr(out), _stream()),
+            'pad_materialize')
+    return out
+
+
+def _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape):
+    """Weight gradient of a 'same' convolution with 1..4 output channels (the generator's last layer,
+    networks.py:1277-1279).  With M = Cout the MFMA rows would be >96 % padding, so the roles are swapped:
+        dW[co][ci][ky][kx] = sum_p' a_pad[ci][p'] * g[co][p' + (k-1-ky) - (k-1)]
+    i.e. a weight gradient with M-role = the PADDED input (Cin rows), shifted tensor = the one-channel gradient,
+    zero padding k-1, and mirrored taps."""
+    a_pad = pad_materialize(srcs, pad, pad_mode)                      # (N, Cin, H+2p, W+2p), plain
+    m = g.data.shape[1]
+    cin = a_pad.shape[1]
+    outs = []
+    for co in range(m):
+        gc = g.data[:, co:co + 1].contiguous() if m > 1 else g.data
+        dwt = wgrad(k, 1, k - 1, PAD_ZERO, Feat(a_pad), [Feat(gc)], (cin, 1, k, k))   # [ci][0][ky'][kx']
+        outs.append(dwt.flip(2, 3).permute(1, 0, 2, 3))
+    return torch.cat(outs, 0).contiguous().view(out_shape)
 
 
 def _split_contribs(contribs):

@@ -148,7 +148,13 @@ typedef struct ap_wgrad_desc {
     ap_src g;             /* g.C is ignored (M is used) */
     ap_src src[3];
 } ap_wgrad_desc;
+/* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
+ * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);
+/* out[n][c][y][x], y < Hp, x < Wp: the padded view of act(InstanceNorm(concat(src))) -- (y,x) maps to input
+ * (y-pad, x-pad) with zero or reflection padding (F.pad / nn.ReflectionPad2d), zeros beyond H+2pad / W+2pad */
+int ap_pad_materialize(const ap_src* src, int32_t nsrc, int32_t N, int32_t H, int32_t W, int32_t pad, int32_t pad_mode,
+                       int32_t Hp, int32_t Wp, float* out, ap_stream_t stream);
 int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream);
 
 /* backward of a = act(InstanceNorm(y)) w.r.t. y.  The incoming gradient is fold(g1) + g2 where g1 has spatial

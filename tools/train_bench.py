@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Time the full geomgm_ifw_fore train step (drawing config, README values) on one GPU."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from animateportrait_amd.options.base_options import TrainOptions
+from animateportrait_amd.models import create_model
+from animateportrait_amd.data.synthetic_dataset import make_train_batch
+
+def main():
+    bs = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    ngf = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+    argv = ['--model', 'geomgm_ifw_fore', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--dataset_mode', 'synthetic',
+            '--output_nc', '1', '--ngf', str(ngf), '--ndf', str(ngf), '--netg_resb_div', '3', '--netg_resb_disp', '3',
+            '--lr', '0.00005', '--lambda_geom', '50', '--lambda_geom_lipline', '50', '--more_weight_for_lip', '2',
+            '--lambda_face', '3.0', '--lambda_warp_inter', '10', '--blendbg', '1', '--niter', '70', '--niter_decay', '0',
+            '--batch_size', str(bs), '--gpu_ids', '0']
+    opt = TrainOptions().parse(argv)
+    model = create_model(opt)
+    batch = {k: (v.cuda() if torch.is_tensor(v) and k not in ('winA', 'winB', 'winB2', 'winBr') else v)
+             for k, v in make_train_batch(bs, seed=3).items()}
+    for _ in range(2):
+        model.set_input(batch); model.optimize_parameters()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        model.set_input(batch); model.optimize_parameters()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print('train step B=%d ngf=%d: %.1f ms/step  (%.1f samples/s)  max mem %.1f GB' % (
+        bs, ngf, dt * 1e3, bs / dt, torch.cuda.max_memory_allocated() / 2**30))
+    print({k: round(v, 4) for k, v in model.get_current_losses().items()})
+
+if __name__ == '__main__':
+    main()
