@@ -78,12 +78,54 @@ def cpu_baseline(budget_s=15.0):
         while True:
             og.generator_forward(sd, *args, div=3, disp=3)
             n += b
-            if time.time() - t0 > budget_s or n >= 64:
+            if time.time() - t0 > budget_s or n >= 1024:
                 break
         dt = time.time() - t0
     return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'sample': 'oracle.generator_forward ngf=64 fp32, %d frames in batches of %d (%.1f s), torch CPU %d threads'
                       % (n, b, dt, cores)}
+
+
+def train_step_ms(dev, rank, world, dist, steps):
+    """Time `steps` full train steps (after 1 warm-up) of the drawing config (readme.md:65 flags), B=16/GPU."""
+    from animateportrait_amd.options.base_options import TrainOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.data.synthetic_dataset import make_train_batch
+    argv = ['--model', 'geomgm_ifw_fore', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--dataset_mode', 'synthetic',
+            '--output_nc', '1', '--netg_resb_div', '3', '--netg_resb_disp', '3', '--lr', '0.00005', '--lambda_geom', '50',
+            '--lambda_geom_lipline', '50', '--more_weight_for_lip', '2', '--lambda_face', '3.0',
+            '--lambda_warp_inter', '10', '--blendbg', '1', '--select_target12_thre', '0.0', '--niter', '70',
+            '--niter_decay', '0', '--batch_size', str(BATCH), '--gpu_ids', str(dev.index)]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):      # the model prints its notices; keep stdout = one JSON line
+        torch.manual_seed(1234)
+        model = create_model(TrainOptions().parse(argv))
+        batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
+                 for k, v in make_train_batch(BATCH, seed=1234, rank=rank).items()}
+        model.set_input(batch)
+        model.optimize_parameters()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            model.set_input(batch)
+            model.optimize_parameters()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = model.get_current_losses()
+    return {'ms_per_step': round(dt * 1e3, 2), 'samples_per_s': round(world * BATCH / dt, 2), 'steps': steps,
+            'batch_per_gpu': BATCH, 'dtype': 'f32', 'loss_G': round(losses.get('G', float('nan')), 4),
+            'gflop_per_sample_algorithmic': 1234.0,
+            'note': 'geomgm_ifw_fore drawing config; frozen aux nets (MODNet/MobileFaceNet/Sphere20a/FlowUnet) absent '
+                    'from the reference tree: their outputs are synthetic inputs, geometry/identity terms skipped'}
 
 
 def main():
@@ -92,6 +134,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
     a = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,8 +154,11 @@ def main():
 
     from animateportrait_amd import ops
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
-    G = build_generator(dev)
-    args = [t.to(dev) for t in generator_args(make_generator_inputs(BATCH, seed=1234, rank=rank))]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):      # keep stdout = the one JSON line
+        G = build_generator(dev)
+    args =[t.to(dev) for t in generator_args(make_generator_inputs(BATCH, seed=1234, rank=rank))]
 
     def step():
         with torch.no_grad():
@@ -171,6 +217,14 @@ def main():
         except Exception:
             pass
 
+    # ---- second half of the BASELINE metric: "train step ms" -- the geomgm_ifw_fore drawing-config step
+    # (G + 5 PatchGAN D's, warp / coherence losses, Adam), B=16 per GPU, fp32, gradients all-reduced over RCCL
+    train = None
+    if a.train_steps > 0:
+        del G, args, y
+        torch.cuda.empty_cache()
+        train = train_step_ms(dev, rank, world, dist, a.train_steps)
+
     if rank == 0:
         fps = world * BATCH * a.steps / dt
         out = {'metric': 'generator frames/sec @256x256 bs=16', 'value': round(fps, 2), 'unit': 'frames/s',
@@ -183,6 +237,8 @@ def main():
                           'weights': 'random init N(0,0.02), seed 1234'},
                'conv_roofline_frac': round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                'roofline': roofline}
+        if train is not None:
+            out['train_step'] = train
         if not a.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline()
             out['speedup_vs_cpu'] = round(fps / out['cpu_baseline']['value'], 1)
