@@ -6,6 +6,7 @@
 #include "common.h"
 #include "conv_registry.h"
 #include "conv_direct.h"
+#include "conv_bf16x3.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,7 @@ struct Launch {
 struct Plan {
     const ConvKernelInfo* k = nullptr;
     int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
+    bool bf3 = false;              // conv_bf16x3<Bf3Cfg<1,3,1,2,4,4>>
     std::vector<Launch> launches;
     int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
     int chunk_begin[kMaxSeg] = {0, 0, 0};
@@ -116,6 +118,29 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.packed_floats = (long long)pl.cin_pad * K * K * pl.direct_cop;
         pl.stat_tiles = ((pl.Hout + 15) / 16) * ((pl.Wout + 63) / 64);
         return AP_OK;
+    }
+    // split-bf16 matrix path (conv_bf16x3.h): wide stride-1 3x3 layers when the caller allows ~1e-4 relative error
+    if (d->precision == AP_PRECISION_BF16X3 && !d->transposed && d->stride == 1 && K == 3 && d->Cout >= 64 &&
+        pl.Cin >= 64 && !env_int("APAMD_NO_BF16X3", 0)) {
+        bool seg_ok = true;
+        for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
+        if (seg_ok) {
+            using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
+            pl.bf3 = true;
+            pl.nchunks = 0;
+            for (int s = 0; s < d->nsrc; ++s) {
+                pl.chunk_begin[s] = pl.nchunks;
+                pl.nchunks += d->src[s].C / 16;
+            }
+            pl.cin_pad = pl.nchunks * 16;
+            pl.co_tiles = (d->Cout + BC::CO_TILE - 1) / BC::CO_TILE;
+            if (BC::lds_bytes(pl.nchunks > 1 ? 2 : 1, pl.cin_pad) <= 160 * 1024) {
+                pl.packed_floats = (long long)pl.co_tiles * pl.nchunks * BC::wfloats();
+                pl.stat_tiles = ((pl.Hout + BC::TH - 1) / BC::TH) * ((pl.Wout + 31) / 32);
+                return AP_OK;
+            }
+            pl.bf3 = false;
+        }
     }
     // tile configuration by output width
     int co_tile = d->Cout >= 96 ? 128 : (d->Cout >= 48 ? 64 : 32);
@@ -353,6 +378,10 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         snprintf(buf, buflen, "DirectCfg<%d, %d>", d->KH, pl.direct_cop);
         return AP_OK;
     }
+    if (pl.bf3) {
+        snprintf(buf, buflen, "Bf3Cfg<1, 3, 1, 2, 4, 4>");
+        return AP_OK;
+    }
     snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->K, pl.k->WCO, pl.k->MT,
              pl.k->WPX, pl.k->NT);
     return AP_OK;
@@ -372,6 +401,18 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
         for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
         hipLaunchKernelGGL(pack_direct_kernel, dim3(64), dim3(256), 0, (hipStream_t)stream, p);
         return check_launch("pack_direct_kernel");
+    }
+    if (pl.bf3) {
+        using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
+        PackBf3Params p;
+        memset(&p, 0, sizeof(p));
+        p.w = weight; p.out = reinterpret_cast<unsigned short*>(packed);
+        p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout; p.flip = d->w_flip;
+        p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
+        p.CO_TILE = BC::CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
+        hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("pack_bf16x3_kernel");
     }
     for (const auto& L : pl.launches) {
         PackParams p;
@@ -405,6 +446,40 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
+    }
+    if (pl.bf3) {
+        using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
+        const void* fn = reinterpret_cast<const void*>(&conv_bf16x3<BC>);
+        rc = ensure_lds_attr(fn);
+        if (rc) return rc;
+        ConvKParams p;
+        memset(&p, 0, sizeof(p));
+        p.nseg = d->nsrc;
+        for (int s = 0; s < d->nsrc; ++s) {
+            p.seg[s].data = d->src[s].data; p.seg[s].mean = d->src[s].mean; p.seg[s].rstd = d->src[s].rstd;
+            p.seg[s].C = d->src[s].C; p.seg[s].act = d->src[s].act; p.seg[s].chunk_begin = pl.chunk_begin[s];
+        }
+        p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+        p.OH = pl.Hout; p.OW = pl.Wout; p.dy0 = -d->pad; p.dx0 = -d->pad;
+        p.pad_mode = d->pad_mode;
+        p.y = y;
+        p.o_nstride = (long long)d->Cout * pl.Hout * pl.Wout;
+        p.o_cstride = (long long)pl.Hout * pl.Wout;
+        p.o_rstride = pl.Wout;
+        p.osy = p.osx = 1;
+        p.wp = packed; p.bias = bias; p.act = d->act;
+        p.stats = stat_partials; p.stat_tiles = pl.stat_tiles; p.stat_tile_off = 0;
+        p.ntaps = 9; p.nchunks = pl.nchunks;
+        p.tiles_x = (pl.Wout + 31) / 32; p.tiles_y = (pl.Hout + BC::TH - 1) / BC::TH; p.co_tiles = pl.co_tiles;
+        p.cin_pad = pl.cin_pad;
+        p.wfloats = BC::wfloats();
+        p.ablate = env_int("APAMD_ABLATE", 0);
+        const size_t lds = BC::lds_bytes(p.nchunks > 1 ? 2 : 1, p.cin_pad);
+        const long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * pl.co_tiles;
+        void* args[] = {&p};
+        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
+        return AP_OK;
     }
     rc = ensure_lds_attr(pl.direct_cop ? direct_fn(d->KH, pl.direct_cop) : pl.k->fn);
     if (rc) return rc;

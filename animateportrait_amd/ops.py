@@ -7,6 +7,7 @@ activation that the CONSUMER applies while it stages the tensor into LDS.  This 
 (Module2/models/networks.py:1218-1282) run as one kernel per convolution.
 """
 import ctypes
+import os
 
 import torch
 
@@ -18,6 +19,14 @@ EPS = 1e-5  # nn.InstanceNorm2d default (networks.py:33-34)
 # bumped by optimisers that update parameters through raw pointers (optim.FlatAdam); part of the key of the
 # per-layer packed-weight caches
 WEIGHTS_EPOCH = 0
+
+# Arithmetic of the wide 3x3 layers (include/animateportrait_amd.h, ap_conv_desc.precision):
+#   'fp32'   exact fp32 MFMA everywhere;
+#   'bf16x3' operands split into bf16 head + tail, three bf16 MFMAs per tile, fp32 accumulation: fp32-class
+#            results (generator L-inf ~1e-4 vs the fp32 reference, inside the 1e-3 budget) at ~5x the MFMA rate.
+# Picked up by every ConvSpec created afterwards (APAMD_PRECISION=fp32 forces exact arithmetic).
+PRECISION_FP32, PRECISION_BF16X3 = 0, 1
+DEFAULT_PRECISION = PRECISION_FP32 if os.environ.get('APAMD_PRECISION', 'bf16x3') == 'fp32' else PRECISION_BF16X3
 
 
 def _stream():
@@ -62,6 +71,7 @@ class ConvSpec:
         self.cout, self.k, self.stride, self.pad, self.pad_mode = cout, k, stride, pad, pad_mode
         self.transposed, self.output_padding = transposed, output_padding
         self.w_layout, self.w_flip = w_layout, w_flip
+        self.precision = DEFAULT_PRECISION
 
     def desc(self, n, h, w, srcs=None, act=ACT_NONE):
         d = C.ApConvDesc()
@@ -71,6 +81,7 @@ class ConvSpec:
         d.transposed, d.output_padding = int(self.transposed), self.output_padding
         d.w_layout, d.w_flip, d.act = self.w_layout, int(self.w_flip), act
         d.nsrc = len(self.cin_segments)
+        d.precision = self.precision
         for i, c in enumerate(self.cin_segments):
             d.src[i].C = c
             if srcs is not None:

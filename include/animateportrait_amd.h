@@ -35,6 +35,7 @@ enum { AP_OK = 0, AP_ERR_INVALID = -1, AP_ERR_UNSUPPORTED = -2, AP_ERR_LAUNCH = 
 enum { AP_ACT_NONE = 0, AP_ACT_RELU = 1, AP_ACT_LRELU = 2 /* slope 0.2 */, AP_ACT_TANH = 3 };
 enum { AP_PAD_ZERO = 0, AP_PAD_REFLECT = 1 };
 enum { AP_W_OIHW = 0 /* nn.Conv2d weight */, AP_W_IOHW = 1 /* nn.ConvTranspose2d weight */ };
+enum { AP_PRECISION_FP32 = 0, AP_PRECISION_BF16X3 = 1 };
 
 /* One channel segment of a (virtually concatenated) convolution input.  The
  * loader applies, per element, x := act((x - mean[n,c]) * rstd[n,c]) when
@@ -69,7 +70,10 @@ typedef struct ap_conv_desc {
     int32_t w_flip;       /* 1: use tap (KH-1-ky, KW-1-kx) */
     int32_t act;          /* epilogue activation after bias: AP_ACT_NONE / LRELU / TANH / RELU */
     int32_t nsrc;         /* 1..3 */
-    int32_t reserved;
+    int32_t precision;    /* AP_PRECISION_FP32: exact fp32 MFMA.  AP_PRECISION_BF16X3: the caller accepts fp32-class
+                           * (~1e-4 relative) results; wide 3x3 layers then run on the bf16 matrix pipe with operands
+                           * split into bf16 head + tail (three MFMAs per tile, fp32 accumulation); other layers are
+                           * unaffected.  The same value must be used for pack_weights and fwd. */
     ap_src src[3];
 } ap_conv_desc;
 

@@ -360,3 +360,55 @@ def test_patchgan_grads(dev, golden):
                 assert float(p.grad.abs().max()) == 0.0
                 continue
             assert linf(p.grad, ref) <= 3e-3 * float(ref.abs().max()) + 1e-5, k
+
+
+# ------------------------------------------------------------------------------------ split-bf16 matrix path
+BF3_CASES = [
+    # cin segs, cout, mode, H, W
+    ([64], 64, 'reflect', 32, 32),
+    ([128, 16, 16], 96, 'zero', 20, 70),
+    ([256], 256, 'reflect', 64, 64),
+    ([64, 64, 64], 130, 'zero', 17, 33),
+]
+
+
+@pytest.mark.parametrize('case', BF3_CASES)
+def test_conv_bf16x3_vs_oracle(dev, case):
+    """Wide 3x3 layers on the bf16 matrix pipe (operands split into bf16 head + tail): fp32-class accuracy, and the
+    exact-fp32 kernel on the same data for comparison."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    segs, cout, mode, H, W = case
+    g = torch.Generator().manual_seed(sum(map(ord, str(case))))
+    n = 2
+    xs = [torch.randn(n, c, H, W, generator=g) * 2 + 0.5 for c in segs]
+    w = torch.randn(cout, sum(segs), 3, 3, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    feats, refs = [], []
+    for i, x in enumerate(xs):
+        if i % 2 == 0:
+            m = x.mean((2, 3)).reshape(-1)
+            r = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+            feats.append(ops.Feat(x.to(dev), m.to(dev), r.to(dev), ops.ACT_RELU))
+            refs.append(F.relu(F.instance_norm(x)))
+        else:
+            feats.append(ops.Feat(x.to(dev)))
+            refs.append(x)
+    xr = torch.cat(refs, 1).double()
+    ref = (F.conv2d(F.pad(xr, (1,) * 4, mode='reflect'), w.double(), b.double()) if mode == 'reflect'
+           else F.conv2d(xr, w.double(), b.double(), padding=1))
+    scale = float(ref.abs().max())
+    errs = {}
+    for prec in (ops.PRECISION_BF16X3, ops.PRECISION_FP32):
+        layer = ConvLayer(segs, cout, 3, 1, 1, ops.PAD_REFLECT if mode == 'reflect' else ops.PAD_ZERO).to(dev)
+        layer.spec.precision = prec
+        with torch.no_grad():
+            layer.weight.copy_(w); layer.bias.copy_(b)
+        y = layer.run(feats, act=ops.ACT_NONE)
+        errs[prec] = linf(y.data, ref) / scale
+        yn = layer.run(feats, norm_act=ops.ACT_NONE)          # statistics epilogue
+        refn = F.instance_norm(ref.float())
+        got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
+        assert linf(got, refn) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
+    assert errs[ops.PRECISION_FP32] < 2e-6
+    assert errs[ops.PRECISION_BF16X3] < 5e-5, errs     # ~2^-17 per product, averaged down by the K-sum
