@@ -30,6 +30,7 @@ class ApConvDesc(ctypes.Structure):
                 ('transposed', ctypes.c_int32), ('output_padding', ctypes.c_int32),
                 ('w_layout', ctypes.c_int32), ('w_flip', ctypes.c_int32), ('act', ctypes.c_int32),
                 ('nsrc', ctypes.c_int32), ('precision', ctypes.c_int32),
+                ('presplit', ctypes.c_int32), ('reserved', ctypes.c_int32),
                 ('src', ApSrc * 3)]
 
 
@@ -48,6 +49,10 @@ SIGNATURES = {
                                           ctypes.POINTER(ctypes.c_int32)]),
     'ap_conv2d_packed_floats': (ctypes.c_int64, [ctypes.POINTER(ApConvDesc)]),
     'ap_conv2d_stat_tiles': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_wants_presplit': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_split_prepass_bytes': (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'ap_split_prepass': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
     'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
     'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),

@@ -1,6 +1,6 @@
 // conv_bf16x3.h -- the implicit-GEMM convolution of conv_igemm.h on the bf16 matrix pipe, at fp32-class accuracy.
 //
-// gfx950 has no TF32-like mode and its exact-fp32 MFMA runs at 1/16 of the bf16 rate.  This kernel splits
+// gfx950 has no TF32-like mode and its exact-fp32 MFMA runs at 1/16 of the bf16 rate.  This path splits
 // every fp32 operand into a bf16 head and a bf16 tail (x = xh + xl, |xl| <= 2^-9 |x|) and evaluates
 //     x * w  ~=  xh*wh + xh*wl + xl*wh            (the dropped xl*wl term is <= 2^-18 |x w|)
 // with three v_mfma_f32_32x32x16_bf16 per tile and fp32 accumulation: 3/16 of the fp32-MFMA time per FLOP.
@@ -9,12 +9,14 @@
 // reference, against the 1e-3 budget of BASELINE.json and 7.8e-2 for plain bf16.
 //
 // Data flow (same im2col-free scheme as conv_igemm.h; reference layers Module2/models/networks.py:1251, 2329-2421):
-//   * channel chunk = 16 (one MFMA K); LDS activation tile [head|tail][k-group of 8 ch][IH*IW px][8 x bf16]:
-//     a B fragment is ONE 16-byte ds_read_b128 per lane (lane = pixel, half-wave = k-group), conflict-free;
-//   * weights are packed on the device as the LDS image [head|tail][tap][k-group][cout][8 x bf16] and streamed with
-//     global_load_lds_dwordx4; an A fragment is one ds_read_b128 (lane = cout);
-//   * the loader gathers 8 channels of one pixel (8 coalesced dword loads), applies the producer's InstanceNorm +
-//     activation + padding exactly like the fp32 kernel, splits, and writes two 16-byte LDS slots;
+//   * split_prepass_kernel (one streaming pass per activation tensor, shared by all its consumers) applies the
+//     producer's InstanceNorm + activation and writes the split tensor XS[n][head|tail][C/8][H*W][8 x bf16]
+//     (16-byte slots; one extra all-zero slot at the end serves every zero-padding tap);
+//   * the convolution stages BOTH operands with global_load_lds_dwordx4 only -- no staging registers, no VALU:
+//     activation tile [head|tail][k-group][IH*IW px] slots (reflection / zero padding = per-lane source address),
+//     weights pre-packed as the LDS image [head|tail][tap][k-group][cout] slots;
+//   * channel chunk = 16 (one MFMA K); an A / B fragment is ONE ds_read_b128 per lane (lane = cout / pixel,
+//     half-wave = k-group), conflict-free; fragments of tap t+1 are fetched while tap t multiplies;
 //   * epilogue identical to the fp32 kernel (bias, activation, InstanceNorm partial statistics).
 #pragma once
 #include "conv_igemm.h"
@@ -31,16 +33,15 @@ struct Bf3Cfg {
     static constexpr int CO_TILE = WCO * MT * 32;
     static constexpr int IH = (TH - 1) * S + K;
     static constexpr int IW = 31 * S + K;
-    static constexpr int PLANE = IH * IW;                  // pixels of the staged tile
-    static constexpr int X_SLOTS = 4 * PLANE;              // 16-byte slots: [part][kgroup][pixel]
-    static constexpr int W_SLOTS = 2 * T * 2 * CO_TILE;    // [part][tap][kgroup][cout]
-    static constexpr int NIT = (2 * PLANE + 255) / 256;    // (pixel, kgroup) items per thread
+    static constexpr int PLANE = IH * IW;                          // pixels of the staged tile
+    static constexpr int XP = (2 * PLANE + 63) / 64 * 64;          // slots per part: [kgroup][pixel], padded to whole DMA pieces
+    static constexpr int X_SLOTS = 2 * XP;                         // [part][kgroup][pixel]
+    static constexpr int W_SLOTS = 2 * T * 2 * CO_TILE;            // [part][tap][kgroup][cout]
+    static constexpr int NIT = XP / 256 + (XP % 256 ? 1 : 0);      // DMA pieces per thread and part
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(W_SLOTS % 64 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
-    static int wfloats() { return W_SLOTS * 4; }           // floats per (cout tile, chunk) weight block
-    static size_t lds_bytes(int nbuf, int cin_pad) {
-        return (size_t)nbuf * (X_SLOTS + W_SLOTS) * 16 + 2 * (size_t)cin_pad * 4;
-    }
+    static int wfloats() { return W_SLOTS * 4; }                   // floats per (cout tile, chunk) weight block
+    static size_t lds_bytes(int nbuf) { return (size_t)nbuf * (X_SLOTS + W_SLOTS) * 16; }
 };
 
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
@@ -48,10 +49,11 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(v - (float)hi);
 }
 
+// seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
-    constexpr int CI = C::CI, S = C::S, K = C::K, T = C::T, MT = C::MT, NT = C::NT, WCO = C::WCO;
-    constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE;
+    constexpr int S = C::S, K = C::K, T = C::T, MT = C::MT, NT = C::NT, WCO = C::WCO;
+    constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* const smem = reinterpret_cast<uint4*>(smem_raw);
 
@@ -78,8 +80,6 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     const int nbuf = p.nchunks > 1 ? 2 : 1;
     uint4* const wbuf = smem;                                  // [nbuf][W_SLOTS]
     uint4* const xbuf = smem + nbuf * C::W_SLOTS;              // [nbuf][X_SLOTS]
-    float* const s_mean = reinterpret_cast<float*>(xbuf + nbuf * C::X_SLOTS);
-    float* const s_rstd = s_mean + p.cin_pad;
 
     auto seg_of = [&](int chunk) {
         int s = 0;
@@ -87,24 +87,16 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
         return s;
     };
-    for (int c = tid; c < p.cin_pad; c += 256) {
-        const int s = seg_of(c / CI);
-        const int cs = c - p.seg[s].chunk_begin * CI;
-        float m = 0.f, r = 1.f;
-        if (p.seg[s].mean != nullptr && cs < p.seg[s].C) {
-            m = p.seg[s].mean[n * p.seg[s].C + cs];
-            r = p.seg[s].rstd[n * p.seg[s].C + cs];
-        }
-        s_mean[c] = m;
-        s_rstd[c] = r;
-    }
 
-    // ---- loader geometry: item it = (k-group, pixel of the staged tile); stage-invariant
-    int goff[NIT];
+    // ---- DMA geometry: piece k of this thread covers slot it = tid + k*256 of a part = (k-group, tile pixel);
+    // source = that pixel of the image (reflected) or the all-zero slot (zero padding, tile padding)
+    int goff[NIT];      // pixel offset inside a channel-group plane, or -1 -> zero slot
+    int gkg[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int it = tid + k * 256;
-        const int pix = it % PLANE;
+        const int kg = it >= PLANE ? 1 : 0;
+        const int pix = it - kg * PLANE;
         const int ly = pix / IW, lx = pix - ly * IW;
         int gy = iy0 + ly, gx = ix0 + lx;
         bool ok = it < 2 * PLANE;
@@ -115,48 +107,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
         }
         goff[k] = ok ? gy * W + gx : -1;
+        gkg[k] = kg;
     }
-    float xr[NIT][8];
-    auto issue_x = [&](int chunk) __attribute__((always_inline)) {
+    auto issue_x = [&](int chunk, uint4* dst) __attribute__((always_inline)) {
         const int s = seg_of(chunk);
-        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
-        const float* base = p.seg[s].data + ((long long)n * p.seg[s].C + cbase) * HW;
-        const int cleft = p.seg[s].C - cbase;
+        const int cg0 = (chunk - p.seg[s].chunk_begin) * 2;          // first channel group of the chunk
+        const int CG = p.seg[s].C >> 3;
+        const uint4* xs = reinterpret_cast<const uint4*>(p.seg[s].data);
+        const long long zero_slot = (long long)p.N * 2 * CG * HW;
 #pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int kg = (tid + k * 256) / PLANE;
+        for (int part = 0; part < 2; ++part) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const int ch = kg * 8 + c;
-                const bool ok = goff[k] >= 0 && ch < cleft;
-                xr[k][c] = base[ok ? ch * HW + goff[k] : 0];
-            }
-        }
-    };
-    auto commit_x = [&](int chunk, uint4* dst) __attribute__((always_inline)) {
-        const int s = seg_of(chunk);
-        const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
-        const int cleft = p.seg[s].C - cbase;
-        const int act = p.seg[s].act;
-#pragma unroll
-        for (int k = 0; k < NIT; ++k) {
-            const int it = tid + k * 256;
-            if (it < 2 * PLANE) {
-                const int kg = it / PLANE, pix = it - kg * PLANE;
-                bf16x8 hv, lv;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const int ch = kg * 8 + c;
-                    float v = (xr[k][c] - s_mean[chunk * CI + ch]) * s_rstd[chunk * CI + ch];
-                    v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-                    v = (goff[k] >= 0 && ch < cleft) ? v : 0.f;     // padding zeros of the NORMALISED tensor
-                    __bf16 h, l;
-                    split_bf16(v, h, l);
-                    hv[c] = h;
-                    lv[c] = l;
+            for (int k = 0; k < NIT; ++k) {
+                if (k * 256 + wave * 64 < XP) {                       // wave-uniform: whole piece inside the part
+                    const long long src = goff[k] >= 0
+                        ? ((long long)(n * 2 + part) * CG + cg0 + gkg[k]) * HW + goff[k] : zero_slot;
+                    glds16(reinterpret_cast<const float*>(xs + src),
+                           reinterpret_cast<float*>(dst + part * XP + k * 256 + wave * 64));
                 }
-                *reinterpret_cast<bf16x8*>(dst + (0 * 2 + kg) * PLANE + pix) = hv;
-                *reinterpret_cast<bf16x8*>(dst + (1 * 2 + kg) * PLANE + pix) = lv;
             }
         }
     };
@@ -175,49 +143,49 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-    __syncthreads();   // s_mean / s_rstd visible
-    issue_x(0);
+    issue_x(0, xbuf);
     issue_w(0, wbuf);
-    commit_x(0, xbuf);
     __syncthreads();
 
     // fragment addresses (16-byte slots)
     const int a_slot = half * CO_TILE + wco * MT * 32 + l32;                       // + ((part*T + t)*2) * CO_TILE + m*32
-    const int b_slot = half * PLANE + (wpx * NT) * S * IW + l32 * S;               // + part*2*PLANE + toff + q*S*IW
+    const int b_slot = half * PLANE + (wpx * NT) * S * IW + l32 * S;               // + part*XP + toff + q*S*IW
 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int cur = chunk & 1;
-        const bool refill = chunk + 1 < p.nchunks && !(p.ablate & 1);
+        if (chunk + 1 < p.nchunks && !(p.ablate & 1)) {
+            issue_x(chunk + 1, xbuf + (cur ^ 1) * C::X_SLOTS);
+            issue_w(chunk + 1, wbuf + (cur ^ 1) * C::W_SLOTS);
+        }
         const uint4* Wc = wbuf + cur * C::W_SLOTS + a_slot;
         const uint4* Xc = xbuf + cur * C::X_SLOTS + b_slot;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
+        bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+        auto fetch = [&](int t, int buf) __attribute__((always_inline)) {
             const int toff = (t / K) * IW + (t % K);
-            bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                ah[m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
-                al[m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+                ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
+                al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
             }
 #pragma unroll
             for (int q = 0; q < NT; ++q) {
-                bh[q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
-                bl[q] = *reinterpret_cast<const bf16x8*>(Xc + 2 * PLANE + toff + q * S * IW);
+                bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
+                bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
             }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int cb = t & 1;
+            if (t + 1 < T) fetch(t + 1, cb ^ 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
+                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
                 }
-            // refill of the other buffer inside the MFMA stream: loads after the first tap, split + ds_write late
-            if (t == 0 && refill) {
-                issue_x(chunk + 1);
-                issue_w(chunk + 1, wbuf + (cur ^ 1) * C::W_SLOTS);
-            }
-            if (t == (T * 2) / 3 && refill) commit_x(chunk + 1, xbuf + (cur ^ 1) * C::X_SLOTS);
         }
         if (!(p.ablate & 2)) __syncthreads();
     }
@@ -284,6 +252,33 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             }
         }
     }
+}
+
+// ---- activation pre-pass: XS[n][part][cg][pix] (16-byte slots of 8 bf16) = split(act((x - mean) * rstd)),
+// plus one all-zero slot at index N*2*(C/8)*HW.  grid: (ceil(HW/256), C/8, N).  HBM-bound: reads C*HW*4 B and
+// writes the same amount per sample.
+__global__ __launch_bounds__(256) void split_prepass_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, int act, int N, int C,
+                                                            int HW, uint4* __restrict__ out) {
+    const int cg = blockIdx.y, n = blockIdx.z, CG = C >> 3;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && cg == 0 && n == 0 && threadIdx.x == 0)
+        out[(long long)N * 2 * CG * HW] = make_uint4(0u, 0u, 0u, 0u);
+    if (pix >= HW) return;
+    bf16x8 hv, lv;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int ch = cg * 8 + c;
+        float v = x[((long long)n * C + ch) * HW + pix];
+        if (mean != nullptr) v = (v - mean[n * C + ch]) * rstd[n * C + ch];
+        v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+        __bf16 h, l;
+        split_bf16(v, h, l);
+        hv[c] = h;
+        lv[c] = l;
+    }
+    *reinterpret_cast<bf16x8*>(out + ((long long)(n * 2 + 0) * CG + cg) * HW + pix) = hv;
+    *reinterpret_cast<bf16x8*>(out + ((long long)(n * 2 + 1) * CG + cg) * HW + pix) = lv;
 }
 
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16

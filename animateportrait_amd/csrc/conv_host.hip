@@ -134,7 +134,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
             }
             pl.cin_pad = pl.nchunks * 16;
             pl.co_tiles = (d->Cout + BC::CO_TILE - 1) / BC::CO_TILE;
-            if (BC::lds_bytes(pl.nchunks > 1 ? 2 : 1, pl.cin_pad) <= 160 * 1024) {
+            if (BC::lds_bytes(pl.nchunks > 1 ? 2 : 1) <= 160 * 1024) {
                 pl.packed_floats = (long long)pl.co_tiles * pl.nchunks * BC::wfloats();
                 pl.stat_tiles = ((pl.Hout + BC::TH - 1) / BC::TH) * ((pl.Wout + 31) / 32);
                 return AP_OK;
@@ -369,6 +369,28 @@ int32_t ap_conv2d_stat_tiles(const ap_conv_desc* d) {
     return rc ? rc : pl.stat_tiles;
 }
 
+int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    return rc ? rc : (pl.bf3 ? 1 : 0);
+}
+
+int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W) {
+    if (N < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return fail(AP_ERR_INVALID, "split_prepass: C=%d must be a multiple of 8", C);
+    return ((int64_t)N * 2 * (C / 8) * H * W + 1) * 16;
+}
+
+int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {
+    if (!src || !src->data || !out) return fail(AP_ERR_INVALID, "split_prepass: null pointer");
+    if (ap_split_prepass_bytes(N, src->C, H, W) < 0) return AP_ERR_INVALID;
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "split_prepass: mean/rstd mismatch");
+    if (N > 65535 || src->C / 8 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_prepass: grid too large");
+    dim3 grid((H * W + 255) / 256, src->C / 8, N);
+    hipLaunchKernelGGL(split_prepass_kernel, grid, dim3(256), 0, (hipStream_t)stream, src->data, src->mean, src->rstd,
+                       src->act, N, src->C, H * W, reinterpret_cast<uint4*>(out));
+    return check_launch("split_prepass_kernel");
+}
+
 int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
     Plan pl;
     int rc = make_plan(d, pl);
@@ -441,6 +463,7 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
+    if (d->presplit && !pl.bf3) return fail(AP_ERR_INVALID, "desc.presplit set for a layer that does not take split sources");
     for (int s = 0; s < d->nsrc; ++s) {
         if (!d->src[s].data) return fail(AP_ERR_INVALID, "segment %d: null data", s);
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
@@ -449,6 +472,9 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
     }
     if (pl.bf3) {
         using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
+        if (!d->presplit)
+            return fail(AP_ERR_INVALID, "this layer runs on the split-bf16 path: pass sources prepared by "
+                                        "ap_split_prepass and set desc.presplit (see ap_conv2d_wants_presplit)");
         const void* fn = reinterpret_cast<const void*>(&conv_bf16x3<BC>);
         rc = ensure_lds_attr(fn);
         if (rc) return rc;
@@ -474,7 +500,7 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         p.cin_pad = pl.cin_pad;
         p.wfloats = BC::wfloats();
         p.ablate = env_int("APAMD_ABLATE", 0);
-        const size_t lds = BC::lds_bytes(p.nchunks > 1 ? 2 : 1, p.cin_pad);
+        const size_t lds = BC::lds_bytes(p.nchunks > 1 ? 2 : 1);
         const long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * pl.co_tiles;
         void* args[] = {&p};
         hipError_t e = hipLaunchKernel(fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);

@@ -47,10 +47,11 @@ def _require_device(t, name):
 
 class Feat:
     """act((data - mean) * rstd) with mean/rstd of shape (N*C,), or a plain tensor when mean is None."""
-    __slots__ = ('data', 'mean', 'rstd', 'act')
+    __slots__ = ('data', 'mean', 'rstd', 'act', 'xs')
 
     def __init__(self, data, mean=None, rstd=None, act=ACT_NONE):
         self.data, self.mean, self.rstd, self.act = data, mean, rstd, act
+        self.xs = None     # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
 
     @property
     def shape(self):
@@ -131,6 +132,27 @@ def pack_weights(spec, weight):
     return packed
 
 
+def presplit(f):
+    """Split-bf16 copy of a (virtual) feature: XS[n][head|tail][C/8][H*W][8 x bf16] with the producer's
+    InstanceNorm + activation applied (ap_split_prepass).  Cached on the Feat: one pass serves every consumer."""
+    if f.xs is None:
+        x = f.data
+        n, c, h, w = x.shape
+        _require_device(x, 'presplit source')
+        lib = C.lib()
+        nbytes = C.check(lib.ap_split_prepass_bytes(n, c, h, w), 'split_prepass_bytes')
+        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        s = C.ApSrc()
+        s.data = x.data_ptr()
+        s.mean = f.mean.data_ptr() if f.mean is not None else None
+        s.rstd = f.rstd.data_ptr() if f.rstd is not None else None
+        s.C, s.act = c, f.act
+        C.check(lib.ap_split_prepass(ctypes.byref(s), n, h, w, ctypes.c_void_p(out.data_ptr()), _stream()),
+                'split_prepass')
+        f.xs = out
+    return f.xs
+
+
 def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE):
     """Run one convolution.  Returns a Feat:
     * want_stats=False: materialised ``act(conv + bias)``;
@@ -144,6 +166,13 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
             raise ValueError('conv2d: source of shape %s does not match segment C=%d' % (tuple(f.data.shape), c))
     d = spec.desc(n, h, w, srcs, act)
     lib = C.lib()
+    if spec.precision != PRECISION_FP32 and C.check(lib.ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'):
+        # this layer runs on the split-bf16 matrix path: hand it the split copies of its sources
+        d.presplit = 1
+        for i, f in enumerate(srcs):
+            d.src[i].data = presplit(f).data_ptr()
+            d.src[i].mean = d.src[i].rstd = None
+            d.src[i].act = ACT_NONE
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
     y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)

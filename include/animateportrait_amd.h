@@ -74,6 +74,9 @@ typedef struct ap_conv_desc {
                            * (~1e-4 relative) results; wide 3x3 layers then run on the bf16 matrix pipe with operands
                            * split into bf16 head + tail (three MFMAs per tile, fp32 accumulation); other layers are
                            * unaffected.  The same value must be used for pack_weights and fwd. */
+    int32_t presplit;     /* 1: src[s].data are split tensors written by ap_split_prepass (mean/rstd/act already applied
+                           * there and ignored here).  Required iff ap_conv2d_wants_presplit(d) == 1. */
+    int32_t reserved;
     ap_src src[3];
 } ap_conv_desc;
 
@@ -98,6 +101,14 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
  * pre-activation output for every (n, cout) (InstanceNorm2d statistics, networks.py:33-34). */
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream);
+
+/* Split-bf16 path (precision = AP_PRECISION_BF16X3, wide 3x3 layers): the convolution consumes its sources as
+ * split tensors XS[n][head|tail][C/8][H*W][8 x bf16] (+ one zero slot).  ap_split_prepass applies the producer's
+ * InstanceNorm + activation (src->mean/rstd/act) once and writes that tensor; it can be shared by every consumer of
+ * the same activation.  `out` must hold ap_split_prepass_bytes() bytes, 16-byte aligned. */
+int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d);
+int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W);
+int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream);
 
 /* name of the conv_igemm_f32 instantiation the plan selects for `d` (as it appears, demangled, in a
  * rocprofv3 kernel trace), e.g. "ConvCfg<4, 1, 3, 2, 2, 2, 2>"; used by bench.py to attribute time per kernel */

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_ctypes_struct_layout_matches_header():
     from animateportrait_amd import _capi
     assert ctypes.sizeof(_capi.ApSrc) == 32
-    assert ctypes.sizeof(_capi.ApConvDesc) == 16 * 4 + 3 * 32
+    assert ctypes.sizeof(_capi.ApConvDesc) == 18 * 4 + 3 * 32
 
 
 def test_planning_queries_need_no_gpu():
