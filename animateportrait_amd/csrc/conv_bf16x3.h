@@ -28,20 +28,25 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_>
 struct Bf3Cfg {
     static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
-    static constexpr int T = K * K;
+    static constexpr int TMAX = K > 0 ? K * K : 4;                 // K == 0: <= 4 run-time taps in a 2 x 2 window
+    static constexpr int EXT = K > 0 ? K - 1 : 1;
     static constexpr int TH = WPX * NT;
     static constexpr int CO_TILE = WCO * MT * 32;
-    static constexpr int IH = (TH - 1) * S + K;
-    static constexpr int IW = 31 * S + K;
+    static constexpr int IH = (TH - 1) * S + EXT + 1;
+    static constexpr int IW = 31 * S + EXT + 1;
     static constexpr int PLANE = IH * IW;                          // pixels of the staged tile
     static constexpr int XP = (2 * PLANE + 63) / 64 * 64;          // slots per part: [kgroup][pixel], padded to whole DMA pieces
     static constexpr int X_SLOTS = 2 * XP;                         // [part][kgroup][pixel]
-    static constexpr int W_SLOTS = 2 * T * 2 * CO_TILE;            // [part][tap][kgroup][cout]
+    static int w_slots(int ntaps) { return 2 * ntaps * 2 * CO_TILE; }   // [part][tap][kgroup][cout], multiple of 64
     static constexpr int NIT = XP / 256 + (XP % 256 ? 1 : 0);      // DMA pieces per thread and part
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
-    static_assert(W_SLOTS % 64 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
-    static int wfloats() { return W_SLOTS * 4; }                   // floats per (cout tile, chunk) weight block
-    static size_t lds_bytes(int nbuf) { return (size_t)nbuf * (X_SLOTS + W_SLOTS) * 16; }
+    static_assert(CO_TILE % 16 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
+    static int wfloats(int ntaps) { return w_slots(ntaps) * 4; }   // floats per (cout tile, chunk) weight block
+    static size_t lds_bytes(int nbuf, int ntaps) {
+        const size_t pipe = (size_t)nbuf * (X_SLOTS + w_slots(ntaps)) * 16;
+        const size_t epi = (4 * 32 * 36 + WPX * CO_TILE * 2) * 4;   // epilogue patches + statistics
+        return pipe > epi ? pipe : epi;
+    }
 };
 
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
@@ -52,7 +57,7 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
 // seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
-    constexpr int S = C::S, K = C::K, T = C::T, MT = C::MT, NT = C::NT, WCO = C::WCO;
+    constexpr int S = C::S, K = C::K, TMAX = C::TMAX, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* const smem = reinterpret_cast<uint4*>(smem_raw);
@@ -78,8 +83,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     const int H = p.H, W = p.W, HW = H * W;
 
     const int nbuf = p.nchunks > 1 ? 2 : 1;
+    const int T = K > 0 ? K * K : p.ntaps;
+    const int W_SLOTS = 2 * T * 2 * CO_TILE;
     uint4* const wbuf = smem;                                  // [nbuf][W_SLOTS]
-    uint4* const xbuf = smem + nbuf * C::W_SLOTS;              // [nbuf][X_SLOTS]
+    uint4* const xbuf = smem + nbuf * W_SLOTS;                 // [nbuf][X_SLOTS]
 
     auto seg_of = [&](int chunk) {
         int s = 0;
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     const float* wsrc0 = p.wp + (long long)cot * p.nchunks * p.wfloats;
     auto issue_w = [&](int chunk, uint4* dst) __attribute__((always_inline)) {
         const float* src = wsrc0 + (long long)chunk * p.wfloats;
-        for (int j = wave; j < C::W_SLOTS / 64; j += 4)
+        for (int j = wave; j < W_SLOTS / 64; j += 4)
             glds16(src + (j * 64 + lane) * 4, reinterpret_cast<float*>(dst + j * 64));
     };
 
@@ -155,13 +162,15 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         const int cur = chunk & 1;
         if (chunk + 1 < p.nchunks && !(p.ablate & 1)) {
             issue_x(chunk + 1, xbuf + (cur ^ 1) * C::X_SLOTS);
-            issue_w(chunk + 1, wbuf + (cur ^ 1) * C::W_SLOTS);
+            issue_w(chunk + 1, wbuf + (cur ^ 1) * W_SLOTS);
         }
-        const uint4* Wc = wbuf + cur * C::W_SLOTS + a_slot;
+        const uint4* Wc = wbuf + cur * W_SLOTS + a_slot;
         const uint4* Xc = xbuf + cur * C::X_SLOTS + b_slot;
         bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
         auto fetch = [&](int t, int buf) __attribute__((always_inline)) {
-            const int toff = (t / K) * IW + (t % K);
+            int toff;
+            if constexpr (K > 0) toff = (t / K) * IW + (t % K);
+            else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
@@ -175,9 +184,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         };
         fetch(0, 0);
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
+        for (int t = 0; t < TMAX; ++t) {
+            if (K == 0 && t >= T) break;
             const int cb = t & 1;
-            if (t + 1 < T) fetch(t + 1, cb ^ 1);
+            if (t + 1 < TMAX && (K > 0 || t + 1 < T)) fetch(t + 1, cb ^ 1);
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -194,40 +204,62 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
         return;
     }
-    // ---- epilogue (same C/D layout as the fp32 MFMA): col j = lane & 31, row i = (r & 3) + 8 * (r >> 2) + 4 * half
-    float* sred = reinterpret_cast<float*>(smem);
+    // ---- epilogue.  MFMA C/D layout: column j = lane & 31 (pixel), row i = (r & 3) + 8 * (r >> 2) + 4 * half (cout).
+    // Each 32 x 32 tile is transposed through a private LDS patch so that a lane owns 4 consecutive pixels of one
+    // cout row: 16-byte global stores (the dword-per-lane form is store-issue bound) and a 3-step row reduction
+    // for the InstanceNorm statistics instead of a 5-step one per accumulator register.
+    constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
+    float* const patch = reinterpret_cast<float*>(smem) + wave * (32 * TS);
+    float* const sred = reinterpret_cast<float*>(smem) + 4 * 32 * TS;  // [WPX][CO_TILE][2]
     const int co_base = cot * CO_TILE + wco * MT * 32;
-    const int ox = ox0 + l32;
     const bool want_stats = p.stats != nullptr;
+    const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && p.ox_off == 0;
+    const int prow = lane >> 3, pcol = (lane & 7) * 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = co_base + m * 32 + i;
-            const bool cok = co < p.Cout;
-            const float bv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
-            float s = 0.f, q2 = 0.f;
+        for (int q = 0; q < NT; ++q) {
 #pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                const int oy = oy0 + wpx * NT + q;
-                const float v = acc[m][q][r] + bv;
-                if (cok && oy < p.OH && ox < p.OW) {
-                    s += v;
-                    q2 += v * v;
-                    p.y[(long long)n * p.o_nstride + (long long)co * p.o_cstride +
-                        (long long)(oy * p.osy + p.oy_off) * p.o_rstride + (ox * p.osx + p.ox_off)] =
-                        apply_act(v, p.act);
+            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q][r];
+            const int oy = oy0 + wpx * NT + q;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + prow;
+                const int co = co_base + m * 32 + row;
+                float4 v = *reinterpret_cast<const float4*>(patch + row * TS + pcol);
+                const bool cok = co < p.Cout && oy < p.OH;
+                const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+                float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
+                const int oxv = ox0 + pcol;
+                if (cok) {
+                    float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
+                                 (long long)(oy * p.osy + p.oy_off) * p.o_rstride + oxv * p.osx + p.ox_off;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
+                    if (vec_ok && oxv + 3 < p.OW) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(apply_act(vv[0], p.act), apply_act(vv[1], p.act),
+                                                                      apply_act(vv[2], p.act), apply_act(vv[3], p.act));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (oxv + j < p.OW) dst[j * p.osx] = apply_act(vv[j], p.act);
+                    }
                 }
             }
-            if (want_stats) {
+        }
+        if (want_stats) {
 #pragma unroll
-                for (int sh = 1; sh < 32; sh <<= 1) {
+            for (int ps = 0; ps < 4; ++ps) {
+                float s = s4[ps], q2 = q4[ps];
+#pragma unroll
+                for (int sh = 1; sh < 8; sh <<= 1) {
                     s += __shfl_xor(s, sh, 64);
                     q2 += __shfl_xor(q2, sh, 64);
                 }
-                if (l32 == 0) {
-                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + i) * 2;
+                if ((lane & 7) == 0) {
+                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + ps * 8 + prow) * 2;
                     d[0] = s;
                     d[1] = q2;
                 }
@@ -288,10 +320,11 @@ struct PackBf3Params {
     int Cin, Cout, K, layout, flip;
     int nseg, segC[kMaxSeg], chunk_begin[kMaxSeg];
     int CO_TILE, nchunks, co_tiles;
+    int ntaps, tap_ky[kMaxTaps], tap_kx[kMaxTaps];      // source tap of packed tap t (already flipped if needed)
 };
 
 __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
-    const int T = p.K * p.K;
+    const int T = p.ntaps;
     const long long per_block = 2LL * T * 2 * p.CO_TILE * 8;
     const long long total = (long long)p.co_tiles * p.nchunks * per_block;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
@@ -313,8 +346,7 @@ __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
         if (cs < p.segC[s] && co < p.Cout) {
             int cin = cs;
             for (int j = 0; j < s; ++j) cin += p.segC[j];
-            int ky = t / p.K, kx = t % p.K;
-            if (p.flip) { ky = p.K - 1 - ky; kx = p.K - 1 - kx; }
+            const int ky = p.tap_ky[t], kx = p.tap_kx[t];
             const long long off = p.layout == 0 ? (((long long)co * p.Cin + cin) * p.K + ky) * p.K + kx
                                                 : (((long long)cin * p.Cout + co) * p.K + ky) * p.K + kx;
             v = p.w[off];

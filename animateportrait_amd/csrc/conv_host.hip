@@ -45,6 +45,28 @@ static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
     return nullptr;
 }
 
+// split-bf16 kernels (conv_bf16x3.h)
+struct Bf3Kernel {
+    int S, K, CO_TILE, TH;
+    const void* fn;
+    int (*wfloats)(int);
+    size_t (*lds_bytes)(int, int);
+    const char* name;
+};
+template <class C>
+static Bf3Kernel bk(const char* name) {
+    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, reinterpret_cast<const void*>(&conv_bf16x3<C>), &C::wfloats,
+                     &C::lds_bytes, name};
+}
+static const std::vector<Bf3Kernel>& bf3_registry() {
+    static std::vector<Bf3Kernel> v = {
+        bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
+        bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
+        bk<Bf3Cfg<1, 0, 1, 2, 4, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 4>"),      // sub-pixel phases of ConvTranspose2d(s=2)
+    };
+    return v;
+}
+
 struct Tap { int ky, kx, ly, lx; };  // (ky,kx): index into the caller's weight; (ly,lx): LDS tile offset
 
 struct Launch {
@@ -59,7 +81,8 @@ struct Launch {
 struct Plan {
     const ConvKernelInfo* k = nullptr;
     int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
-    bool bf3 = false;              // conv_bf16x3<Bf3Cfg<1,3,1,2,4,4>>
+    bool bf3 = false;              // split-bf16 matrix path
+    const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
     int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
     int chunk_begin[kMaxSeg] = {0, 0, 0};
@@ -119,29 +142,25 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.stat_tiles = ((pl.Hout + 15) / 16) * ((pl.Wout + 63) / 64);
         return AP_OK;
     }
-    // split-bf16 matrix path (conv_bf16x3.h): wide stride-1 3x3 layers when the caller allows ~1e-4 relative error
-    if (d->precision == AP_PRECISION_BF16X3 && !d->transposed && d->stride == 1 && K == 3 && d->Cout >= 64 &&
-        pl.Cin >= 64 && !env_int("APAMD_NO_BF16X3", 0)) {
+    // split-bf16 matrix path (conv_bf16x3.h): wide 3x3 / transposed layers when the caller allows ~1e-4 relative error
+    if (d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
-        if (seg_ok) {
-            using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
-            pl.bf3 = true;
-            pl.nchunks = 0;
-            for (int s = 0; s < d->nsrc; ++s) {
-                pl.chunk_begin[s] = pl.nchunks;
-                pl.nchunks += d->src[s].C / 16;
-            }
-            pl.cin_pad = pl.nchunks * 16;
-            pl.co_tiles = (d->Cout + BC::CO_TILE - 1) / BC::CO_TILE;
-            if (BC::lds_bytes(pl.nchunks > 1 ? 2 : 1) <= 160 * 1024) {
-                pl.packed_floats = (long long)pl.co_tiles * pl.nchunks * BC::wfloats();
-                pl.stat_tiles = ((pl.Hout + BC::TH - 1) / BC::TH) * ((pl.Wout + 31) / 32);
-                return AP_OK;
-            }
-            pl.bf3 = false;
-        }
+        if (seg_ok && (KT == 0 || K == 3))
+            for (const auto& k : bf3_registry())
+                if (k.S == S && k.K == KT) pl.bk = &k;
+        if (KT == 0 && K != 3 && K != 4) pl.bk = nullptr;
     }
+    if (pl.bk) {
+        pl.bf3 = true;
+        pl.nchunks = 0;
+        for (int s = 0; s < d->nsrc; ++s) {
+            pl.chunk_begin[s] = pl.nchunks;
+            pl.nchunks += d->src[s].C / 16;
+        }
+        pl.cin_pad = pl.nchunks * 16;
+        pl.co_tiles = (d->Cout + pl.bk->CO_TILE - 1) / pl.bk->CO_TILE;
+    } else {
     // tile configuration by output width
     int co_tile = d->Cout >= 96 ? 128 : (d->Cout >= 48 ? 64 : 32);
     co_tile = env_int("APAMD_CONV_COTILE", co_tile);
@@ -179,13 +198,16 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     }
     pl.cin_pad = pl.nchunks * ci;
     pl.co_tiles = (d->Cout + co_tile - 1) / co_tile;
+    }
 
     auto finish = [&](Launch& L) {
         L.tiles_x = (L.OW + 31) / 32;
-        L.tiles_y = (L.OH + pl.k->TH - 1) / pl.k->TH;
+        const int th = pl.bk ? pl.bk->TH : pl.k->TH;
+        const int wf = pl.bk ? pl.bk->wfloats((int)L.taps.size()) : pl.k->wfloats((int)L.taps.size());
+        L.tiles_y = (L.OH + th - 1) / th;
         L.wp_off = pl.packed_floats;
         L.stat_tile_off = pl.stat_tiles;
-        pl.packed_floats += (long long)pl.co_tiles * pl.nchunks * pl.k->wfloats((int)L.taps.size());
+        pl.packed_floats += (long long)pl.co_tiles * pl.nchunks * wf;
         pl.stat_tiles += L.tiles_x * L.tiles_y;
     };
     if (!d->transposed) {
@@ -401,7 +423,7 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         return AP_OK;
     }
     if (pl.bf3) {
-        snprintf(buf, buflen, "Bf3Cfg<1, 3, 1, 2, 4, 4>");
+        snprintf(buf, buflen, "%s", pl.bk->name);
         return AP_OK;
     }
     snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->K, pl.k->WCO, pl.k->MT,
@@ -425,16 +447,22 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
         return check_launch("pack_direct_kernel");
     }
     if (pl.bf3) {
-        using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
-        PackBf3Params p;
-        memset(&p, 0, sizeof(p));
-        p.w = weight; p.out = reinterpret_cast<unsigned short*>(packed);
-        p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout; p.flip = d->w_flip;
-        p.nseg = d->nsrc;
-        for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
-        p.CO_TILE = BC::CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
-        hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
-        return check_launch("pack_bf16x3_kernel");
+        for (const auto& L : pl.launches) {
+            PackBf3Params p;
+            memset(&p, 0, sizeof(p));
+            p.w = weight;
+            p.out = reinterpret_cast<unsigned short*>(packed + L.wp_off);
+            p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout; p.flip = 0;
+            p.nseg = d->nsrc;
+            for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
+            p.CO_TILE = pl.bk->CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
+            p.ntaps = (int)L.taps.size();
+            for (int t = 0; t < p.ntaps; ++t) { p.tap_ky[t] = L.taps[t].ky; p.tap_kx[t] = L.taps[t].kx; }
+            hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
+            rc = check_launch("pack_bf16x3_kernel");
+            if (rc) return rc;
+        }
+        return AP_OK;
     }
     for (const auto& L : pl.launches) {
         PackParams p;
@@ -471,40 +499,46 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
     }
     if (pl.bf3) {
-        using BC = Bf3Cfg<1, 3, 1, 2, 4, 4>;
         if (!d->presplit)
             return fail(AP_ERR_INVALID, "this layer runs on the split-bf16 path: pass sources prepared by "
                                         "ap_split_prepass and set desc.presplit (see ap_conv2d_wants_presplit)");
-        const void* fn = reinterpret_cast<const void*>(&conv_bf16x3<BC>);
-        rc = ensure_lds_attr(fn);
+        rc = ensure_lds_attr(pl.bk->fn);
         if (rc) return rc;
-        ConvKParams p;
-        memset(&p, 0, sizeof(p));
-        p.nseg = d->nsrc;
-        for (int s = 0; s < d->nsrc; ++s) {
-            p.seg[s].data = d->src[s].data; p.seg[s].mean = d->src[s].mean; p.seg[s].rstd = d->src[s].rstd;
-            p.seg[s].C = d->src[s].C; p.seg[s].act = d->src[s].act; p.seg[s].chunk_begin = pl.chunk_begin[s];
+        for (const auto& L : pl.launches) {
+            ConvKParams p;
+            memset(&p, 0, sizeof(p));
+            p.nseg = d->nsrc;
+            for (int s = 0; s < d->nsrc; ++s) {
+                p.seg[s].data = d->src[s].data; p.seg[s].C = d->src[s].C; p.seg[s].chunk_begin = pl.chunk_begin[s];
+            }
+            p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+            p.OH = L.OH; p.OW = L.OW; p.dy0 = L.dy0; p.dx0 = L.dx0;
+            p.pad_mode = d->pad_mode;
+            p.y = y;
+            p.o_nstride = (long long)d->Cout * pl.Hout * pl.Wout;
+            p.o_cstride = (long long)pl.Hout * pl.Wout;
+            p.o_rstride = pl.Wout;
+            p.osy = L.osy; p.osx = L.osx; p.oy_off = L.oy_off; p.ox_off = L.ox_off;
+            p.wp = packed + L.wp_off; p.bias = bias; p.act = d->act;
+            p.stats = stat_partials; p.stat_tiles = pl.stat_tiles; p.stat_tile_off = L.stat_tile_off;
+            p.ntaps = (int)L.taps.size(); p.nchunks = pl.nchunks;
+            p.tiles_x = L.tiles_x; p.tiles_y = L.tiles_y; p.co_tiles = pl.co_tiles;
+            p.cin_pad = pl.cin_pad;
+            p.wfloats = pl.bk->wfloats(p.ntaps);
+            p.ablate = env_int("APAMD_ABLATE", 0);
+            p.tap_bits = 0;
+            if (pl.bk->K == 0) {
+                if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);
+                for (int t = 0; t < p.ntaps; ++t)
+                    p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
+            }
+            const size_t lds = pl.bk->lds_bytes(p.nchunks > 1 ? 2 : 1, p.ntaps);
+            if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
+            const long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
+            void* args[] = {&p};
+            hipError_t e = hipLaunchKernel(pl.bk->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
+            if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
         }
-        p.N = d->N; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
-        p.OH = pl.Hout; p.OW = pl.Wout; p.dy0 = -d->pad; p.dx0 = -d->pad;
-        p.pad_mode = d->pad_mode;
-        p.y = y;
-        p.o_nstride = (long long)d->Cout * pl.Hout * pl.Wout;
-        p.o_cstride = (long long)pl.Hout * pl.Wout;
-        p.o_rstride = pl.Wout;
-        p.osy = p.osx = 1;
-        p.wp = packed; p.bias = bias; p.act = d->act;
-        p.stats = stat_partials; p.stat_tiles = pl.stat_tiles; p.stat_tile_off = 0;
-        p.ntaps = 9; p.nchunks = pl.nchunks;
-        p.tiles_x = (pl.Wout + 31) / 32; p.tiles_y = (pl.Hout + BC::TH - 1) / BC::TH; p.co_tiles = pl.co_tiles;
-        p.cin_pad = pl.cin_pad;
-        p.wfloats = BC::wfloats();
-        p.ablate = env_int("APAMD_ABLATE", 0);
-        const size_t lds = BC::lds_bytes(p.nchunks > 1 ? 2 : 1);
-        const long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * pl.co_tiles;
-        void* args[] = {&p};
-        hipError_t e = hipLaunchKernel(fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
-        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
         return AP_OK;
     }
     rc = ensure_lds_attr(pl.direct_cop ? direct_fn(d->KH, pl.direct_cop) : pl.k->fn);

@@ -412,3 +412,41 @@ def test_conv_bf16x3_vs_oracle(dev, case):
         assert linf(got, refn) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
     assert errs[ops.PRECISION_FP32] < 2e-6
     assert errs[ops.PRECISION_BF16X3] < 5e-5, errs     # ~2^-17 per product, averaged down by the K-sum
+
+
+@pytest.mark.parametrize('case', [
+    # cin, cout, k, stride, transposed, H, W
+    (64, 128, 3, 2, False, 64, 64),
+    (128, 96, 3, 2, False, 38, 70),
+    (256, 128, 3, 2, True, 16, 32),
+    (64, 64, 4, 2, True, 20, 24),
+])
+def test_conv_bf16x3_strided_and_transposed(dev, case):
+    """Stride-2 3x3 and ConvTranspose2d (as sub-pixel phases) on the split-bf16 path, virtual (IN+ReLU) source."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    cin, cout, k, stride, transposed, H, W = case
+    g = torch.Generator().manual_seed(sum(map(ord, str(case))))
+    n = 2
+    x = torch.randn(n, cin, H, W, generator=g) * 2 + 0.5
+    w = torch.randn((cin, cout, k, k) if transposed else (cout, cin, k, k), generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    m = x.mean((2, 3)).reshape(-1)
+    r = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+    feat = ops.Feat(x.to(dev), m.to(dev), r.to(dev), ops.ACT_RELU)
+    xr = F.relu(F.instance_norm(x)).double()
+    op = 1 if k == 3 else 0
+    ref = (F.conv_transpose2d(xr, w.double(), b.double(), stride=2, padding=1, output_padding=op) if transposed
+           else F.conv2d(xr, w.double(), b.double(), stride=2, padding=1))
+    scale = float(ref.abs().max())
+    for prec, tol in ((ops.PRECISION_BF16X3, 5e-5), (ops.PRECISION_FP32, 2e-6)):
+        layer = ConvLayer([cin], cout, k, 2, 1, ops.PAD_ZERO, transposed, op if transposed else 0).to(dev)
+        layer.spec.precision = prec
+        with torch.no_grad():
+            layer.weight.copy_(w); layer.bias.copy_(b)
+        y = layer.run(feat, act=ops.ACT_NONE)
+        assert y.data.shape == ref.shape
+        assert linf(y.data, ref) / scale < tol, (prec, linf(y.data, ref) / scale)
+        yn = layer.run(feat, norm_act=ops.ACT_NONE)
+        got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
+        assert linf(got, F.instance_norm(ref.float())) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
