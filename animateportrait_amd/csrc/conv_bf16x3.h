@@ -17,18 +17,29 @@
 //     weights pre-packed as the LDS image [head|tail][tap][k-group][cout] slots;
 //   * channel chunk = 16 (one MFMA K); an A / B fragment is ONE ds_read_b128 per lane (lane = cout / pixel,
 //     half-wave = k-group), conflict-free; fragments of tap t+1 are fetched while tap t multiplies;
+//   * the workgroups are PERSISTENT: one per CU, each walking its share of the (image, pixel tile, cout tile)
+//     list.  The (tile, chunk) stages form one flat software pipeline -- stage g+2 is issued to the LDS-DMA
+//     while stage g multiplies, across tile boundaries -- so the first-stage latency of a tile and the drain of
+//     the previous tile's output stores hide under MFMA work; the one barrier per stage sits in front of the
+//     LAST tap of a stage (whose fragments are already in registers), so the matrix pipe never idles at it;
 //   * epilogue identical to the fp32 kernel (bias, activation, InstanceNorm partial statistics).
 #pragma once
+#include <type_traits>
+
 #include "conv_igemm.h"
 
 namespace apamd {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_>
+// K_ > 0: dense K x K taps.  K_ == 0: NTAP_ (1, 2 or 4) taps at run-time offsets inside a 2 x 2 window (the
+// sub-pixel phases of a stride-2 transposed convolution); the count is a template parameter so that the tap
+// loop unrolls with compile-time register buffers.
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0>
 struct Bf3Cfg {
     static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
-    static constexpr int TMAX = K > 0 ? K * K : 4;                 // K == 0: <= 4 run-time taps in a 2 x 2 window
+    static constexpr int TMAX = K > 0 ? K * K : NTAP_;
+    static_assert(TMAX >= 1, "K == 0 needs a tap count");
     static constexpr int EXT = K > 0 ? K - 1 : 1;
     static constexpr int TH = WPX * NT;
     static constexpr int CO_TILE = WCO * MT * 32;
@@ -39,14 +50,13 @@ struct Bf3Cfg {
     static constexpr int X_SLOTS = 2 * XP;                         // [part][kgroup][pixel]
     static int w_slots(int ntaps) { return 2 * ntaps * 2 * CO_TILE; }   // [part][tap][kgroup][cout], multiple of 64
     static constexpr int NIT = XP / 256 + (XP % 256 ? 1 : 0);      // DMA pieces per thread and part
+    static constexpr int EPI_FLOATS = 4 * 32 * 36 + WPX * CO_TILE * 2;  // epilogue patches + statistics
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(CO_TILE % 16 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
+    static_assert(EPI_FLOATS * 4 <= X_SLOTS * 16, "the epilogue patches live in one activation stage buffer");
+    static_assert(IH < 128 && IW < 256, "piece geometry is packed into 15 bits");
     static int wfloats(int ntaps) { return w_slots(ntaps) * 4; }   // floats per (cout tile, chunk) weight block
-    static size_t lds_bytes(int nbuf, int ntaps) {
-        const size_t pipe = (size_t)nbuf * (X_SLOTS + w_slots(ntaps)) * 16;
-        const size_t epi = (4 * 32 * 36 + WPX * CO_TILE * 2) * 4;   // epilogue patches + statistics
-        return pipe > epi ? pipe : epi;
-    }
+    static size_t lds_bytes(int ntaps) { return (size_t)2 * (X_SLOTS + w_slots(ntaps)) * 16; }   // two stages
 };
 
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
@@ -54,39 +64,61 @@ __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
     lo = (__bf16)(v - (float)hi);
 }
 
-// seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels
+struct Bf3Tile {
+    int n, cot, ty, tx;
+};
+
+// LDS-DMA issued behind the compiler's back.  With the builtin, the compiler books every in-flight
+// global_load_lds as a "flat access that may touch LDS" and degrades each later s_waitcnt on an LDS read to
+// lgkmcnt(0) for as long as the DMA is pending -- i.e. through the whole MFMA stage this kernel overlaps it with.
+// Raw issue keeps the fragment-read waits exact; the price is that completion must be awaited explicitly
+// (dma_wait_all) before the barrier that publishes the stage.  lds_addr: wave-uniform LDS byte address of
+// lane 0's 16 bytes (lane i lands at +16 i).
+__device__ __forceinline__ void glds16_raw(const uint4* gsrc, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels.
+// Launch with min(#tiles, #CUs) workgroups of 256 threads; needs nchunks >= 2.
 template <class C>
 __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     constexpr int S = C::S, K = C::K, TMAX = C::TMAX, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
+    constexpr bool XPF = true;             // fragments of the next stage's tap 0 are fetched during this stage's last tap
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* const smem = reinterpret_cast<uint4*>(smem_raw);
 
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // scalar: LDS-DMA destinations stay in SGPRs
+    const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
     const int wco = wave % WCO, wpx = wave / WCO;
-
-    int logical;
-    {
-        const int nblk = gridDim.x, b = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int cot = logical % p.co_tiles;
-    int t_ = logical / p.co_tiles;
-    const int tx = t_ % p.tiles_x;
-    t_ /= p.tiles_x;
-    const int ty = t_ % p.tiles_y;
-    const int n = t_ / p.tiles_y;
-    const int oy0 = ty * C::TH, ox0 = tx * 32;
-    const int iy0 = oy0 * S + p.dy0, ix0 = ox0 * S + p.dx0;
     const int H = p.H, W = p.W, HW = H * W;
+    const int nchunks = p.nchunks;         // even: the host pads an odd count with one all-zero weight chunk
+    const int nreal = p.cin_pad >> 4;      // chunks that exist in the sources
 
-    const int nbuf = p.nchunks > 1 ? 2 : 1;
-    const int T = K > 0 ? K * K : p.ntaps;
-    const int W_SLOTS = 2 * T * 2 * CO_TILE;
-    uint4* const wbuf = smem;                                  // [nbuf][W_SLOTS]
-    uint4* const xbuf = smem + nbuf * W_SLOTS;                 // [nbuf][X_SLOTS]
+    constexpr int T = TMAX;
+    constexpr int W_SLOTS = 2 * T * 2 * CO_TILE;
+    uint4* const wbuf = smem;                                  // [2][W_SLOTS]
+    uint4* const xbuf = smem + 2 * W_SLOTS;                    // [2][X_SLOTS]
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+
+    // ---- this workgroup's tiles.  Workgroup b runs on XCD b % 8; each XCD owns a contiguous range of the tile
+    // list (cout tile fastest, so the workgroups of an XCD share activation tiles through its L2) and its
+    // workgroups walk that range in lock step.
+    int tile, tile_end, tile_step;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int nx = G < 8 ? G : 8;                              // XCDs that received workgroups
+        const int xcd = b % nx, idx = b / nx;
+        const int ntl = p.N * p.tiles_y * p.tiles_x * p.co_tiles;
+        const int q = ntl / nx, r = ntl % nx;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_step = (G - xcd + nx - 1) / nx;                       // workgroups on this XCD
+        tile = base + idx;
+        tile_end = base + q + (xcd < r ? 1 : 0);
+    }
+    if (tile >= tile_end) return;
 
     auto seg_of = [&](int chunk) {
         int s = 0;
@@ -97,192 +129,279 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
 
     // ---- DMA geometry: piece k of this thread covers slot it = tid + k*256 of a part = (k-group, tile pixel);
     // source = that pixel of the image (reflected) or the all-zero slot (zero padding, tile padding)
-    int goff[NIT];      // pixel offset inside a channel-group plane, or -1 -> zero slot
-    int gkg[NIT];
+    int pgeo[NIT];      // (k-group << 15) | (ly << 8) | lx of the piece, or -1 beyond the tile
 #pragma unroll
     for (int k = 0; k < NIT; ++k) {
         const int it = tid + k * 256;
         const int kg = it >= PLANE ? 1 : 0;
         const int pix = it - kg * PLANE;
         const int ly = pix / IW, lx = pix - ly * IW;
-        int gy = iy0 + ly, gx = ix0 + lx;
-        bool ok = it < 2 * PLANE;
-        if (p.pad_mode == 1) {
-            gy = reflect_clamp(gy, H);
-            gx = reflect_clamp(gx, W);
-        } else {
-            ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        }
-        goff[k] = ok ? gy * W + gx : -1;
-        gkg[k] = kg;
+        pgeo[k] = it < 2 * PLANE ? ((kg << 15) | (ly << 8) | lx) : -1;
     }
-    auto issue_x = [&](int chunk, uint4* dst) __attribute__((always_inline)) {
+    auto locate = [&](int logical, Bf3Tile& t, int (&goff)[NIT]) __attribute__((always_inline)) {
+        t.cot = logical % p.co_tiles;
+        int t_ = logical / p.co_tiles;
+        t.tx = t_ % p.tiles_x;
+        t_ /= p.tiles_x;
+        t.ty = t_ % p.tiles_y;
+        t.n = t_ / p.tiles_y;
+        const int iy0 = t.ty * C::TH * S + p.dy0, ix0 = t.tx * 32 * S + p.dx0;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) {
+            int gy = iy0 + ((pgeo[k] >> 8) & 127), gx = ix0 + (pgeo[k] & 255);
+            bool ok = pgeo[k] >= 0;
+            if (p.pad_mode == 1) {
+                gy = reflect_clamp(gy, H);
+                gx = reflect_clamp(gx, W);
+            } else {
+                ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
+            // slot offset from the chunk's first channel-group plane, or -1 -> zero slot
+            goff[k] = ok ? ((pgeo[k] >> 15) & 1) * HW + gy * W + gx : -1;
+        }
+    };
+    auto issue = [&](const Bf3Tile& t, const int (&goff)[NIT], int chunk_, int buf) __attribute__((always_inline)) {
+        const int zpad = chunk_ >= nreal ? -1 : 0;                   // padding chunk: every piece reads the zero slot
+        const int chunk = chunk_ >= nreal ? nreal - 1 : chunk_;
         const int s = seg_of(chunk);
         const int cg0 = (chunk - p.seg[s].chunk_begin) * 2;          // first channel group of the chunk
         const int CG = p.seg[s].C >> 3;
         const uint4* xs = reinterpret_cast<const uint4*>(p.seg[s].data);
-        const long long zero_slot = (long long)p.N * 2 * CG * HW;
+        const int zero_slot = p.N * 2 * CG * HW;                     // slot indices fit 31 bits (checked by the host)
+        const unsigned xdst = lds0 + (2 * W_SLOTS + buf * C::X_SLOTS + wave * 64) * 16;
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
+            const int sbase = ((t.n * 2 + part) * CG + cg0) * HW;   // scalar
 #pragma unroll
             for (int k = 0; k < NIT; ++k) {
-                if (k * 256 + wave * 64 < XP) {                       // wave-uniform: whole piece inside the part
-                    const long long src = goff[k] >= 0
-                        ? ((long long)(n * 2 + part) * CG + cg0 + gkg[k]) * HW + goff[k] : zero_slot;
-                    glds16(reinterpret_cast<const float*>(xs + src),
-                           reinterpret_cast<float*>(dst + part * XP + k * 256 + wave * 64));
+                if (k * 256 + 3 * 64 < XP || k * 256 + wave * 64 < XP) {   // wave-uniform: whole piece inside the part
+                    const int src = (goff[k] | zpad) >= 0 ? sbase + goff[k] : zero_slot;
+                    glds16_raw(xs + src, xdst + (part * XP + k * 256) * 16);
                 }
             }
         }
+        const uint4* wsrc = reinterpret_cast<const uint4*>(p.wp + ((long long)t.cot * nchunks + chunk_) * p.wfloats) + lane;
+        const unsigned wdst = lds0 + buf * W_SLOTS * 16;
+#pragma unroll
+        for (int j0 = 0; j0 < W_SLOTS / 64; j0 += 4) {
+            const int j = j0 + wave;
+            if (j < W_SLOTS / 64) glds16_raw(wsrc + j * 64, wdst + j * 1024);
+        }
     };
-    const float* wsrc0 = p.wp + (long long)cot * p.nchunks * p.wfloats;
-    auto issue_w = [&](int chunk, uint4* dst) __attribute__((always_inline)) {
-        const float* src = wsrc0 + (long long)chunk * p.wfloats;
-        for (int j = wave; j < W_SLOTS / 64; j += 4)
-            glds16(src + (j * 64 + lane) * 4, reinterpret_cast<float*>(dst + j * 64));
-    };
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
-
-    issue_x(0, xbuf);
-    issue_w(0, wbuf);
-    __syncthreads();
 
     // fragment addresses (16-byte slots)
     const int a_slot = half * CO_TILE + wco * MT * 32 + l32;                       // + ((part*T + t)*2) * CO_TILE + m*32
     const int b_slot = half * PLANE + (wpx * NT) * S * IW + l32 * S;               // + part*XP + toff + q*S*IW
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int cur = chunk & 1;
-        if (chunk + 1 < p.nchunks && !(p.ablate & 1)) {
-            issue_x(chunk + 1, xbuf + (cur ^ 1) * C::X_SLOTS);
-            issue_w(chunk + 1, wbuf + (cur ^ 1) * W_SLOTS);
+    f32x16 acc[MT][NT];
+    bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    auto fetch = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
+        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
+        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
+        int toff;
+        if constexpr (K > 0) toff = (t / K) * IW + (t % K);
+        else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
+            al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
         }
-        const uint4* Wc = wbuf + cur * W_SLOTS + a_slot;
-        const uint4* Xc = xbuf + cur * C::X_SLOTS + b_slot;
-        bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-        auto fetch = [&](int t, int buf) __attribute__((always_inline)) {
-            int toff;
-            if constexpr (K > 0) toff = (t / K) * IW + (t % K);
-            else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
-                al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
-            }
-#pragma unroll
-            for (int q = 0; q < NT; ++q) {
-                bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
-                bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
-            }
-        };
-        fetch(0, 0);
-#pragma unroll
-        for (int t = 0; t < TMAX; ++t) {
-            if (K == 0 && t >= T) break;
-            const int cb = t & 1;
-            if (t + 1 < TMAX && (K > 0 || t + 1 < T)) fetch(t + 1, cb ^ 1);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int q = 0; q < NT; ++q) {
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
-                    acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
-                }
-        }
-        if (!(p.ablate & 2)) __syncthreads();
-    }
-
-    if (p.ablate & 8) {
-        if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
-        return;
-    }
-    // ---- epilogue.  MFMA C/D layout: column j = lane & 31 (pixel), row i = (r & 3) + 8 * (r >> 2) + 4 * half (cout).
-    // Each 32 x 32 tile is transposed through a private LDS patch so that a lane owns 4 consecutive pixels of one
-    // cout row: 16-byte global stores (the dword-per-lane form is store-issue bound) and a 3-step row reduction
-    // for the InstanceNorm statistics instead of a 5-step one per accumulator register.
-    constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
-    float* const patch = reinterpret_cast<float*>(smem) + wave * (32 * TS);
-    float* const sred = reinterpret_cast<float*>(smem) + 4 * 32 * TS;  // [WPX][CO_TILE][2]
-    const int co_base = cot * CO_TILE + wco * MT * 32;
-    const bool want_stats = p.stats != nullptr;
-    const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && p.ox_off == 0;
-    const int prow = lane >> 3, pcol = (lane & 7) * 4;
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
+            bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
+            bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
+        }
+    };
+
+    Bf3Tile cur, nxt;
+    int cgoff[NIT], ngoff[NIT];
+    locate(tile, cur, cgoff);
+    issue(cur, cgoff, 0, 0);
+    issue(cur, cgoff, 1, 1);
+    dma_wait_all();
+    __syncthreads();
+
+    for (;;) {
+        const bool has_next = tile + tile_step < tile_end;
+        locate(has_next ? tile + tile_step : tile, nxt, ngoff);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q][r];
-            const int oy = oy0 + wpx * NT + q;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const int row = ps * 8 + prow;
-                const int co = co_base + m * 32 + row;
-                float4 v = *reinterpret_cast<const float4*>(patch + row * TS + pcol);
-                const bool cok = co < p.Cout && oy < p.OH;
-                const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
-                float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
-                const int oxv = ox0 + pcol;
-                if (cok) {
-                    float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
-                                 (long long)(oy * p.osy + p.oy_off) * p.o_rstride + oxv * p.osx + p.ox_off;
+            for (int q = 0; q < NT; ++q)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
-                    if (vec_ok && oxv + 3 < p.OW) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(apply_act(vv[0], p.act), apply_act(vv[1], p.act),
-                                                                      apply_act(vv[2], p.act), apply_act(vv[3], p.act));
-                    } else {
+                for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+        // one pipeline stage = one 16-channel chunk; P = its LDS stage buffer (compile-time in each copy)
+        auto stage = [&](auto ptag, int c) __attribute__((always_inline)) {
+            constexpr int P = decltype(ptag)::value;
+            constexpr int FP = (XPF && (TMAX & 1)) ? P : 0;        // register buffer of tap 0
+            if (!XPF || c == 0) fetch(P, 0, FP);
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (oxv + j < p.OW) dst[j * p.osx] = apply_act(vv[j], p.act);
+            for (int t = 0; t < TMAX; ++t) {
+                const int cb = (t + FP) & 1;
+                const bool last = t == TMAX - 1;
+                if (!last) {
+                    fetch(P, t + 1, cb ^ 1);
+                } else {
+                    // every fragment of this stage is in registers: the stage buffer can be refilled, and the
+                    // next stage (issued one stage ago) has landed once everybody is past the barrier
+                    dma_wait_all();
+                    if (!(p.ablate & 2)) __syncthreads();
+                    if (c + 1 < nchunks) {
+                        // stage c+2 goes into this buffer; past the tile's end it is chunk 0 of the next tile
+                        const bool tail = c + 2 >= nchunks;
+                        if (!(p.ablate & 1) && (!tail || has_next)) {
+                            Bf3Tile it;
+                            it.n = tail ? nxt.n : cur.n;
+                            it.cot = tail ? nxt.cot : cur.cot;
+                            int ig[NIT];
+#pragma unroll
+                            for (int k = 0; k < NIT; ++k) ig[k] = tail ? ngoff[k] : cgoff[k];
+                            issue(it, ig, tail ? 0 : c + 2, P);
+                        }
+                        if (XPF) fetch(P ^ 1, 0, cb ^ 1);
+                    }
+                }
+                // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
+                // never wait on each other's result (small terms first)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NT; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+                // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
+                // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
+                if (!last) {
+                    constexpr int NRD = 2 * MT + 2 * NT, PER = (3 * MT * NT + NRD - 1) / NRD;
+#pragma unroll
+                    for (int i = 0; i < NRD; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // PER MFMAs
                     }
                 }
             }
+        };
+        // nchunks is even: chunk pairs run straight-line through stage buffers 0 and 1 (a run-time choice of the
+        // buffer per stage makes the register allocator shuttle all accumulators between VGPRs and AGPRs)
+        for (int c = 0; c < nchunks; c += 2) {
+            stage(std::integral_constant<int, 0>{}, c);
+            stage(std::integral_constant<int, 1>{}, c + 1);
         }
-        if (want_stats) {
+        constexpr int pl = 1;                                      // stage buffer of the last chunk: free now; the
+                                                                   // next tile's chunk 0 sits in buffer 0 again
+
+        // ACT >= 0: activation known at compile time (a run-time switch per element costs scalar branches)
+        auto epilogue = [&](auto atag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(atag)::value;
+            auto actf = [&](float v) { return ACT >= 0 ? apply_act(v, ACT) : apply_act(v, p.act); };
+            // ---- epilogue.  MFMA C/D layout: column j = lane & 31 (pixel), row i = (r & 3) + 8 * (r >> 2) + 4 * half
+            // (cout).  Each 32 x 32 tile is transposed through a private LDS patch so that a lane owns 4 consecutive
+            // pixels of one cout row: 16-byte global stores (the dword-per-lane form is store-issue bound) and a
+            // 3-step row reduction for the InstanceNorm statistics instead of a 5-step one per accumulator register.
+            constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
+            float* const epi = reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
+            float* const patch = epi + wave * (32 * TS);
+            float* const sred = epi + 4 * 32 * TS;                             // [WPX][CO_TILE][2]
+            const int n = cur.n, cot = cur.cot;
+            const int oy0 = cur.ty * C::TH, ox0 = cur.tx * 32;
+            const int co_base = cot * CO_TILE + wco * MT * 32;
+            const bool want_stats = p.stats != nullptr;
+            const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && p.ox_off == 0;
+            const int prow = lane >> 3, pcol = (lane & 7) * 4;
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                float s = s4[ps], q2 = q4[ps];
+            for (int m = 0; m < MT; ++m) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int sh = 1; sh < 8; sh <<= 1) {
-                    s += __shfl_xor(s, sh, 64);
-                    q2 += __shfl_xor(q2, sh, 64);
+                for (int q = 0; q < NT; ++q) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q][r];
+                    const int oy = oy0 + wpx * NT + q;
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        const int row = ps * 8 + prow;
+                        const int co = co_base + m * 32 + row;
+                        float4 v = *reinterpret_cast<const float4*>(patch + row * TS + pcol);
+                        const bool cok = co < p.Cout && oy < p.OH;
+                        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
+                        float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
+                        const int oxv = ox0 + pcol;
+                        if (cok) {
+                            float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
+                                         (long long)(oy * p.osy + p.oy_off) * p.o_rstride + oxv * p.osx + p.ox_off;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
+                            if (vec_ok && oxv + 3 < p.OW) {
+                                *reinterpret_cast<float4*>(dst) =
+                                    make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (oxv + j < p.OW) dst[j * p.osx] = actf(vv[j]);
+                            }
+                        }
+                    }
                 }
-                if ((lane & 7) == 0) {
-                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + ps * 8 + prow) * 2;
-                    d[0] = s;
-                    d[1] = q2;
+                if (want_stats) {
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        float s = s4[ps], q2 = q4[ps];
+#pragma unroll
+                        for (int sh = 1; sh < 8; sh <<= 1) {
+                            s += __shfl_xor(s, sh, 64);
+                            q2 += __shfl_xor(q2, sh, 64);
+                        }
+                        if ((lane & 7) == 0) {
+                            float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + ps * 8 + prow) * 2;
+                            d[0] = s;
+                            d[1] = q2;
+                        }
+                    }
                 }
             }
-        }
-    }
-    if (want_stats) {
-        __syncthreads();
-        if (tid < CO_TILE) {
-            const int co = cot * CO_TILE + tid;
-            if (co < p.Cout) {
-                float s = 0.f, q2 = 0.f;
+            if (want_stats) {
+                __syncthreads();
+                if (tid < CO_TILE) {
+                    const int co = cot * CO_TILE + tid;
+                    if (co < p.Cout) {
+                        float s = 0.f, q2 = 0.f;
 #pragma unroll
-                for (int w = 0; w < C::WPX; ++w) {
-                    s += sred[(w * CO_TILE + tid) * 2];
-                    q2 += sred[(w * CO_TILE + tid) * 2 + 1];
+                        for (int w = 0; w < C::WPX; ++w) {
+                            s += sred[(w * CO_TILE + tid) * 2];
+                            q2 += sred[(w * CO_TILE + tid) * 2 + 1];
+                        }
+                        float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + p.stat_tile_off +
+                                              cur.ty * p.tiles_x + cur.tx) * 2;
+                        d[0] = s;
+                        d[1] = q2;
+                    }
                 }
-                float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + p.stat_tile_off +
-                                      ty * p.tiles_x + tx) * 2;
-                d[0] = s;
-                d[1] = q2;
             }
+        };
+        if (p.ablate & 8) {
+            if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
+        } else if (p.act == 0) {
+            epilogue(std::integral_constant<int, 0>{});
+        } else {
+            epilogue(std::integral_constant<int, -1>{});
         }
+        if (!has_next) break;
+        __syncthreads();                                           // patches and statistics consumed: refill that stage
+        if (!(p.ablate & 1)) issue(nxt, ngoff, 1, pl);
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < NIT; ++k) cgoff[k] = ngoff[k];
+        tile += tile_step;
     }
 }
 

@@ -47,24 +47,34 @@ static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
 
 // split-bf16 kernels (conv_bf16x3.h)
 struct Bf3Kernel {
-    int S, K, CO_TILE, TH;
+    int S, K, CO_TILE, TH, TMAX;
     const void* fn;
     int (*wfloats)(int);
-    size_t (*lds_bytes)(int, int);
+    size_t (*lds_bytes)(int);
     const char* name;
 };
 template <class C>
 static Bf3Kernel bk(const char* name) {
-    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, reinterpret_cast<const void*>(&conv_bf16x3<C>), &C::wfloats,
-                     &C::lds_bytes, name};
+    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, reinterpret_cast<const void*>(&conv_bf16x3<C>),
+                     &C::wfloats, &C::lds_bytes, name};
 }
 static const std::vector<Bf3Kernel>& bf3_registry() {
     static std::vector<Bf3Kernel> v = {
         bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
         bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
-        bk<Bf3Cfg<1, 0, 1, 2, 4, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 4>"),      // sub-pixel phases of ConvTranspose2d(s=2)
+        // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
+        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
+        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
+        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 4>"),
     };
     return v;
+}
+// the kernel of one launch: K == 0 kernels are instantiated per tap count
+static const Bf3Kernel* bf3_for_taps(const Bf3Kernel* k, int ntaps) {
+    if (k->K != 0) return k;
+    for (const auto& e : bf3_registry())
+        if (e.K == 0 && e.S == k->S && e.TMAX == ntaps) return &e;
+    return nullptr;
 }
 
 struct Tap { int ky, kx, ly, lx; };  // (ky,kx): index into the caller's weight; (ly,lx): LDS tile offset
@@ -158,7 +168,8 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
             pl.chunk_begin[s] = pl.nchunks;
             pl.nchunks += d->src[s].C / 16;
         }
-        pl.cin_pad = pl.nchunks * 16;
+        pl.cin_pad = pl.nchunks * 16;              // channels that exist in the sources
+        pl.nchunks = (pl.nchunks + 1) & ~1;        // the kernel's pipeline runs chunk pairs: pad with an all-zero chunk
         pl.co_tiles = (d->Cout + pl.bk->CO_TILE - 1) / pl.bk->CO_TILE;
     } else {
     // tile configuration by output width
@@ -361,6 +372,21 @@ static int ensure_lds_attr(const void* fn) {
     return AP_OK;
 }
 
+// compute units of the current device (cached per device ordinal)
+static int num_cus() {
+    static std::mutex mu;
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!cached[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+        cached[dev] = n;
+    }
+    return cached[dev];
+}
+
 }  // namespace apamd
 
 using namespace apamd;
@@ -502,9 +528,11 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if (!d->presplit)
             return fail(AP_ERR_INVALID, "this layer runs on the split-bf16 path: pass sources prepared by "
                                         "ap_split_prepass and set desc.presplit (see ap_conv2d_wants_presplit)");
-        rc = ensure_lds_attr(pl.bk->fn);
-        if (rc) return rc;
         for (const auto& L : pl.launches) {
+            const Bf3Kernel* kern = bf3_for_taps(pl.bk, (int)L.taps.size());
+            if (!kern) return fail(AP_ERR_UNSUPPORTED, "no split-bf16 kernel for a phase with %d taps", (int)L.taps.size());
+            rc = ensure_lds_attr(kern->fn);
+            if (rc) return rc;
             ConvKParams p;
             memset(&p, 0, sizeof(p));
             p.nseg = d->nsrc;
@@ -532,11 +560,18 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
                 for (int t = 0; t < p.ntaps; ++t)
                     p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
             }
-            const size_t lds = pl.bk->lds_bytes(p.nchunks > 1 ? 2 : 1, p.ntaps);
+            const size_t lds = pl.bk->lds_bytes(p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
-            const long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
+            if (p.nchunks < 2) return fail(AP_ERR_UNSUPPORTED, "bf16x3 pipeline needs >= 32 input channels");
+            for (int s = 0; s < d->nsrc; ++s)
+                if ((long long)d->N * 2 * (d->src[s].C / 8) * d->H * d->W >= (1LL << 31) - 1)
+                    return fail(AP_ERR_UNSUPPORTED, "split source %d exceeds 2^31 16-byte slots", s);
+            // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
+            long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
+            const int cus = env_int("APAMD_BF3_BLOCKS", num_cus());
+            if (nblk > cus) nblk = cus;
             void* args[] = {&p};
-            hipError_t e = hipLaunchKernel(pl.bk->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
+            hipError_t e = hipLaunchKernel(kern->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
             if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
         }
         return AP_OK;

@@ -369,6 +369,8 @@ BF3_CASES = [
     ([128, 16, 16], 96, 'zero', 20, 70),
     ([256], 256, 'reflect', 64, 64),
     ([64, 64, 64], 130, 'zero', 17, 33),
+    ([48], 64, 'reflect', 33, 40),                 # odd chunk count: the pipeline pads with an all-zero chunk
+    ([32, 16, 32], 70, 'zero', 40, 40),
 ]
 
 
@@ -414,8 +416,37 @@ def test_conv_bf16x3_vs_oracle(dev, case):
     assert errs[ops.PRECISION_BF16X3] < 5e-5, errs     # ~2^-17 per product, averaged down by the K-sum
 
 
+@pytest.mark.parametrize('blocks', [1, 7, 24])
+def test_conv_bf16x3_persistent_walk(dev, blocks, monkeypatch):
+    """The split-bf16 kernel's workgroups are persistent: each walks several (image, pixel tile, cout tile) entries
+    with the LDS stages of consecutive tiles overlapped.  Force small grids (also ones that are not a multiple of
+    the 8 XCDs) and compare bit-for-bit with the default launch of the same layer."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    g = torch.Generator().manual_seed(77 + blocks)
+    n, H, W = 3, 50, 70
+    segs, cout = [64, 48], 136
+    feats = [ops.Feat((torch.randn(n, c, H, W, generator=g) * 2).to(dev)) for c in segs]
+    layer = ConvLayer(segs, cout, 3, 1, 1, ops.PAD_REFLECT).to(dev)
+    layer.spec.precision = ops.PRECISION_BF16X3
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) * 0.05)
+    monkeypatch.delenv('APAMD_BF3_BLOCKS', raising=False)
+    want = layer.run(feats, norm_act=ops.ACT_NONE)
+    monkeypatch.setenv('APAMD_BF3_BLOCKS', str(blocks))
+    got = layer.run(feats, norm_act=ops.ACT_NONE)
+    assert torch.equal(got.data, want.data)
+    assert torch.equal(got.mean, want.mean) and torch.equal(got.rstd, want.rstd)
+    xr = torch.cat([f.data for f in feats], 1).double().cpu()
+    ref = F.conv2d(F.pad(xr, (1,) * 4, mode='reflect'), layer.weight.detach().double().cpu())
+    gotn = (got.data - got.mean.view(n, cout, 1, 1)) * got.rstd.view(n, cout, 1, 1)
+    assert linf(gotn, F.instance_norm(ref.float())) < 2e-3
+
+
 @pytest.mark.parametrize('case', [
     # cin, cout, k, stride, transposed, H, W
+    (48, 64, 3, 2, False, 30, 66),
+    (80, 64, 3, 2, True, 16, 32),
     (64, 128, 3, 2, False, 64, 64),
     (128, 96, 3, 2, False, 38, 70),
     (256, 128, 3, 2, True, 16, 32),

@@ -22,6 +22,7 @@ LAYERS = [
     ('final 64->1 k7 @256', [64], 1, 7, 1, 3, ops.PAD_REFLECT, False, 256),
     ('D 256->512 k4 @32', [256], 512, 4, 1, 1, ops.PAD_ZERO, False, 32),
     ('D 128->256 k4s2 @64', [128], 256, 4, 2, 1, ops.PAD_ZERO, False, 64),
+    ('res 256->256 k3 @64 (again, clocks warm)', [256], 256, 3, 1, 1, ops.PAD_REFLECT, False, 64),
 ]
 
 
