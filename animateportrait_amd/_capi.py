@@ -9,7 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libapamd.so')
+# APAMD_LIB: alternative build of the same library (A/B kernel experiments); default = the in-tree build
+LIB_PATH = os.environ.get('APAMD_LIB') or os.path.join(_HERE, 'libapamd.so')
 
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
 PAD_ZERO, PAD_REFLECT = 0, 1

@@ -10,8 +10,8 @@
 //
 // Data flow (same im2col-free scheme as conv_igemm.h; reference layers Module2/models/networks.py:1251, 2329-2421):
 //   * split_prepass_kernel (one streaming pass per activation tensor, shared by all its consumers) applies the
-//     producer's InstanceNorm + activation and writes the split tensor XS[n][head|tail][C/8][H*W][8 x bf16]
-//     (16-byte slots; one extra all-zero slot at the end serves every zero-padding tap);
+//     producer's InstanceNorm + activation and writes the split tensor XS[n][head|tail][C/8][H*W + 1][8 x bf16]
+//     (16-byte slots; the extra slot of every plane is all-zero and serves the zero-padding taps);
 //   * the convolution stages BOTH operands with global_load_lds_dwordx4 only -- no staging registers, no VALU:
 //     activation tile [head|tail][k-group][IH*IW px] slots (reflection / zero padding = per-lane source address),
 //     weights pre-packed as the LDS image [head|tail][tap][k-group][cout] slots;
@@ -74,8 +74,10 @@ struct Bf3Tile {
 // Raw issue keeps the fragment-read waits exact; the price is that completion must be awaited explicitly
 // (dma_wait_all) before the barrier that publishes the stage.  lds_addr: wave-uniform LDS byte address of
 // lane 0's 16 bytes (lane i lands at +16 i).
-__device__ __forceinline__ void glds16_raw(const uint4* gsrc, unsigned lds_addr) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_addr) : "memory", "m0");
+// Source address = scalar base + per-lane unsigned 32-bit byte offset.
+__device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
+                 : "memory", "m0");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -156,37 +158,57 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             } else {
                 ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
             }
-            // slot offset from the chunk's first channel-group plane, or -1 -> zero slot
-            goff[k] = ok ? ((pgeo[k] >> 15) & 1) * HW + gy * W + gx : -1;
+            // byte offset from the chunk's first channel-group plane; out-of-image pixels read that plane's zero slot
+            goff[k] = (ok ? ((pgeo[k] >> 15) & 1) * (HW + 1) + gy * W + gx : HW) * 16;
         }
     };
-    auto issue = [&](const Bf3Tile& t, const int (&goff)[NIT], int chunk_, int buf) __attribute__((always_inline)) {
-        const int zpad = chunk_ >= nreal ? -1 : 0;                   // padding chunk: every piece reads the zero slot
-        const int chunk = chunk_ >= nreal ? nreal - 1 : chunk_;
+    // ---- LDS-DMA of one stage = NPIECE wave-wide 1 KiB pieces per wave: 2 * NIT activation pieces (head, tail) and
+    // the wave's share of the weight image.  DmaCtx holds the scalar part of the addresses.
+    // A piece is {s_mov m0; global_load_lds v_off, s[base]}: the per-lane 32-bit byte offsets are constants of the
+    // tile (goff) or of the kernel (woff), everything that changes per stage is scalar -- so a piece costs no
+    // vector ALU work and slots between two MFMAs of the stage's last tap.
+    struct DmaCtx {
+        const unsigned char* xh;   // the chunk's first head plane of image n (scalar)
+        const unsigned char* xl;   // ... and tail plane
+        const unsigned char* wsrc; // the (cout tile, chunk) weight block (scalar)
+        unsigned xdst, wdst;       // LDS byte addresses of the stage's activation / weight images (this wave's lane 0)
+        bool real;                 // false: the padding chunk of an odd count -- its weights are zero, the activation
+                                   // image keeps whatever finite data the buffer held two stages ago
+    };
+    constexpr int NWP = (W_SLOTS / 64 + 3) / 4, NPIECE = 2 * NIT + NWP;
+    unsigned woff[NWP];            // byte offset of this lane's slot in weight piece j
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) woff[j] = ((j * 4 + wave) * 64 + lane) * 16;
+    auto dma_setup = [&](int n, int cot, int chunk_, int buf) __attribute__((always_inline)) {
+        DmaCtx d;
+        d.real = chunk_ < nreal;
+        const int chunk = d.real ? chunk_ : nreal - 1;
         const int s = seg_of(chunk);
         const int cg0 = (chunk - p.seg[s].chunk_begin) * 2;          // first channel group of the chunk
         const int CG = p.seg[s].C >> 3;
-        const uint4* xs = reinterpret_cast<const uint4*>(p.seg[s].data);
-        const int zero_slot = p.N * 2 * CG * HW;                     // slot indices fit 31 bits (checked by the host)
-        const unsigned xdst = lds0 + (2 * W_SLOTS + buf * C::X_SLOTS + wave * 64) * 16;
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int sbase = ((t.n * 2 + part) * CG + cg0) * HW;   // scalar
-#pragma unroll
-            for (int k = 0; k < NIT; ++k) {
-                if (k * 256 + 3 * 64 < XP || k * 256 + wave * 64 < XP) {   // wave-uniform: whole piece inside the part
-                    const int src = (goff[k] | zpad) >= 0 ? sbase + goff[k] : zero_slot;
-                    glds16_raw(xs + src, xdst + (part * XP + k * 256) * 16);
-                }
-            }
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
+        d.xh = xs + ((long long)(n * 2 + 0) * CG + cg0) * (HW + 1) * 16;
+        d.xl = xs + ((long long)(n * 2 + 1) * CG + cg0) * (HW + 1) * 16;
+        d.xdst = lds0 + (2 * W_SLOTS + buf * C::X_SLOTS + wave * 64) * 16;
+        d.wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
+        d.wdst = lds0 + (buf * W_SLOTS + wave * 64) * 16;
+        return d;
+    };
+    auto dma_piece = [&](const DmaCtx& d, const int (&goff)[NIT], int j) __attribute__((always_inline)) {
+        if (j < 2 * NIT) {
+            const int part = j / NIT, k = j % NIT;
+            // wave-uniform conditions: a real chunk, and the whole piece inside the part
+            if (d.real && (k * 256 + 3 * 64 < XP || k * 256 + wave * 64 < XP))
+                glds16_sv(part ? d.xl : d.xh, (unsigned)goff[k], d.xdst + (part * XP + k * 256) * 16);
+        } else {
+            const int jj = j - 2 * NIT;
+            if (jj * 4 + 3 < W_SLOTS / 64 || jj * 4 + wave < W_SLOTS / 64) glds16_sv(d.wsrc, woff[jj], d.wdst + jj * 4096);
         }
-        const uint4* wsrc = reinterpret_cast<const uint4*>(p.wp + ((long long)t.cot * nchunks + chunk_) * p.wfloats) + lane;
-        const unsigned wdst = lds0 + buf * W_SLOTS * 16;
+    };
+    auto issue = [&](const Bf3Tile& t, const int (&goff)[NIT], int chunk_, int buf) __attribute__((always_inline)) {
+        const DmaCtx d = dma_setup(t.n, t.cot, chunk_, buf);
 #pragma unroll
-        for (int j0 = 0; j0 < W_SLOTS / 64; j0 += 4) {
-            const int j = j0 + wave;
-            if (j < W_SLOTS / 64) glds16_raw(wsrc + j * 64, wdst + j * 1024);
-        }
+        for (int j = 0; j < NPIECE; ++j) dma_piece(d, goff, j);
     };
 
     // fragment addresses (16-byte slots)
@@ -210,6 +232,24 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         for (int q = 0; q < NT; ++q) {
             bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
             bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
+        }
+    };
+
+    // fragment r of tap t (r < 2 MT: weights head / tail alternating; then activations)
+    auto fetch_one = [&](int stage_buf, int t, int buf, int r) __attribute__((always_inline)) {
+        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
+        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
+        int toff;
+        if constexpr (K > 0) toff = (t / K) * IW + (t % K);
+        else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
+        if (r < 2 * MT) {
+            const int m = r >> 1;
+            if (r & 1) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+            else ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
+        } else {
+            const int q = (r - 2 * MT) >> 1;
+            if (r & 1) bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
+            else bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
         }
     };
 
@@ -240,53 +280,58 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             for (int t = 0; t < TMAX; ++t) {
                 const int cb = (t + FP) & 1;
                 const bool last = t == TMAX - 1;
+                auto mfma_one = [&](int i) __attribute__((always_inline)) {
+                    // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
+                    // never wait on each other's result (small terms first)
+                    const int g = i / (MT * NT), m = (i % (MT * NT)) / NT, q = i % NT;
+                    if (g == 0) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+                    else if (g == 1) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
+                    else acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+                };
+                constexpr int NM = 3 * MT * NT, NRD = 2 * MT + 2 * NT;
                 if (!last) {
                     fetch(P, t + 1, cb ^ 1);
-                } else {
-                    // every fragment of this stage is in registers: the stage buffer can be refilled, and the
-                    // next stage (issued one stage ago) has landed once everybody is past the barrier
-                    dma_wait_all();
-                    if (!(p.ablate & 2)) __syncthreads();
-                    if (c + 1 < nchunks) {
-                        // stage c+2 goes into this buffer; past the tile's end it is chunk 0 of the next tile
-                        const bool tail = c + 2 >= nchunks;
-                        if (!(p.ablate & 1) && (!tail || has_next)) {
-                            Bf3Tile it;
-                            it.n = tail ? nxt.n : cur.n;
-                            it.cot = tail ? nxt.cot : cur.cot;
-                            int ig[NIT];
 #pragma unroll
-                            for (int k = 0; k < NIT; ++k) ig[k] = tail ? ngoff[k] : cgoff[k];
-                            issue(it, ig, tail ? 0 : c + 2, P);
-                        }
-                        if (XPF) fetch(P ^ 1, 0, cb ^ 1);
-                    }
-                }
-                // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
-                // never wait on each other's result (small terms first)
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int q = 0; q < NT; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
-                // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
-                // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
-                if (!last) {
-                    constexpr int NRD = 2 * MT + 2 * NT, PER = (3 * MT * NT + NRD - 1) / NRD;
+                    for (int i = 0; i < NM; ++i) mfma_one(i);
+                    // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
+                    // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
+                    constexpr int PER = (NM + NRD - 1) / NRD;
 #pragma unroll
                     for (int i = 0; i < NRD; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
                         __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // PER MFMAs
+                    }
+                } else {
+                    // every fragment of this stage is in registers: the stage buffer can be refilled, and the
+                    // next stage (issued one stage ago) has landed once everybody is past the barrier.  The DMA
+                    // pieces of stage c+2 (past the tile's end: chunk 0 of the next tile) and the fragment reads of
+                    // the next stage's tap 0 are issued one per MFMA slot, so the matrix pipe keeps running.
+                    const bool do_fetch = c + 1 < nchunks;
+                    const bool tail = c + 2 >= nchunks;
+                    const bool do_dma = do_fetch && !(p.ablate & 1) && (!tail || has_next);
+                    int ig[NIT];
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) ig[k] = tail ? ngoff[k] : cgoff[k];
+                    const DmaCtx d = dma_setup(tail ? nxt.n : cur.n, tail ? nxt.cot : cur.cot, tail ? 0 : c + 2, P);
+                    dma_wait_all();
+                    if (!(p.ablate & 2)) __syncthreads();
+                    constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
+                    constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
+                    constexpr int R0 = NM - (NRD + RPS - 1) / RPS;              // first slot that carries reads
+#pragma unroll
+                    for (int i = 0; i < NM; ++i) {
+                        mfma_one(i);
+                        if (do_dma) {
+#pragma unroll
+                            for (int pp = 0; pp < PPS; ++pp)
+                                if (i * PPS + pp < NPIECE) dma_piece(d, ig, i * PPS + pp);
+                        }
+                        if (XPF && do_fetch && i >= R0) {
+#pragma unroll
+                            for (int rr = 0; rr < RPS; ++rr)
+                                if ((i - R0) * RPS + rr < NRD) fetch_one(P ^ 1, 0, cb ^ 1, (i - R0) * RPS + rr);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -405,16 +450,18 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     }
 }
 
-// ---- activation pre-pass: XS[n][part][cg][pix] (16-byte slots of 8 bf16) = split(act((x - mean) * rstd)),
-// plus one all-zero slot at index N*2*(C/8)*HW.  grid: (ceil(HW/256), C/8, N).  HBM-bound: reads C*HW*4 B and
-// writes the same amount per sample.
+// ---- activation pre-pass: XS[n][part][cg][HW + 1] (16-byte slots of 8 bf16) = split(act((x - mean) * rstd));
+// slot HW of every plane is all-zero (the source of every out-of-image tap: a fixed offset from the plane, so the
+// convolution's per-lane DMA offsets are constants of the tile).  grid: (ceil(HW/256), C/8, N).  HBM-bound: reads
+// C*HW*4 B and writes the same amount per sample.
 __global__ __launch_bounds__(256) void split_prepass_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int act, int N, int C,
                                                             int HW, uint4* __restrict__ out) {
     const int cg = blockIdx.y, n = blockIdx.z, CG = C >> 3;
     const int pix = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && cg == 0 && n == 0 && threadIdx.x == 0)
-        out[(long long)N * 2 * CG * HW] = make_uint4(0u, 0u, 0u, 0u);
+    uint4* const ph = out + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1);
+    uint4* const pl = out + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) ph[HW] = pl[HW] = make_uint4(0u, 0u, 0u, 0u);
     if (pix >= HW) return;
     bf16x8 hv, lv;
 #pragma unroll
@@ -428,8 +475,8 @@ __global__ __launch_bounds__(256) void split_prepass_kernel(const float* __restr
         hv[c] = h;
         lv[c] = l;
     }
-    *reinterpret_cast<bf16x8*>(out + ((long long)(n * 2 + 0) * CG + cg) * HW + pix) = hv;
-    *reinterpret_cast<bf16x8*>(out + ((long long)(n * 2 + 1) * CG + cg) * HW + pix) = lv;
+    *reinterpret_cast<bf16x8*>(ph + pix) = hv;
+    *reinterpret_cast<bf16x8*>(pl + pix) = lv;
 }
 
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16

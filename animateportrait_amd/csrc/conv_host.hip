@@ -425,7 +425,7 @@ int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d) {
 
 int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W) {
     if (N < 1 || C < 8 || (C & 7) || H < 1 || W < 1) return fail(AP_ERR_INVALID, "split_prepass: C=%d must be a multiple of 8", C);
-    return ((int64_t)N * 2 * (C / 8) * H * W + 1) * 16;
+    return (int64_t)N * 2 * (C / 8) * ((int64_t)H * W + 1) * 16;     // one all-zero slot closes every plane
 }
 
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {
@@ -563,9 +563,8 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             const size_t lds = pl.bk->lds_bytes(p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
             if (p.nchunks < 2) return fail(AP_ERR_UNSUPPORTED, "bf16x3 pipeline needs >= 32 input channels");
-            for (int s = 0; s < d->nsrc; ++s)
-                if ((long long)d->N * 2 * (d->src[s].C / 8) * d->H * d->W >= (1LL << 31) - 1)
-                    return fail(AP_ERR_UNSUPPORTED, "split source %d exceeds 2^31 16-byte slots", s);
+            if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes
+                return fail(AP_ERR_UNSUPPORTED, "split-bf16 path: %d x %d planes are too large", d->H, d->W);
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
             long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
             const int cus = env_int("APAMD_BF3_BLOCKS", num_cus());

@@ -103,7 +103,8 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
                   float* stat_partials, ap_stream_t stream);
 
 /* Split-bf16 path (precision = AP_PRECISION_BF16X3, wide 3x3 layers): the convolution consumes its sources as
- * split tensors XS[n][head|tail][C/8][H*W][8 x bf16] (+ one zero slot).  ap_split_prepass applies the producer's
+ * split tensors XS[n][head|tail][C/8][H*W + 1][8 x bf16] (the last 16-byte slot of every plane is all-zero and
+ * feeds the zero-padding taps).  ap_split_prepass applies the producer's
  * InstanceNorm + activation (src->mean/rstd/act) once and writes that tensor; it can be shared by every consumer of
  * the same activation.  `out` must hold ap_split_prepass_bytes() bytes, 16-byte aligned. */
 int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d);
