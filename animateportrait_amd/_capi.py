@@ -54,6 +54,9 @@ SIGNATURES = {
     'ap_split_prepass_bytes': (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'ap_split_prepass': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                         ctypes.c_void_p, ctypes.c_void_p]),
+    'ap_norm_apply_split': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p,
+                                           ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
     'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
     'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
@@ -64,6 +67,9 @@ SIGNATURES = {
     'ap_warp_concat_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
+    'ap_warp_concat_fwd_split': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                                ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
     'ap_conv2d_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.POINTER(ApWgradDesc)]),
     'ap_pad_materialize': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

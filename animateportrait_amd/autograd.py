@@ -125,8 +125,12 @@ def materialize_forward(tape, f, residual=None):
     return out
 
 
-def warp_forward(tape, f, motion, flow, ifmask, level):
-    out = ops.warp_concat(f, motion, flow, ifmask, level)
+def warp_forward(tape, f, motion, flow, ifmask, level, consumer=None):
+    """consumer: the ConvLayer that reads the warped concat.  When it stages split-bf16 sources the warp writes that
+    copy itself; in inference (no tape) the fp32 concat is then not written at all."""
+    n, _, h, w = f.data.shape
+    emit_xs = consumer is not None and ops.takes_split(consumer.spec, n, h, w)
+    out = ops.warp_concat(f, motion, flow, ifmask, level, emit_xs=emit_xs, keep_fp32=tape is not None or not emit_xs)
     if tape is not None:
         tape.track(out)
 

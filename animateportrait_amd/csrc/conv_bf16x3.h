@@ -454,29 +454,166 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
 // slot HW of every plane is all-zero (the source of every out-of-image tap: a fixed offset from the plane, so the
 // convolution's per-lane DMA offsets are constants of the tile).  grid: (ceil(HW/256), C/8, N).  HBM-bound: reads
 // C*HW*4 B and writes the same amount per sample.
-__global__ __launch_bounds__(256) void split_prepass_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, int act, int N, int C,
-                                                            int HW, uint4* __restrict__ out) {
-    const int cg = blockIdx.y, n = blockIdx.z, CG = C >> 3;
-    const int pix = blockIdx.x * 256 + threadIdx.x;
-    uint4* const ph = out + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1);
-    uint4* const pl = out + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0) ph[HW] = pl[HW] = make_uint4(0u, 0u, 0u, 0u);
-    if (pix >= HW) return;
-    bf16x8 hv, lv;
+//
+// The same pass is the generator's whole "between two convolutions" step (norm_split_kernel):
+//   v = act((x - mean) * rstd) [+ (res - res_mean) * res_rstd]        InstanceNorm + activation + residual add
+//   y  = v   (fp32, optional)       the materialised feature (ResnetBlock output, networks.py:2358-2360)
+//   xs = split(v) (optional)        what the next split-bf16 convolution stages
+// and, when the producing convolution's per-tile (sum, sum of squares) are passed instead of finished statistics,
+// it finalises mean / rstd itself (fp64, as instnorm_finalize_kernel) and stores them for later consumers -- so a
+// Conv -> IN -> ReLU -> Conv link costs one streaming pass, not finalize + apply + split.
+struct NormSplitParams {
+    const float* x;
+    const float* mean;        // finished statistics [N*C], or null
+    const float* rstd;
+    const float* partials;    // or the conv epilogue's [N*C][tiles][2] partial sums (then mean/rstd above are null)
+    int tiles;
+    double inv_count;
+    float eps;
+    float* mean_out;          // where the finalised statistics go (partials mode)
+    float* rstd_out;
+    int act;
+    const float* res;         // residual [N, C, HW] or null
+    const float* res_mean;    // its statistics or null (plain residual)
+    const float* res_rstd;
+    float* y;                 // fp32 output or null
+    uint4* xs;                // split output or null
+    int N, C, HW;
+};
+
+// grid: (ceil(HW / (256 * VEC)), C/8, N); VEC pixels per thread (4 when HW % 4 == 0)
+template <int VEC>
+__global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p) {
+    __shared__ float s_m[8], s_r[8];
+    const int cg = blockIdx.y, n = blockIdx.z, C = p.C, HW = p.HW, CG = C >> 3;
+    const int tid = threadIdx.x;
+    const bool normed = p.partials != nullptr || p.mean != nullptr;
+    if (p.partials != nullptr) {
+        // wave 0: lane = (channel, 8-way tile split); fp64 sums of fp32 partials are exact, so the grouping
+        // does not change the result
+        if (tid < 64) {
+            const int c = tid >> 3, sub = tid & 7;
+            const float2* pp = reinterpret_cast<const float2*>(p.partials) + ((long long)n * C + cg * 8 + c) * p.tiles;
+            double s = 0.0, q = 0.0;
+            for (int t = sub; t < p.tiles; t += 8) {
+                const float2 v = pp[t];
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 8; sh <<= 1) {
+                s += __shfl_xor(s, sh, 64);
+                q += __shfl_xor(q, sh, 64);
+            }
+            if (sub == 0) {
+                const double m = s * p.inv_count;
+                double var = q * p.inv_count - m * m;
+                var = var > 0.0 ? var : 0.0;
+                const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)p.eps));
+                s_m[c] = mf;
+                s_r[c] = rf;
+                if (blockIdx.x == 0) {
+                    p.mean_out[n * C + cg * 8 + c] = mf;
+                    p.rstd_out[n * C + cg * 8 + c] = rf;
+                }
+            }
+        }
+        __syncthreads();
+    } else if (p.mean != nullptr) {
+        if (tid < 8) {
+            s_m[tid] = p.mean[n * C + cg * 8 + tid];
+            s_r[tid] = p.rstd[n * C + cg * 8 + tid];
+        }
+        __syncthreads();
+    }
+    uint4* ph = nullptr;
+    uint4* pl = nullptr;
+    if (p.xs != nullptr) {
+        ph = p.xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1);
+        pl = p.xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1);
+        if (blockIdx.x == 0 && tid == 0) ph[HW] = pl[HW] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    const int pix = (blockIdx.x * 256 + tid) * VEC;
+    const bool live = pix < HW;
+    if (VEC == 1 && !live) return;
+    float v[8][VEC];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const int ch = cg * 8 + c;
-        float v = x[((long long)n * C + ch) * HW + pix];
-        if (mean != nullptr) v = (v - mean[n * C + ch]) * rstd[n * C + ch];
-        v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-        __bf16 h, l;
-        split_bf16(v, h, l);
-        hv[c] = h;
-        lv[c] = l;
+        if (!live) continue;
+        const long long off = ((long long)n * C + cg * 8 + c) * HW + pix;
+        if constexpr (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p.x + off);
+            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
+        } else {
+            v[c][0] = p.x[off];
+        }
+        const float m = normed ? s_m[c] : 0.f, r = normed ? s_r[c] : 1.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = normed ? (v[c][j] - m) * r : v[c][j];
+            t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+            v[c][j] = t;
+        }
+        if (p.res != nullptr) {
+            float rm = 0.f, rr = 1.f;
+            if (p.res_mean != nullptr) { rm = p.res_mean[n * C + cg * 8 + c]; rr = p.res_rstd[n * C + cg * 8 + c]; }
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p.res + off);
+                v[c][0] += (t.x - rm) * rr; v[c][1] += (t.y - rm) * rr;
+                v[c][2] += (t.z - rm) * rr; v[c][3] += (t.w - rm) * rr;
+            } else {
+                v[c][0] += (p.res[off] - rm) * rr;
+            }
+        }
+        if (p.y != nullptr) {
+            if constexpr (VEC == 4) *reinterpret_cast<float4*>(p.y + off) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);
+            else p.y[off] = v[c][0];
+        }
     }
-    *reinterpret_cast<bf16x8*>(ph + pix) = hv;
-    *reinterpret_cast<bf16x8*>(pl + pix) = lv;
+    if (p.xs == nullptr) return;
+    if constexpr (VEC == 1) {
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            __bf16 h, l;
+            split_bf16(v[c][0], h, l);
+            hv[c] = h;
+            lv[c] = l;
+        }
+        *reinterpret_cast<bf16x8*>(ph + pix) = hv;
+        *reinterpret_cast<bf16x8*>(pl + pix) = lv;
+    } else {
+        // A thread owns VEC consecutive pixels (16-byte loads), but a 16-byte store per lane at a 64-byte lane
+        // stride writes every cache line in four partial pieces.  Transpose the block's slots through LDS so
+        // that store k of lane T lands on slot k*256 + T of the block's span: 1 KiB contiguous per wave.
+        // Staging position of (thread i, pixel j) = j * (256 + 4) + i: conflict-free both ways.
+        constexpr int LP = 256 + 4;
+        __shared__ uint4 stage[2][VEC * LP];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            bf16x8 hv, lv;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                __bf16 h, l;
+                split_bf16(live ? v[c][j] : 0.f, h, l);
+                hv[c] = h;
+                lv[c] = l;
+            }
+            *reinterpret_cast<bf16x8*>(&stage[0][j * LP + tid]) = hv;
+            *reinterpret_cast<bf16x8*>(&stage[1][j * LP + tid]) = lv;
+        }
+        __syncthreads();
+        const int base = blockIdx.x * 256 * VEC;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            const int g = k * 256 + tid;                       // slot inside the block's span = pixel base + g
+            const int i = g / VEC, j = g % VEC;                // owner thread and its pixel
+            if (base + g < HW) {
+                ph[base + g] = stage[0][j * LP + i];
+                pl[base + g] = stage[1][j * LP + i];
+            }
+        }
+    }
 }
 
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16

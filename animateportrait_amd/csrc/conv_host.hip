@@ -428,15 +428,47 @@ int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W) {
     return (int64_t)N * 2 * (C / 8) * ((int64_t)H * W + 1) * 16;     // one all-zero slot closes every plane
 }
 
+int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
+                        float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
+                        ap_stream_t stream) {
+    if (!src || !src->data) return fail(AP_ERR_INVALID, "norm_apply_split: null source");
+    if (!y && !xs && !stat_partials) return fail(AP_ERR_INVALID, "norm_apply_split: nothing to produce");
+    if (N < 1 || src->C < 8 || (src->C & 7) || H < 1 || W < 1)
+        return fail(AP_ERR_INVALID, "norm_apply_split: C=%d must be a multiple of 8", src->C);
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "norm_apply_split: mean/rstd mismatch");
+    if (src->act < 0 || src->act > 2) return fail(AP_ERR_INVALID, "norm_apply_split: act %d", src->act);
+    if (stat_partials) {
+        if (src->mean) return fail(AP_ERR_INVALID, "norm_apply_split: pass finished statistics OR partial tiles");
+        if (tiles < 1 || !mean_out || !rstd_out) return fail(AP_ERR_INVALID, "norm_apply_split: partial tiles need tiles >= 1 and mean_out / rstd_out");
+    }
+    if (residual) {
+        if (!residual->data || residual->C != src->C) return fail(AP_ERR_INVALID, "norm_apply_split: residual mismatch");
+        if ((residual->mean == nullptr) != (residual->rstd == nullptr) || residual->act != AP_ACT_NONE)
+            return fail(AP_ERR_INVALID, "norm_apply_split: a residual may be normalised but not activated");
+    }
+    if (N > 65535 || src->C / 8 > 65535) return fail(AP_ERR_UNSUPPORTED, "norm_apply_split: grid too large");
+    NormSplitParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = src->data; p.mean = src->mean; p.rstd = src->rstd;
+    p.partials = stat_partials; p.tiles = tiles; p.inv_count = 1.0 / ((double)H * W); p.eps = eps;
+    p.mean_out = mean_out; p.rstd_out = rstd_out;
+    p.act = src->act;
+    if (residual) { p.res = residual->data; p.res_mean = residual->mean; p.res_rstd = residual->rstd; }
+    p.y = y; p.xs = reinterpret_cast<uint4*>(xs);
+    p.N = N; p.C = src->C; p.HW = H * W;
+    if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
+        dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);
+        hipLaunchKernelGGL(norm_split_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    } else {
+        dim3 grid((p.HW + 255) / 256, src->C / 8, N);
+        hipLaunchKernelGGL(norm_split_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    }
+    return check_launch("norm_split_kernel");
+}
+
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {
-    if (!src || !src->data || !out) return fail(AP_ERR_INVALID, "split_prepass: null pointer");
-    if (ap_split_prepass_bytes(N, src->C, H, W) < 0) return AP_ERR_INVALID;
-    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "split_prepass: mean/rstd mismatch");
-    if (N > 65535 || src->C / 8 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_prepass: grid too large");
-    dim3 grid((H * W + 255) / 256, src->C / 8, N);
-    hipLaunchKernelGGL(split_prepass_kernel, grid, dim3(256), 0, (hipStream_t)stream, src->data, src->mean, src->rstd,
-                       src->act, N, src->C, H * W, reinterpret_cast<uint4*>(out));
-    return check_launch("split_prepass_kernel");
+    if (!src || !out) return fail(AP_ERR_INVALID, "split_prepass: null pointer");
+    return ap_norm_apply_split(src, nullptr, 0, 0.f, nullptr, nullptr, nullptr, N, H, W, nullptr, out, stream);
 }
 
 int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {

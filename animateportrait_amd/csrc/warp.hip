@@ -70,15 +70,37 @@ __device__ __forceinline__ float tap_val(const float* plane, int off, float m, f
     return v;
 }
 
-constexpr int kWarpCG = 8;   // channels per thread
+constexpr int kWarpCG = 8;   // channels per thread = one 16-byte slot of the split-bf16 layout
 
-// grid: (ceil(H*W/256), ceil(C/CG), N)
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+
+// store 8 channels of one pixel as a head / tail slot pair of XS[n][part][cg][HW + 1] (conv_bf16x3.h)
+__device__ __forceinline__ void store_split_slot(uint4* xs, int n, int CG2, int cg, int HW, int pix, const float (&v)[8]) {
+    wbf16x8 hv, lv;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const __bf16 h = (__bf16)v[c];
+        hv[c] = h;
+        lv[c] = (__bf16)(v[c] - (float)h);
+    }
+    *reinterpret_cast<wbf16x8*>(xs + ((long long)(n * 2 + 0) * CG2 + cg) * (HW + 1) + pix) = hv;
+    *reinterpret_cast<wbf16x8*>(xs + ((long long)(n * 2 + 1) * CG2 + cg) * (HW + 1) + pix) = lv;
+}
+
+// grid: (ceil(H*W/256), ceil(C/CG), N).  out (fp32 [N, 2C, H, W]) and xs (its split-bf16 copy) are both optional.
 __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
                                                           const float* __restrict__ x_rstd, int x_act,
                                                           const float* __restrict__ motion,
                                                           const float* __restrict__ flow,
                                                           const float* __restrict__ ifmask, float* __restrict__ out,
+                                                          uint4* __restrict__ xs,
                                                           int C, int H, int W, int S, float flow_scale) {
+    if (xs != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+        // the all-zero slot that closes every plane of the split layout (this block's two channel groups x 2 parts)
+        const int CG2 = (2 * C) >> 3, HWz = H * W;
+        const int part = threadIdx.x & 1, cg = (threadIdx.x >> 1) ? (C >> 3) + blockIdx.y : blockIdx.y;
+        xs[((long long)(blockIdx.z * 2 + part) * CG2 + cg) * (HWz + 1) + HWz] = make_uint4(0u, 0u, 0u, 0u);
+    }
     const int pix = blockIdx.x * 256 + threadIdx.x;
     if (pix >= H * W) return;
     const int n = blockIdx.z;
@@ -117,6 +139,56 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
     const int HW = H * W;
     const int c0 = blockIdx.y * kWarpCG;
     const int c1 = c0 + kWarpCG < C ? c0 + kWarpCG : C;
+    if (c0 + kWarpCG <= C) {
+        // full channel group: all 64 gathers of the thread are issued before the first use (out-of-range taps read
+        // offset 0 with weight 0: same sums as skipping them), then the 8 + 8 results leave as coalesced rows
+        int om[4], of[4];
+        float wm[4], wf[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            om[k] = tm.off[k] < 0 ? 0 : tm.off[k];
+            wm[k] = tm.off[k] < 0 ? 0.f : tm.w[k];
+            of[k] = (tf.off[k] < 0 || !keep) ? 0 : tf.off[k];
+            wf[k] = tf.off[k] < 0 ? 0.f : tf.w[k];
+        }
+        float a[8][4], b[8][4], m[8], r[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float* plane = x + ((long long)n * C + c0 + c) * HW;
+            m[c] = 0.f; r[c] = 1.f;
+            if (x_mean != nullptr) { m[c] = x_mean[n * C + c0 + c]; r[c] = x_rstd[n * C + c0 + c]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a[c][k] = plane[om[k]]; b[c][k] = plane[of[k]]; }
+        }
+        float v1[8], v2[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = (a[c][k] - m[c]) * r[c];
+                t = x_act == 1 ? (t > 0.f ? t : 0.f) : (x_act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+                s1 += (tm.off[k] < 0 ? 0.f : t) * wm[k];
+                float u = (b[c][k] - m[c]) * r[c];
+                u = x_act == 1 ? (u > 0.f ? u : 0.f) : (x_act == 2 ? (u > 0.f ? u : 0.2f * u) : u);
+                s2 += (tf.off[k] < 0 ? 0.f : u) * wf[k];
+            }
+            v1[c] = s1;
+            v2[c] = keep ? s2 : -1.f;
+        }
+        if (out != nullptr) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                out[((long long)n * 2 * C + c0 + c) * HW + pix] = v1[c];
+                out[((long long)n * 2 * C + C + c0 + c) * HW + pix] = v2[c];
+            }
+        }
+        if (xs != nullptr) {
+            store_split_slot(xs, n, (2 * C) >> 3, blockIdx.y, HW, pix, v1);
+            store_split_slot(xs, n, (2 * C) >> 3, (C >> 3) + blockIdx.y, HW, pix, v2);
+        }
+        return;
+    }
     for (int c = c0; c < c1; ++c) {
         const float* plane = x + ((long long)n * C + c) * HW;
         float m = 0.f, r = 1.f;
@@ -208,16 +280,28 @@ extern "C" int ap_warp_concat_bwd(const float* gout, const float* motion, const 
     return check_launch("warp_concat_bwd_kernel");
 }
 
-extern "C" int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
-                                  const float* motion, const float* flow, const float* ifmask, float* out, int32_t N,
-                                  int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale, ap_stream_t stream) {
-    if (!x || !motion || !flow || !ifmask || !out) return fail(AP_ERR_INVALID, "warp_concat_fwd: null pointer");
+extern "C" int ap_warp_concat_fwd_split(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                                        const float* motion, const float* flow, const float* ifmask, float* out,
+                                        void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
+                                        float flow_scale, ap_stream_t stream) {
+    if (!x || !motion || !flow || !ifmask) return fail(AP_ERR_INVALID, "warp_concat_fwd: null pointer");
+    if (!out && !xs) return fail(AP_ERR_INVALID, "warp_concat_fwd: neither an fp32 nor a split output");
     if ((x_mean == nullptr) != (x_rstd == nullptr)) return fail(AP_ERR_INVALID, "warp_concat_fwd: mean/rstd mismatch");
     if (N < 1 || C < 1 || H < 1 || W < 1 || S < 1) return fail(AP_ERR_INVALID, "warp_concat_fwd: bad sizes");
     if (x_act < 0 || x_act > 2) return fail(AP_ERR_INVALID, "warp_concat_fwd: act %d", x_act);
     if (N > 65535) return fail(AP_ERR_UNSUPPORTED, "warp_concat_fwd: N too large");
+    if ((C % kWarpCG) != 0 && (xs || !out))
+        return fail(AP_ERR_UNSUPPORTED, "warp_concat_fwd: the split output needs C %% 8 == 0 (C=%d)", C);
     dim3 grid((H * W + 255) / 256, (C + kWarpCG - 1) / kWarpCG, N);
     hipLaunchKernelGGL(warp_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
-                       flow, ifmask, out, C, H, W, S, flow_scale);
+                       flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale);
     return check_launch("warp_concat_kernel");
+}
+
+extern "C" int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                                  const float* motion, const float* flow, const float* ifmask, float* out, int32_t N,
+                                  int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale, ap_stream_t stream) {
+    if (!out) return fail(AP_ERR_INVALID, "warp_concat_fwd: null pointer");
+    return ap_warp_concat_fwd_split(x, x_mean, x_rstd, x_act, motion, flow, ifmask, out, nullptr, N, C, H, W, S,
+                                    flow_scale, stream);
 }

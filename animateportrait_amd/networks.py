@@ -159,8 +159,8 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
     def is_block2(self, i):
         return (i + self.disp) % self.div == 0
 
-    def double_feature_warping(self, x, motion, flow, ifmask, level, tape=None):
-        return warp_forward(tape, x, motion, flow, ifmask, level)
+    def double_feature_warping(self, x, motion, flow, ifmask, level, tape=None, consumer=None):
+        return warp_forward(tape, x, motion, flow, ifmask, level, consumer=consumer)
 
     def forward(self, input, land1, land2, motion, flow, ifmask):
         """G(input, land1, land2, motion, flow, ifmask) -> (B, output_nc, S, S)   (networks.py:1315)."""
@@ -178,17 +178,17 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
         cf, dfw = conv_forward, self.double_feature_warping
         x1 = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)
-        x1 = dfw(x1, motion, flow, ifmask, 0, tape)
+        x1 = dfw(x1, motion, flow, ifmask, 0, tape, self.model_tri01['0'])
         x1 = cf(tape, self.model_tri01['0'], x1, norm_act=ACT_RELU)
         x1 = cf(tape, self.model_tri02['0'], x1, norm_act=ACT_RELU)
         x2 = cf(tape, self.model_tri10['1'], inp, norm_act=ACT_RELU)
         x2 = cf(tape, self.model_tri11['0'], x2, norm_act=ACT_RELU)
-        x2 = dfw(x2, motion, flow, ifmask, 1, tape)
+        x2 = dfw(x2, motion, flow, ifmask, 1, tape, self.model_tri12['0'])
         x2 = cf(tape, self.model_tri12['0'], x2, norm_act=ACT_RELU)
         x3 = cf(tape, self.model_tri20['1'], inp, norm_act=ACT_RELU)
         x3 = cf(tape, self.model_tri21['0'], x3, norm_act=ACT_RELU)
         x3 = cf(tape, self.model_tri22['0'], x3, norm_act=ACT_RELU)
-        x3 = dfw(x3, motion, flow, ifmask, 2, tape)
+        x3 = dfw(x3, motion, flow, ifmask, 2, tape, self.model_tri_merge)
         x = cf(tape, self.model_tri_merge, [x1, x2, x3])
         # land1 / land2 share the encoder weights: one pass over the 2B batch
         lands = Feat(torch.cat([land1, land2], 0).contiguous())

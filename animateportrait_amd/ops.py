@@ -46,16 +46,61 @@ def _require_device(t, name):
 
 
 class Feat:
-    """act((data - mean) * rstd) with mean/rstd of shape (N*C,), or a plain tensor when mean is None."""
-    __slots__ = ('data', 'mean', 'rstd', 'act', 'xs')
+    """act((data - mean) * rstd) with mean/rstd of shape (N*C,), or a plain tensor when mean is None.
 
-    def __init__(self, data, mean=None, rstd=None, act=ACT_NONE):
-        self.data, self.mean, self.rstd, self.act = data, mean, rstd, act
-        self.xs = None     # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
+    A convolution hands its InstanceNorm statistics over as per-tile partial sums (``pending``); they are
+    finalised by whichever consumer comes first -- inside the fused norm/residual/split pass when that is the
+    consumer (ap_norm_apply_split), by a standalone ap_instnorm_finalize when ``mean`` / ``rstd`` are read."""
+    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending')
+
+    def __init__(self, data, mean=None, rstd=None, act=ACT_NONE, pending=None):
+        self.data, self._mean, self._rstd, self.act = data, mean, rstd, act
+        self.pending = pending   # (partials [N*C, tiles, 2], tiles) of the producing convolution, or None
+        self.xs = None           # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
 
     @property
     def shape(self):
         return self.data.shape
+
+    @classmethod
+    def split_only(cls, shape, xs):
+        """A feature that exists only as its split-bf16 copy (inference: the fp32 tensor is never written).
+        ``data`` is a storage-less stand-in that carries shape and device; fp32 consumers reject it."""
+        f = cls(torch.empty(1, dtype=torch.float32, device=xs.device).expand(shape))
+        f.xs = xs
+        return f
+
+    @property
+    def is_split_only(self):
+        return self.xs is not None and self.data.stride(0) == 0 and self.data.numel() > 1
+
+    @property
+    def virtual(self):
+        return self._mean is not None or self.pending is not None
+
+    def _finalize(self):
+        if self.pending is not None:
+            partial, tiles = self.pending
+            n, c, h, w = self.data.shape
+            self._alloc_stats()
+            C.check(C.lib().ap_instnorm_finalize(_ptr(partial), n * c, tiles, h * w, EPS, _ptr(self._mean),
+                                                 _ptr(self._rstd), _stream()), 'instnorm_finalize')
+            self.pending = None
+
+    def _alloc_stats(self):
+        n, c = self.data.shape[:2]
+        self._mean = torch.empty(n * c, dtype=torch.float32, device=self.data.device)
+        self._rstd = torch.empty_like(self._mean)
+
+    @property
+    def mean(self):
+        self._finalize()
+        return self._mean
+
+    @property
+    def rstd(self):
+        self._finalize()
+        return self._rstd
 
     def batch_slice(self, lo, hi):
         c = self.data.shape[1]
@@ -85,13 +130,17 @@ class ConvSpec:
         d.precision = self.precision
         for i, c in enumerate(self.cin_segments):
             d.src[i].C = c
-            if srcs is not None:
-                f = srcs[i]
-                d.src[i].data = f.data.data_ptr()
-                d.src[i].mean = f.mean.data_ptr() if f.mean is not None else None
-                d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
-                d.src[i].act = f.act
+        if srcs is not None:
+            self.fill_sources(d, srcs)
         return d
+
+    def fill_sources(self, d, srcs):
+        """Point the descriptor at (virtual) fp32 sources; reading mean / rstd finalises pending statistics."""
+        for i, f in enumerate(srcs):
+            d.src[i].data = f.data.data_ptr()
+            d.src[i].mean = f.mean.data_ptr() if f.virtual else None
+            d.src[i].rstd = f.rstd.data_ptr() if f.virtual else None
+            d.src[i].act = f.act
 
     def out_size(self, h, w):
         d = self.desc(1, h, w)
@@ -136,21 +185,66 @@ def presplit(f):
     """Split-bf16 copy of a (virtual) feature: XS[n][head|tail][C/8][H*W][8 x bf16] with the producer's
     InstanceNorm + activation applied (ap_split_prepass).  Cached on the Feat: one pass serves every consumer."""
     if f.xs is None:
-        x = f.data
-        n, c, h, w = x.shape
-        _require_device(x, 'presplit source')
-        lib = C.lib()
-        nbytes = C.check(lib.ap_split_prepass_bytes(n, c, h, w), 'split_prepass_bytes')
-        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-        s = C.ApSrc()
-        s.data = x.data_ptr()
-        s.mean = f.mean.data_ptr() if f.mean is not None else None
-        s.rstd = f.rstd.data_ptr() if f.rstd is not None else None
-        s.C, s.act = c, f.act
-        C.check(lib.ap_split_prepass(ctypes.byref(s), n, h, w, ctypes.c_void_p(out.data_ptr()), _stream()),
-                'split_prepass')
-        f.xs = out
+        _norm_apply_split(f, None, want_y=False, want_xs=True)
     return f.xs
+
+
+def _alloc_xs(x):
+    n, c, h, w = x.shape
+    nbytes = C.check(C.lib().ap_split_prepass_bytes(n, c, h, w), 'split_prepass_bytes')
+    return torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+
+
+def _norm_apply_split(f, residual, want_y, want_xs):
+    """One ap_norm_apply_split pass over ``f``: finalises pending statistics on the way, returns the fp32
+    tensor ``act(IN(f)) [+ IN(residual)]`` (want_y) and / or its split-bf16 copy (want_xs).  Without a residual the
+    split copy is f's own and is cached on it."""
+    x = f.data
+    n, c, h, w = x.shape
+    _require_device(x, 'norm/split source')
+    s = C.ApSrc()
+    s.data, s.C, s.act = x.data_ptr(), c, f.act
+    partial, tiles, mo, ro = None, 0, None, None
+    if f.pending is not None:
+        partial, tiles = f.pending
+        f._alloc_stats()
+        mo, ro = f._mean, f._rstd
+    elif f._mean is not None:
+        s.mean, s.rstd = f._mean.data_ptr(), f._rstd.data_ptr()
+    r = None
+    if residual is not None:
+        if residual.act != ACT_NONE and residual.virtual:
+            raise ValueError('a normalised residual cannot carry an activation')
+        if residual.data.shape != x.shape:
+            raise ValueError('residual shape mismatch')
+        r = C.ApSrc()
+        r.data, r.C, r.act = residual.data.data_ptr(), c, ACT_NONE
+        if residual.virtual:
+            r.mean, r.rstd = residual.mean.data_ptr(), residual.rstd.data_ptr()
+    y = torch.empty_like(x) if want_y else None
+    xs = _alloc_xs(x) if want_xs else None
+    C.check(C.lib().ap_norm_apply_split(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
+                                        ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
+                                        _stream()), 'norm_apply_split')
+    f.pending = None
+    if want_xs and residual is None:
+        f.xs = xs
+    return y, xs
+
+
+def wants_split(c):
+    """Whether a materialised residual-trunk feature of ``c`` channels is going to be staged by a split-bf16
+    convolution: its consumers are c -> c 3x3 layers, so this is the C library's eligibility rule (>= 48 outputs,
+    >= 32 inputs in 16-channel segments).  A wrong guess only costs the unused copy."""
+    return DEFAULT_PRECISION == PRECISION_BF16X3 and c >= 48 and c % 16 == 0
+
+
+def takes_split(spec, n, h, w):
+    """Whether the convolution ``spec`` stages its sources as split-bf16 copies at this input size."""
+    if spec.precision == PRECISION_FP32:
+        return False
+    d = spec.desc(n, h, w)
+    return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
 
 
 def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE):
@@ -161,18 +255,24 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
     x0 = srcs[0].data
     n, _, h, w = x0.shape
     for f, c in zip(srcs, spec.cin_segments):
-        _require_device(f.data, 'conv input')
+        if not f.is_split_only:
+            _require_device(f.data, 'conv input')
         if f.data.shape[1] != c or f.data.shape[0] != n or f.data.shape[2:] != x0.shape[2:]:
             raise ValueError('conv2d: source of shape %s does not match segment C=%d' % (tuple(f.data.shape), c))
-    d = spec.desc(n, h, w, srcs, act)
+    d = spec.desc(n, h, w, None, act)
     lib = C.lib()
     if spec.precision != PRECISION_FP32 and C.check(lib.ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'):
-        # this layer runs on the split-bf16 matrix path: hand it the split copies of its sources
+        # this layer runs on the split-bf16 matrix path: hand it the split copies of its sources (made, together
+        # with the sources' pending InstanceNorm statistics, in one pass each)
         d.presplit = 1
         for i, f in enumerate(srcs):
             d.src[i].data = presplit(f).data_ptr()
             d.src[i].mean = d.src[i].rstd = None
             d.src[i].act = ACT_NONE
+    else:
+        if any(f.is_split_only for f in srcs):
+            raise RuntimeError('conv2d: a source exists only as its split-bf16 copy but this layer reads fp32')
+        spec.fill_sources(d, srcs)
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
     y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)
@@ -195,23 +295,28 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
                                  e0, e1))
     if not want_stats:
         return Feat(y)
-    mean = torch.empty(n * spec.cout, dtype=torch.float32, device=x0.device)
-    rstd = torch.empty_like(mean)
-    C.check(lib.ap_instnorm_finalize(_ptr(partial), n * spec.cout, tiles, ho.value * wo.value, EPS,
-                                     _ptr(mean), _ptr(rstd), _stream()), 'instnorm_finalize')
-    return Feat(y, mean, rstd, out_act)
+    return Feat(y, act=out_act, pending=(partial, tiles))
 
 
-def materialize(f, residual=None):
-    """out = act(IN(f.data)) [+ residual]; residual may itself be a virtual Feat (act must be NONE)."""
-    if f.mean is None:
+def materialize(f, residual=None, emit_xs=None):
+    """out = act(IN(f.data)) [+ residual]; residual may itself be a virtual Feat (act must be NONE).
+    emit_xs: also write the split-bf16 copy of ``out`` in the same pass (default: when a split-bf16 convolution
+    can consume it)."""
+    if not f.virtual:
         raise ValueError('materialize: feature is already plain')
+    n, c, h, w = f.data.shape
+    if emit_xs is None:
+        emit_xs = wants_split(c)
+    if c % 8 == 0:
+        y, xs = _norm_apply_split(f, residual, want_y=True, want_xs=bool(emit_xs))
+        out = Feat(y)
+        out.xs = xs
+        return out
     x = f.data
-    n, c, h, w = x.shape
     out = torch.empty_like(x)
     res = rm = rr = None
     if residual is not None:
-        if residual.act != ACT_NONE and residual.mean is not None:
+        if residual.act != ACT_NONE and residual.virtual:
             raise ValueError('materialize: a normalised residual cannot carry an activation')
         res, rm, rr = residual.data, residual.mean, residual.rstd
         if res.shape != x.shape:
@@ -221,8 +326,10 @@ def materialize(f, residual=None):
     return Feat(out)
 
 
-def warp_concat(f, motion, flow, ifmask, level):
-    """double_feature_warping (networks.py:1298-1313) on a (possibly virtual) feature map."""
+def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True):
+    """double_feature_warping (networks.py:1298-1313) on a (possibly virtual) feature map.  emit_xs: the 2C-channel
+    concat is going to be staged by a split-bf16 convolution, so the kernel also writes its split copy; with
+    keep_fp32=False (inference) that copy is the only output and the result is a split-only Feat."""
     x = f.data
     n, c, h, w = x.shape
     for t, name in ((x, 'x'), (motion, 'motion'), (flow, 'flow'), (ifmask, 'ifmask')):
@@ -232,11 +339,21 @@ def warp_concat(f, motion, flow, ifmask, level):
         raise ValueError('warp_concat: motion/flow/ifmask shapes %s %s %s' % (motion.shape, flow.shape, ifmask.shape))
     if h != s >> level or w != s >> level:
         raise ValueError('warp_concat: level %d expects %d px features, got %dx%d' % (level, s >> level, h, w))
-    out = torch.empty((n, 2 * c, h, w), dtype=torch.float32, device=x.device)
-    C.check(C.lib().ap_warp_concat_fwd(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
-                                       _ptr(ifmask), _ptr(out), n, c, h, w, s, 1.0 / (1 << level), _stream()),
-            'warp_concat_fwd')
-    return Feat(out)
+    emit_xs = bool(emit_xs) and c % 8 == 0
+    out = xs = None
+    if keep_fp32 or not emit_xs:
+        out = torch.empty((n, 2 * c, h, w), dtype=torch.float32, device=x.device)
+    if emit_xs:
+        nbytes = C.check(C.lib().ap_split_prepass_bytes(n, 2 * c, h, w), 'split_prepass_bytes')
+        xs = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    C.check(C.lib().ap_warp_concat_fwd_split(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
+                                             _ptr(ifmask), _ptr(out), _ptr(xs), n, c, h, w, s, 1.0 / (1 << level),
+                                             _stream()), 'warp_concat_fwd')
+    if out is None:
+        return Feat.split_only((n, 2 * c, h, w), xs)
+    res = Feat(out)
+    res.xs = xs
+    return res
 
 
 # =============================================================================== backward ops

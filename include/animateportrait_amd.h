@@ -110,6 +110,15 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
 int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d);
 int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W);
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream);
+/* The whole step between two convolutions in one streaming pass (ResnetBlock: networks.py:2329-2360):
+ *     v = act(IN(src)) [+ IN(residual)]      y = v as fp32 (NULL: skip)      xs = split-bf16 copy of v (NULL: skip)
+ * The InstanceNorm statistics of `src` come finished (src->mean / rstd) or -- stat_partials != NULL, src->mean NULL --
+ * as the producing convolution's partial tiles (ap_conv2d_fwd), which this call finalises exactly as
+ * ap_instnorm_finalize does and stores to mean_out / rstd_out ([N*C]) for later consumers.  `residual` (nullable)
+ * may carry finished statistics but no activation.  With y == xs == NULL it is a plain finalize. */
+int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
+                        float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
+                        ap_stream_t stream);
 
 /* name of the conv_igemm_f32 instantiation the plan selects for `d` (as it appears, demangled, in a
  * rocprofv3 kernel trace), e.g. "ConvCfg<4, 1, 3, 2, 2, 2, 2>"; used by bench.py to attribute time per kernel */
@@ -137,6 +146,13 @@ int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd,
                        const float* motion, const float* flow, const float* ifmask,
                        float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                        float flow_scale, ap_stream_t stream);
+/* Same operator with both outputs optional: out (fp32 [N, 2C, H, W]) and / or xs, the split-bf16 copy of that
+ * tensor (ap_split_prepass layout, ap_split_prepass_bytes(N, 2C, H, W) bytes; needs C % 8 == 0) that the next
+ * split-bf16 convolution stages -- an inference pass then never writes or re-reads the fp32 concat. */
+int ap_warp_concat_fwd_split(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                             const float* motion, const float* flow, const float* ifmask,
+                             float* out, void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
+                             float flow_scale, ap_stream_t stream);
 
 /* ======================================================================= backward pass
  * What torch.autograd launches for the layers above (loss.backward() at

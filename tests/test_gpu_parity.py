@@ -113,6 +113,72 @@ def test_warp_of_virtual_feature(dev):
     assert float(((y - ref).abs() > 1e-4).float().mean()) < 1e-4
 
 
+def _decode_split(xs, n, c, h, w):
+    """XS[n][head|tail][c/8][h*w + 1][8 x bf16] (include/animateportrait_amd.h) -> (head + tail as fp32 NCHW,
+    the all-zero slots)."""
+    t = xs.view(torch.bfloat16).view(n, 2, c // 8, h * w + 1, 8).float()
+    val = (t[:, 0] + t[:, 1])[:, :, :h * w]                      # n, c/8, hw, 8
+    return val.permute(0, 1, 3, 2).reshape(n, c, h, w), t[:, :, :, h * w]
+
+
+def test_warp_split_output(dev):
+    """The warp kernel's split-bf16 output (what the next split-bf16 conv stages) carries the same values as its
+    fp32 output, to the 16 mantissa bits a bf16 head + tail hold; split-only mode writes no fp32 tensor."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.synthetic import make_generator_inputs
+    d = make_generator_inputs(2, seed=9)
+    mo, fl, mk = d['motion'].to(dev), d['flow'].to(dev), d['ifmask'].to(dev)
+    x = torch.randn(2, 16, 64, 64, generator=torch.Generator().manual_seed(3)) * 3 + 1
+    m = x.mean((2, 3)).reshape(-1)
+    r = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+
+    def feat():
+        return ops.Feat(x.to(dev), m.to(dev), r.to(dev), ops.ACT_RELU)
+    plain = ops.warp_concat(feat(), mo, fl, mk, 2)
+    both = ops.warp_concat(feat(), mo, fl, mk, 2, emit_xs=True)
+    only = ops.warp_concat(feat(), mo, fl, mk, 2, emit_xs=True, keep_fp32=False)
+    assert plain.xs is None and torch.equal(both.data, plain.data)
+    assert only.is_split_only and tuple(only.shape) == (2, 32, 64, 64) and torch.equal(only.xs, both.xs)
+    val, zeros = _decode_split(both.xs, 2, 32, 64, 64)
+    assert float(zeros.abs().max()) == 0.0
+    err = (val - plain.data).abs()
+    assert float((err - plain.data.abs() * 2.0 ** -16).max()) <= 1e-30
+    with pytest.raises(RuntimeError):
+        ops.materialize(ops.Feat(only.data, m.to(dev).repeat(2), r.to(dev).repeat(2)))   # no fp32 data to read
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32), (1, 48, 17, 23), (2, 8, 40, 40)])
+def test_fused_norm_residual_split(dev, shape):
+    """ap_norm_apply_split: InstanceNorm finalised from the conv's partial tiles + activation + residual add, written
+    as fp32 and as the split copy in one pass == finalize + instnorm_apply + split_prepass."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(n * 1000 + c)
+    src = ops.Feat((torch.randn(n, 16, h, w, generator=g) * 2).to(dev))
+    res = torch.randn(n, c, h, w, generator=g).to(dev)
+    layer = ConvLayer([16], c, 3, 1, 1, ops.PAD_REFLECT).to(dev)
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) * 0.1)
+    a = layer.run(src, norm_act=ops.ACT_RELU)        # statistics pending
+    b = layer.run(src, norm_act=ops.ACT_RELU)
+    assert a.pending is not None
+    mean, rstd = b.mean.clone(), b.rstd.clone()       # standalone finalize
+    y, xs = ops._norm_apply_split(a, ops.Feat(res), want_y=True, want_xs=True)
+    assert a.pending is None and torch.equal(a.mean, mean) and torch.equal(a.rstd, rstd)
+    ref = F.relu(F.instance_norm(b.data.double().cpu())) + res.double().cpu()
+    assert linf(y, ref) < 2e-5 * float(ref.abs().max())
+    val, zeros = _decode_split(xs, n, c, h, w)
+    assert float(zeros.abs().max()) == 0.0
+    assert float(((val - y).abs() - y.abs() * 2.0 ** -16).max()) <= 1e-30
+    # the split of a plain feature, and of a virtual one without residual
+    xs2 = ops.presplit(ops.Feat(y))
+    assert torch.equal(_decode_split(xs2, n, c, h, w)[0], val)
+    y3, xs3 = ops._norm_apply_split(b, None, want_y=True, want_xs=True)
+    assert linf(y3, F.relu(F.instance_norm(b.data.double().cpu()))) < 2e-5 * float(ref.abs().max())
+    assert float(((_decode_split(xs3, n, c, h, w)[0] - y3).abs() - y3.abs() * 2.0 ** -16).max()) <= 1e-30
+
+
 @pytest.mark.parametrize('disp', [3, 1])
 def test_generator_ngf8(dev, golden, disp):
     from animateportrait_amd import networks as N
