@@ -81,6 +81,9 @@ SIGNATURES = {
     'ap_act_bwd': (ctypes.c_int, [c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
                                   ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
     'ap_bias_grad': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_bias_grad_workspace_floats': (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'ap_bias_grad_ws': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p,
+                                       ctypes.c_void_p]),
     'ap_warp_concat_bwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                           ctypes.c_void_p]),

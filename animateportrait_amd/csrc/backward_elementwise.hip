@@ -145,6 +145,29 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict_
     if (threadIdx.x == 0) db[c] = s;
 }
 
+// Two-stage form for few channels (C = 1: the final layer of the generator and of every PatchGAN): stage 1 reduces
+// SPLIT slices of every (n, c) plane in parallel, stage 2 adds the N * SPLIT partials of a channel in a fixed order.
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float* __restrict__ dy, int C, int HW, int split,
+                                                                float* __restrict__ ws) {
+    __shared__ float red[8];
+    const int c = blockIdx.x, n = blockIdx.y, sp = blockIdx.z;
+    const int per = (HW + split - 1) / split;
+    const int lo = sp * per, hi = lo + per < HW ? lo + per : HW;
+    const float* p = dy + ((long long)n * C + c) * HW;
+    float s = 0.f;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) s += p[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) ws[((long long)c * gridDim.y + n) * split + sp] = s;
+}
+
+__global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* __restrict__ ws, int count, float* __restrict__ db) {
+    const int c = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    float s = 0.f;
+    for (int i = 0; i < count; ++i) s += ws[(long long)c * count + i];
+    db[c] = s;
+}
+
 }  // namespace apamd
 
 using namespace apamd;
@@ -194,6 +217,31 @@ int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, a
     if (!dy || !db || N < 1 || C < 1 || HW < 1) return fail(AP_ERR_INVALID, "bias_grad: bad arguments");
     hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, N, C, HW, db);
     return check_launch("bias_grad_kernel");
+}
+
+static int bias_grad_split(int N, int C, int HW) {
+    // enough slices to put ~2 workgroups on every CU, each still streaming >= 4096 elements
+    int split = 512 / (N * C > 0 ? N * C : 1);
+    const int cap = HW / 4096;
+    if (split > cap) split = cap;
+    return split < 1 ? 1 : split;
+}
+
+int64_t ap_bias_grad_workspace_floats(int32_t N, int32_t C, int32_t HW) {
+    if (N < 1 || C < 1 || HW < 1) return fail(AP_ERR_INVALID, "bias_grad: bad arguments");
+    return (int64_t)N * C * bias_grad_split(N, C, HW);
+}
+
+int ap_bias_grad_ws(const float* dy, int32_t N, int32_t C, int32_t HW, float* workspace, float* db, ap_stream_t stream) {
+    if (!dy || !db || !workspace || N < 1 || C < 1 || HW < 1) return fail(AP_ERR_INVALID, "bias_grad: bad arguments");
+    if (N > 65535) return fail(AP_ERR_UNSUPPORTED, "bias_grad: N too large");
+    const int split = bias_grad_split(N, C, HW);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(C, N, split), dim3(256), 0, (hipStream_t)stream, dy, C, HW, split,
+                       workspace);
+    int rc = check_launch("bias_grad_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, workspace, N * split, db);
+    return check_launch("bias_grad_final_kernel");
 }
 
 }  // extern "C"

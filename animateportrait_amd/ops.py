@@ -477,7 +477,13 @@ def act_bwd(contribs, out, act):
 def bias_grad(dy):
     n, c, h, w = dy.shape
     db = torch.empty(c, dtype=torch.float32, device=dy.device)
-    C.check(C.lib().ap_bias_grad(_ptr(dy), n, c, h * w, _ptr(db), _stream()), 'bias_grad')
+    lib = C.lib()
+    if c >= 128:
+        C.check(lib.ap_bias_grad(_ptr(dy), n, c, h * w, _ptr(db), _stream()), 'bias_grad')
+    else:   # few channels: one workgroup per channel would leave the GPU idle
+        nws = C.check(lib.ap_bias_grad_workspace_floats(n, c, h * w), 'bias_grad_workspace_floats')
+        ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
+        C.check(lib.ap_bias_grad_ws(_ptr(dy), n, c, h * w, _ptr(ws), _ptr(db), _stream()), 'bias_grad')
     return db
 
 

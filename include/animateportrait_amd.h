@@ -201,6 +201,10 @@ int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* ou
                int32_t H, int32_t W, float* dy, ap_stream_t stream);
 /* db[c] = sum over n and pixels of dy (layers whose bias is live) */
 int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, ap_stream_t stream);
+/* the same sum in two stages (parallel over n and slices of the plane, then a fixed-order add): the form to use when
+ * C is small (the 1-channel output layers); workspace: ap_bias_grad_workspace_floats() floats */
+int64_t ap_bias_grad_workspace_floats(int32_t N, int32_t C, int32_t HW);
+int ap_bias_grad_ws(const float* dy, int32_t N, int32_t C, int32_t HW, float* workspace, float* db, ap_stream_t stream);
 /* backward of ap_warp_concat_fwd w.r.t. x (gout: N x 2C x H x W -> dx: N x C x H x W, zeroed inside) */
 int ap_warp_concat_bwd(const float* gout, const float* motion, const float* flow, const float* ifmask,
                        float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale,
