@@ -62,6 +62,7 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
     static std::vector<Bf3Kernel> v = {
         bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
         bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
+        bk<Bf3Cfg<1, 4, 1, 1, 4, 4>>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
         // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
@@ -156,7 +157,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     if (d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
-        if (seg_ok && (KT == 0 || K == 3))
+        if (seg_ok && (KT == 0 || K == 3 || (K == 4 && S == 1)))
             for (const auto& k : bf3_registry())
                 if (k.S == S && k.K == KT) pl.bk = &k;
         if (KT == 0 && K != 3 && K != 4) pl.bk = nullptr;

@@ -511,6 +511,8 @@ def test_conv_bf16x3_persistent_walk(dev, blocks, monkeypatch):
 
 @pytest.mark.parametrize('case', [
     # cin, cout, k, stride, transposed, H, W
+    (64, 96, 4, 1, False, 33, 31),               # PatchGAN 4x4 stride-1 layers (32-cout tiles)
+    (256, 512, 4, 1, False, 32, 32),
     (48, 64, 3, 2, False, 30, 66),
     (80, 64, 3, 2, True, 16, 32),
     (64, 128, 3, 2, False, 64, 64),
@@ -534,10 +536,10 @@ def test_conv_bf16x3_strided_and_transposed(dev, case):
     xr = F.relu(F.instance_norm(x)).double()
     op = 1 if k == 3 else 0
     ref = (F.conv_transpose2d(xr, w.double(), b.double(), stride=2, padding=1, output_padding=op) if transposed
-           else F.conv2d(xr, w.double(), b.double(), stride=2, padding=1))
+           else F.conv2d(xr, w.double(), b.double(), stride=stride, padding=1))
     scale = float(ref.abs().max())
     for prec, tol in ((ops.PRECISION_BF16X3, 5e-5), (ops.PRECISION_FP32, 2e-6)):
-        layer = ConvLayer([cin], cout, k, 2, 1, ops.PAD_ZERO, transposed, op if transposed else 0).to(dev)
+        layer = ConvLayer([cin], cout, k, stride, 1, ops.PAD_ZERO, transposed, op if transposed else 0).to(dev)
         layer.spec.precision = prec
         with torch.no_grad():
             layer.weight.copy_(w); layer.bias.copy_(b)
