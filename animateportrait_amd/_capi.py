@@ -39,7 +39,7 @@ class ApWgradDesc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int32), ('M', ctypes.c_int32), ('GH', ctypes.c_int32), ('GW', ctypes.c_int32),
                 ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('K', ctypes.c_int32), ('stride', ctypes.c_int32),
                 ('pad', ctypes.c_int32), ('pad_mode', ctypes.c_int32), ('nsrc', ctypes.c_int32),
-                ('reserved', ctypes.c_int32), ('g', ApSrc), ('src', ApSrc * 3)]
+                ('precision', ctypes.c_int32), ('g', ApSrc), ('src', ApSrc * 3)]
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares

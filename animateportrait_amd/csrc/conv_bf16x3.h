@@ -626,7 +626,7 @@ struct PackBf3Params {
     int ntaps, tap_ky[kMaxTaps], tap_kx[kMaxTaps];      // source tap of packed tap t (already flipped if needed)
 };
 
-__global__ void pack_bf16x3_kernel(const PackBf3Params p) {
+static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
     const int T = p.ntaps;
     const long long per_block = 2LL * T * 2 * p.CO_TILE * 8;
     const long long total = (long long)p.co_tiles * p.nchunks * per_block;

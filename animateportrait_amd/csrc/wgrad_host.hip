@@ -4,6 +4,7 @@
 //                   -> wgrad_igemm_f32 (split over pixels) -> wgrad_reduce_kernel.
 // The caller provides ONE workspace; its layout is  [A padded][G padded (optional)][partials].
 #include "common.h"
+#include "wgrad_bf16x3.h"
 #include "wgrad_igemm.h"
 
 #include <cstdlib>
@@ -39,7 +40,31 @@ struct WgradPlan {
     int GHp = 0, GWp = 0, Hp = 0, Wp = 0;
     bool g_direct = false;
     long long a_floats = 0, g_floats = 0, part_floats = 0;
+    // split-bf16 kernel (wgrad_bf16x3.h): operands as [n][part][row][x/8][channel] pixel-octet slots
+    bool bf3 = false;
+    int c_tiles = 0, Mp = 0, Cp = 0, GX8 = 0, AX8 = 0;
 };
+
+// split-bf16 instantiations by kernel size (stride 1)
+struct WgradBf3Kernel {
+    int K;
+    const void* fn;
+    size_t lds_bytes;
+};
+static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
+    static std::vector<WgradBf3Kernel> v = {
+        {3, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>>), WgradBf3Cfg<3>::lds_bytes()},
+        {4, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>>), WgradBf3Cfg<4>::lds_bytes()},
+    };
+    return v;
+}
+
+static int num_cus_w() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) return 256;
+    return n;
+}
 
 static long long round4(long long x) { return (x + 3) / 4 * 4; }
 
@@ -61,8 +86,36 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         if (d->src[s].C < 1) return fail(AP_ERR_INVALID, "wgrad: segment %d has C=%d", s, d->src[s].C);
         pl.Cin += d->src[s].C;
     }
-    const int S = d->stride, K = d->K, PR = pl.k->PR;
+    const int S = d->stride, K = d->K;
     pl.Q = pl.Cin * K * K;
+    const char* nob = getenv("APAMD_NO_BF16X3");
+    if (d->precision == AP_PRECISION_BF16X3 && S == 1 && (K == 3 || K == 4) && d->M >= 48 && pl.Cin >= 32 &&
+        !(nob && atoi(nob))) {
+        // wide stride-1 layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
+        pl.bf3 = true;
+        pl.tiles_x = (d->GW + 31) / 32;
+        pl.tiles_y = (d->GH + 1) / 2;
+        pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
+        pl.m_tiles = (d->M + 63) / 64;
+        pl.c_tiles = (pl.Cin + 63) / 64;
+        const char* e = getenv("APAMD_WGRAD_BLOCKS");
+        const int target = e ? atoi(e) : num_cus_w();            // one workgroup per CU (its LDS stages fill a CU)
+        int P = target / (pl.m_tiles * pl.c_tiles);
+        if (P > pl.nstages / 2) P = pl.nstages / 2;
+        if (P < 1) P = 1;
+        pl.P = P;
+        pl.Mp = pl.m_tiles * 64;
+        pl.Cp = pl.c_tiles * 64;
+        pl.GHp = pl.tiles_y * 2;
+        pl.GX8 = pl.tiles_x * 4;
+        pl.Hp = pl.GHp + K - 1;
+        pl.AX8 = pl.tiles_x * 4 + 1;
+        pl.a_floats = (long long)d->N * 2 * pl.Hp * pl.AX8 * pl.Cp * 4;      // 16-byte slots -> floats
+        pl.g_floats = (long long)d->N * 2 * pl.GHp * pl.GX8 * pl.Mp * 4;
+        pl.part_floats = (long long)pl.P * d->M * pl.Q;
+        return AP_OK;
+    }
+    const int PR = pl.k->PR;
     pl.tiles_x = (d->GW + 31) / 32;
     pl.tiles_y = (d->GH + PR - 1) / PR;
     pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
@@ -107,8 +160,35 @@ static int launch_pad(const ap_src* segs, int nseg, int N, int C, int H, int W, 
     return check_launch("pad_materialize_kernel");
 }
 
+static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode,
+                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream) {
+    SplitTParams p;
+    memset(&p, 0, sizeof(p));
+    p.nseg = nseg;
+    int cbeg = 0;
+    for (int s = 0; s < nseg; ++s) {
+        p.seg[s].data = segs[s].data; p.seg[s].mean = segs[s].mean; p.seg[s].rstd = segs[s].rstd;
+        p.seg[s].C = segs[s].C; p.seg[s].act = segs[s].act; p.seg[s].chunk_begin = cbeg;
+        cbeg += segs[s].C;
+    }
+    p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
+    if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
+    hipLaunchKernelGGL(split_transpose_kernel, dim3(Hp, Cp / 64, N), dim3(256), 0, stream, p);
+    return check_launch("split_transpose_kernel");
+}
+
 static std::mutex g_wattr_mu;
 static std::vector<const void*> g_wattr_done;
+
+static int ensure_wattr(const void* fn) {
+    std::lock_guard<std::mutex> lk(g_wattr_mu);
+    for (auto f : g_wattr_done)
+        if (f == fn) return AP_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    g_wattr_done.push_back(fn);
+    return AP_OK;
+}
 
 }  // namespace apamd
 
@@ -149,16 +229,42 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
     }
-    {
-        std::lock_guard<std::mutex> lk(g_wattr_mu);
-        bool done = false;
-        for (auto f : g_wattr_done) done = done || f == pl.k->fn;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(pl.k->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            g_wattr_done.push_back(pl.k->fn);
-        }
+    if (pl.bf3) {
+        const WgradBf3Kernel* bk = nullptr;
+        for (const auto& k : wgrad_bf3_registry())
+            if (k.K == d->K) bk = &k;
+        if (!bk) return fail(AP_ERR_UNSUPPORTED, "wgrad: no split-bf16 kernel for k=%d", d->K);
+        rc = ensure_wattr(bk->fn);
+        if (rc) return rc;
+        uint4* at = reinterpret_cast<uint4*>(workspace);
+        uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
+        float* partial = workspace + pl.a_floats + pl.g_floats;
+        rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cin, d->H, d->W, d->pad, d->pad_mode, pl.Hp, pl.AX8, pl.Cp,
+                                    at, stream);
+        if (rc) return rc;
+        ap_src g = d->g;
+        g.C = d->M;
+        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream);
+        if (rc) return rc;
+        WgradBf3Params p;
+        memset(&p, 0, sizeof(p));
+        p.gt = gt; p.at = at;
+        p.N = d->N; p.M = d->M; p.Cin = pl.Cin; p.Q = pl.Q;
+        p.GHp = pl.GHp; p.GX8 = pl.GX8; p.Mp = pl.Mp; p.Hp = pl.Hp; p.AX8 = pl.AX8; p.Cp = pl.Cp;
+        p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P;
+        p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
+        p.partial = partial;
+        void* args[] = {&p};
+        const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
+        hipError_t e = hipLaunchKernel(bk->fn, dim3(nblk), dim3(256), args, bk->lds_bytes, stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
+        const long long n = (long long)d->M * pl.Q;
+        int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, n, dw);
+        return check_launch("wgrad_reduce_kernel");
     }
+    rc = ensure_wattr(pl.k->fn);
+    if (rc) return rc;
     float* a_pad = workspace;
     float* g_pad = workspace + pl.a_floats;
     float* partial = g_pad + pl.g_floats;

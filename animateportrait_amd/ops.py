@@ -357,9 +357,10 @@ def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True):
 
 
 # =============================================================================== backward ops
-def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape):
+def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
-    srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW)."""
+    srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW).
+    precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers)."""
     n, m, gh, gw = g.data.shape
     cin = sum(f.data.shape[1] for f in srcs)
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
@@ -369,6 +370,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape):
     d.H, d.W = srcs[0].data.shape[2], srcs[0].data.shape[3]
     d.K, d.stride, d.pad, d.pad_mode = k, stride, pad, pad_mode
     d.nsrc = len(srcs)
+    d.precision = DEFAULT_PRECISION if precision is None else precision
     d.g.data = g.data.data_ptr()
     d.g.mean = g.mean.data_ptr() if g.mean is not None else None
     d.g.rstd = g.rstd.data_ptr() if g.rstd is not None else None

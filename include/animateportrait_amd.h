@@ -176,7 +176,9 @@ typedef struct ap_wgrad_desc {
     int32_t GH, GW;       /* spatial size of g (the grid that is iterated) */
     int32_t H, W;         /* spatial size of the src tensors */
     int32_t K, stride, pad, pad_mode;
-    int32_t nsrc, reserved;
+    int32_t nsrc;
+    int32_t precision;    /* AP_PRECISION_*: BF16X3 lets wide stride-1 3x3 / 4x4 layers run on the bf16 matrix pipe
+                             with split operands (fp32-class results, ~4x the exact-fp32 MFMA rate) */
     ap_src g;             /* g.C is ignored (M is used) */
     ap_src src[3];
 } ap_wgrad_desc;

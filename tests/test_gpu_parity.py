@@ -355,6 +355,41 @@ def test_conv_backward_vs_autograd(dev, case, norm):
         assert linf(gx, x.grad) <= 2e-4 * float(x.grad.abs().max()) + 1e-5
 
 
+@pytest.mark.parametrize('case', [
+    # cin segs, cout, k, pad, mode, H, W, n
+    ([64], 64, 3, 1, 'reflect', 32, 32, 2),
+    ([32, 16, 16], 96, 3, 1, 'zero', 21, 45, 3),        # ragged: odd rows, partial column tile, 3 segments
+    ([256], 256, 3, 1, 'reflect', 64, 64, 2),
+    ([64], 128, 4, 1, 'zero', 32, 32, 2),               # PatchGAN 4x4 stride 1 (output 31 x 31)
+    ([40], 48, 3, 1, 'zero', 40, 40, 1),                # channel counts that are not multiples of 64
+])
+def test_wgrad_bf16x3(dev, case):
+    """Weight gradient on the bf16 matrix pipe (split operands) against the fp64 gradient, beside the exact-fp32
+    kernel on the same data; the input is a virtual (IN + ReLU) feature for the first segment."""
+    from animateportrait_amd import ops
+    segs, cout, k, pad, mode, H, W, n = case
+    g = torch.Generator().manual_seed(sum(map(ord, str(case))))
+    cin = sum(segs)
+    xs = [torch.randn(n, c, H, W, generator=g) * 1.5 + 0.3 for c in segs]
+    m0 = xs[0].mean((2, 3)).reshape(-1)
+    r0 = 1.0 / torch.sqrt(xs[0].var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+    feats = [ops.Feat(xs[0].to(dev), m0.to(dev), r0.to(dev), ops.ACT_RELU)] + [ops.Feat(x.to(dev)) for x in xs[1:]]
+    xr = torch.cat([F.relu(F.instance_norm(xs[0]))] + xs[1:], 1).double()
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    xp = F.pad(xr, (pad,) * 4, mode='reflect') if mode == 'reflect' else F.pad(xr, (pad,) * 4)
+    y = F.conv2d(xp, w)
+    up = torch.randn(y.shape, generator=g)
+    (y * up.double()).sum().backward()
+    ref = w.grad
+    pm = ops.PAD_REFLECT if mode == 'reflect' else ops.PAD_ZERO
+    scale = float(ref.abs().max())
+    got = {}
+    for prec in (ops.PRECISION_BF16X3, ops.PRECISION_FP32):
+        got[prec] = ops.wgrad(k, 1, pad, pm, ops.Feat(up.to(dev)), feats, (cout, cin, k, k), precision=prec)
+    assert linf(got[ops.PRECISION_FP32], ref) < 5e-6 * scale
+    assert linf(got[ops.PRECISION_BF16X3], ref) < 5e-5 * scale, linf(got[ops.PRECISION_BF16X3], ref) / scale
+
+
 def test_warp_backward(dev):
     from animateportrait_amd import ops
     from animateportrait_amd.synthetic import make_generator_inputs
