@@ -34,6 +34,7 @@ struct WgradBf3Params {
     int nstages, P;
     int m_tiles, c_tiles;
     float* partial;           // [P][M][Q]
+    int ablate;               // debugging only (APAMD_ABLATE): 1 = no refill of the stage buffers, 2 = no barrier
 };
 
 template <int K_>
@@ -148,12 +149,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
     __syncthreads();
 
     // one group = (K step ks, kernel row ky): 4 raw octets of the shifted operand (+ 2 fragments of G at ky == 0),
-    // then K taps x 3 MFMAs
+    // then K taps x 3 MFMAs.  Groups run as a 3-deep software pipeline, flat across stages:
+    //     while group g multiplies:  the raw octets of group g+2 are read from LDS,
+    //                                the odd-shift operands of group g+1 are funnelled out of ITS raw octets,
+    // so every LDS read and every vector-ALU result has a whole group (>= 9 MFMAs) before its first use, and the
+    // products go round the K accumulators of the kernel row (consecutive MFMAs never wait on each other).
     constexpr int NG = 4 * K;
+    constexpr int RB = K == 3 ? 3 : 4;                                 // raw-octet register sets (RB divides NG)
+    static_assert(NG % RB == 0 && NG % 2 == 0, "register set indices must be stage-invariant");
     bf16x8 ah[2], al[2];                                               // by ks parity
-    u32x4 rh[2][2], rl[2][2];                                          // by group parity: [octet j]
-    auto fetch_group = [&](int buf, int gidx, int pb) __attribute__((always_inline)) {
-        const int ks = gidx / K, ky = gidx % K;
+    u32x4 rh[RB][2], rl[RB][2];                                        // by group index mod RB: [octet j]
+    bf16x8 sh[2][K], sl[2][K];                                         // funnelled operands by group parity (odd shifts)
+    auto fetch_group = [&](int buf, int gidx) __attribute__((always_inline)) {
+        const int ks = gidx / K, ky = gidx % K, rb = gidx % RB;
         const int py = ks >> 1, xh = ks & 1;
         const uint4* S0 = smem + buf * STAGE;
         if (ky == 0) {
@@ -163,78 +171,80 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
         const int row = py + ky;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            rh[pb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((0 * ROWS + row) * NXG + xh * 2 + j) * 64);
-            rl[pb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((1 * ROWS + row) * NXG + xh * 2 + j) * 64);
+            rh[rb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((0 * ROWS + row) * NXG + xh * 2 + j) * 64);
+            rl[rb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((1 * ROWS + row) * NXG + xh * 2 + j) * 64);
         }
     };
-    // shifted fragments of one group, then K taps x 3 products.  The products go round the K accumulators of the
-    // kernel row in turn (small terms first), so consecutive MFMAs never wait on each other's result.
-    auto shift_group = [&](int pb, bf16x8 (&bh)[K], bf16x8 (&bl)[K]) __attribute__((always_inline)) {
-        auto one = [&](auto kxtag) __attribute__((always_inline)) {
-            constexpr int KX = decltype(kxtag)::value;
-            bh[KX] = funnel8<KX>(rh[pb][0], rh[pb][1]);
-            bl[KX] = funnel8<KX>(rl[pb][0], rl[pb][1]);
-        };
-        one(std::integral_constant<int, 0>{});
-        one(std::integral_constant<int, 1>{});
-        one(std::integral_constant<int, 2>{});
-        if constexpr (K > 3) one(std::integral_constant<int, 3>{});
+    auto shift_group = [&](int gidx) __attribute__((always_inline)) {  // odd shifts only: even ones are register picks
+        const int rb = gidx % RB, pb = gidx & 1;
+        sh[pb][1] = funnel8<1>(rh[rb][0], rh[rb][1]);
+        sl[pb][1] = funnel8<1>(rl[rb][0], rl[rb][1]);
+        if constexpr (K > 3) {
+            sh[pb][3] = funnel8<3>(rh[rb][0], rh[rb][1]);
+            sl[pb][3] = funnel8<3>(rl[rb][0], rl[rb][1]);
+        }
     };
-    auto mfma_slot = [&](int gidx, int i, const bf16x8 (&bh)[K], const bf16x8 (&bl)[K]) __attribute__((always_inline)) {
-        const int ks = gidx / K, ky = gidx % K;
-        const int pr = i / K, kx = i % K;
+    auto mfma_one = [&](int gidx, int i) __attribute__((always_inline)) {
+        const int ks = gidx / K, ky = gidx % K, rb = gidx % RB, pb = gidx & 1;
+        const int pr = i / K, kx = i % K;                               // product-major: round the K accumulators
+        bf16x8 bh, bl;
+        if (kx == 0) { bh = funnel8<0>(rh[rb][0], rh[rb][1]); bl = funnel8<0>(rl[rb][0], rl[rb][1]); }
+        else if (kx == 2) { bh = funnel8<2>(rh[rb][0], rh[rb][1]); bl = funnel8<2>(rl[rb][0], rl[rb][1]); }
+        else { bh = sh[pb][kx]; bl = sl[pb][kx]; }
         f32x16& a = acc[ky * K + kx];
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al[ks & 1] : ah[ks & 1], pr == 1 ? bl[kx] : bh[kx], a, 0, 0, 0);
-    };
-    auto mfma_group = [&](int gidx, int pb) __attribute__((always_inline)) {
-        bf16x8 bh[K], bl[K];
-        shift_group(pb, bh, bl);
-#pragma unroll
-        for (int i = 0; i < 3 * K; ++i) mfma_slot(gidx, i, bh, bl);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al[ks & 1] : ah[ks & 1], pr == 1 ? bl : bh, a, 0, 0, 0);
     };
 
     auto stage = [&](auto ptag, int st) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;                       // stage buffer
-        // group parity continues across stages: NG is even, so group 0 always uses register set 0
-        if (st == st0) fetch_group(P, 0, 0);
+        constexpr int NM = 3 * K, PPS = (NPW + 2 * NM - 1) / (2 * NM);  // DMA pieces per MFMA slot (last two groups)
+        const bool more = st + 1 < st1, dma = st + 2 < st1 && !(p.ablate & 1);
+        if (st == st0) {
+            fetch_group(P, 0);
+            fetch_group(P, 1);
+            shift_group(0);
+        }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            const int pb = gi & 1;
-            if (gi + 1 < NG) {
-                fetch_group(P, gi + 1, pb ^ 1);
-                mfma_group(gi, pb);
-                // pin the schedule: the next group's LDS reads go one by one between this group's MFMAs (left
-                // alone, the scheduler sinks each read to just before its first use and waits on it)
-#pragma unroll
-                for (int i = 0; i < 3 * K; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                // every fragment of this stage is in registers: after the barrier the buffer is refilled with
-                // stage st+2, one DMA piece per MFMA triple, and the first group of stage st+1 is fetched
-                const bool more = st + 1 < st1, dma = st + 2 < st1;
+            if (gi == NG - 2) {
+                // the reads of this stage's last group were issued one group ago: once everybody is past the
+                // barrier the buffer can be refilled (stage st+2), and stage st+1 has landed for the reads below
                 if (dma) locate();
-                dma_wait_all();
-                __syncthreads();
-                constexpr int NM = 3 * K, PPS = (NPW + NM - 1) / NM;
-                bf16x8 bh[K], bl[K];
-                shift_group(pb, bh, bl);
+                if (!(p.ablate & 2)) {
+                    dma_wait_all();
+                    __syncthreads();
+                }
+            }
+            // (no run-time conditions in the steady-state groups: a branch would split the basic block and the
+            // compiler's wait-count bookkeeping turns conservative across blocks)
+            if (gi + 2 < NG) fetch_group(P, gi + 2);
+            else if (more) fetch_group(P ^ 1, gi + 2 - NG);
+            if (gi + 1 < NG) shift_group(gi + 1);
+            else if (more) shift_group(0);
 #pragma unroll
-                for (int i = 0; i < NM; ++i) {
-                    mfma_slot(gi, i, bh, bl);
-                    if (i == 0 && more) fetch_group(P ^ 1, 0, pb ^ 1);
-                    if (dma) {
+            for (int i = 0; i < NM; ++i) {
+                mfma_one(gi, i);
+                if (gi >= NG - 2 && dma) {
 #pragma unroll
-                        for (int pp = 0; pp < PPS; ++pp)
-                            if (i * PPS + pp < NPW) issue_piece(P, i * PPS + pp);
+                    for (int pp = 0; pp < PPS; ++pp) {
+                        const int j = ((gi - (NG - 2)) * NM + i) * PPS + pp;
+                        if (j < NPW) issue_piece(P, j);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (dma) advance();
             }
+            if (gi < NG - 2) {
+                // pin: the LDS reads go one by one after the first MFMAs (left alone, the scheduler sinks every
+                // read to just before its first use and waits on it)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (dma) advance();
     };
     for (int st = st0; st < st1; st += 2) {
         stage(std::integral_constant<int, 0>{}, st);
@@ -244,6 +254,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
     // partial[split][m][q], q = ci*T + tap.  C/D layout: column j = lane & 31 (ci), row i = (r&3) + 8*(r>>2) + 4*half (m)
     float* out = p.partial + (long long)split * p.M * p.Q;
     const int ci = ct * 64 + wq * 32 + l32;
+    if (p.ablate & 16) {
+        if (acc[0][0] == 123.456f) out[0] = 1.f;
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -255,8 +269,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
 
 // ---- operand preparation: T[n][part][y][x/8][c][8 px] (bf16 head / tail) = padded view of act(IN(concat(src))),
 // (y, x) <-> source (y - pad, x - pad); reflection or zero padding inside [0, H+2pad) x [0, W+2pad); zeros beyond,
-// and for channels >= C.  grid: (Hp, Cp/64, N); a workgroup transposes one padded row of 64 channels through LDS:
-// coalesced fp32 reads along x, 1 KiB contiguous slot writes along c.
+// and for channels >= C.  The transposition goes through LDS: fp32 reads run along x, slot writes along c.
 struct SplitTParams {
     SrcSeg seg[kMaxSeg];      // chunk_begin = first concat channel
     int nseg;
@@ -264,57 +277,65 @@ struct SplitTParams {
     uint4* out;
 };
 
+// grid: (ceil(Hp * X8 / 8), Cp / 64, N): a workgroup transposes 8 consecutive octets (64 padded pixels, possibly
+// across a row boundary) of 64 channels.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams p) {
     __shared__ float f[64][65];
-    const int y = blockIdx.x, cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
-    const int He = p.H + 2 * p.pad, We = p.W + 2 * p.pad;
-    int sy = y - p.pad;
-    bool yok = y < He;
-    if (p.pad_mode == 1) sy = reflect_clamp(sy, p.H);
-    else yok = yok && sy >= 0 && sy < p.H;
-    uint4* const oh = p.out + (((long long)(n * 2 + 0) * p.Hp + y) * p.X8) * p.Cp + cg * 64;
-    uint4* const ol = p.out + (((long long)(n * 2 + 1) * p.Hp + y) * p.X8) * p.Cp + cg * 64;
-    for (int x0 = 0; x0 < p.X8 * 8; x0 += 64) {
-        // phase 1: thread = (x, channel quarter): 64 consecutive pixels of one channel per wave-load
-        const int x = x0 + (tid & 63);
-        int sx = x - p.pad;
-        bool ok = yok && x < We;
-        if (p.pad_mode == 1) sx = reflect_clamp(sx, p.W);
-        else ok = ok && sx >= 0 && sx < p.W;
-        for (int cl = tid >> 6; cl < 64; cl += 4) {
-            const int c = cg * 64 + cl;
-            float v = 0.f;
-            if (ok && c < p.C) {
+    const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+    const int He = p.H + 2 * p.pad, We = p.W + 2 * p.pad, HW = p.H * p.W;
+    const int oct0 = blockIdx.x * 8, noct = p.Hp * p.X8;
+    // phase 1: thread = (pixel of the span, channel quarter): 16 independent loads, 8-pixel runs per octet
+    {
+        const int px = tid & 63, oct = oct0 + (px >> 3);
+        const int y = oct / p.X8, x = (oct - y * p.X8) * 8 + (px & 7);
+        int sy = y - p.pad, sx = x - p.pad;
+        bool ok = oct < noct && y < He && x < We;
+        if (p.pad_mode == 1) {
+            sy = reflect_clamp(sy, p.H);
+            sx = reflect_clamp(sx, p.W);
+        } else {
+            ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        }
+        const int soff = ok ? sy * p.W + sx : 0;
+        const int cq = (tid >> 6) * 16;                            // this thread's 16 channels of the group
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = cg * 64 + cq + i;
+            v[i] = 0.f;
+            if (c < p.C) {
                 int s = 0;
                 if (p.nseg > 1 && c >= p.seg[1].chunk_begin) s = 1;
                 if (p.nseg > 2 && c >= p.seg[2].chunk_begin) s = 2;
-                const SrcSeg sg = s == 0 ? p.seg[0] : (s == 1 ? p.seg[1] : p.seg[2]);
+                const SrcSeg sg = s == 0 ? p.seg[0] : (s == 1 ? p.seg[1] : p.seg[2]);   // wave-uniform
                 const int cs = c - sg.chunk_begin;
-                v = sg.data[((long long)n * sg.C + cs) * p.H * p.W + sy * p.W + sx];
-                if (sg.mean != nullptr) v = (v - sg.mean[n * sg.C + cs]) * sg.rstd[n * sg.C + cs];
-                v = sg.act == 1 ? fmaxf(v, 0.f) : (sg.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+                float t = sg.data[((long long)n * sg.C + cs) * HW + soff];
+                if (sg.mean != nullptr) t = (t - sg.mean[n * sg.C + cs]) * sg.rstd[n * sg.C + cs];
+                t = sg.act == 1 ? fmaxf(t, 0.f) : (sg.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+                v[i] = ok ? t : 0.f;
             }
-            f[cl][tid & 63] = v;
         }
-        __syncthreads();
-        // phase 2: thread = (channel, octet pair): 64 consecutive channels of one octet per wave-store
-        const int c = tid & 63;
-        for (int o = tid >> 6; o < 8; o += 4) {
-            const int xg = x0 / 8 + o;
-            if (xg < p.X8) {
-                bf16x8 hv, lv;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    __bf16 h, l;
-                    split_bf16(f[c][o * 8 + j], h, l);
-                    hv[j] = h;
-                    lv[j] = l;
-                }
-                *reinterpret_cast<bf16x8*>(oh + (long long)xg * p.Cp + c) = hv;
-                *reinterpret_cast<bf16x8*>(ol + (long long)xg * p.Cp + c) = lv;
+        for (int i = 0; i < 16; ++i) f[cq + i][px] = v[i];
+    }
+    __syncthreads();
+    // phase 2: thread = (channel, octet): 64 consecutive channels of one octet per wave-store (1 KiB contiguous)
+    const int c = tid & 63;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int o = (tid >> 6) + 4 * k, oct = oct0 + o;
+        if (oct < noct) {
+            bf16x8 hv, lv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 h, l;
+                split_bf16(f[c][o * 8 + j], h, l);
+                hv[j] = h;
+                lv[j] = l;
             }
+            *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * noct + oct) * p.Cp + cg * 64 + c) = hv;
+            *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cg * 64 + c) = lv;
         }
-        __syncthreads();
     }
 }
 

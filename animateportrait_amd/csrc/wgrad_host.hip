@@ -173,7 +173,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     }
     p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
-    hipLaunchKernelGGL(split_transpose_kernel, dim3(Hp, Cp / 64, N), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
     return check_launch("split_transpose_kernel");
 }
 
@@ -254,6 +254,10 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P;
         p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
         p.partial = partial;
+        {
+            const char* ab = getenv("APAMD_ABLATE");
+            p.ablate = ab ? atoi(ab) : 0;
+        }
         void* args[] = {&p};
         const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
         hipError_t e = hipLaunchKernel(bk->fn, dim3(nblk), dim3(256), args, bk->lds_bytes, stream);

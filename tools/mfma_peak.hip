@@ -10,7 +10,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int LDSREADS, int RANDOM_DATA>
+template <int LDSREADS, int RANDOM_DATA, int TRIPLES = 0>
 __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
     extern __shared__ uint4 lds[];
     const int tid = threadIdx.x;
@@ -50,6 +50,17 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) b[cb ^ 1][i] = src[((t * 12 + 4 + i) & 63) * 64];
             }
+            if (TRIPLES) {
+                // three dependent MFMAs back to back on every accumulator (the naive bf16x3 order)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            acc[m * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][m + 2 * (k & 1)], b[cb][q + 4 * (k >> 1)],
+                                                                                     acc[m * 4 + q], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -58,6 +69,7 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
                     for (int q = 0; q < 4; ++q)
                         acc[m * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][m + 2 * (k & 1)], b[cb][q + 4 * (k >> 1)],
                                                                                  acc[m * 4 + q], 0, 0, 0);
+            }
             if (LDSREADS) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
@@ -73,11 +85,11 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
     if (s == 123.456f) out[0] = s;
 }
 
-template <int LDSREADS, int RANDOM_DATA>
+template <int LDSREADS, int RANDOM_DATA, int TRIPLES = 0>
 static void run(const char* label, int blocks, int threads, size_t ldsbytes) {
     float* out;
     hipMalloc(&out, 64);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_stream<LDSREADS, RANDOM_DATA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_stream<LDSREADS, RANDOM_DATA, TRIPLES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                         160 * 1024);
     const int iters = 4000;
     hipEvent_t e0, e1;
@@ -85,7 +97,7 @@ static void run(const char* label, int blocks, int threads, size_t ldsbytes) {
     hipEventCreate(&e1);
     for (int rep = 0; rep < 4; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((mfma_stream<LDSREADS, RANDOM_DATA>), dim3(blocks), dim3(threads), ldsbytes, 0, out, iters);
+        hipLaunchKernelGGL((mfma_stream<LDSREADS, RANDOM_DATA, TRIPLES>), dim3(blocks), dim3(threads), ldsbytes, 0, out, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms = 0.f;
@@ -106,5 +118,7 @@ int main() {
     run<0, 1>("1 wave/SIMD, registers only, random data", cus, 256, 150 * 1024);
     run<1, 1>("1 wave/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
     run<1, 1>("2 waves/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 512, 150 * 1024);
+    run<0, 1, 1>("1 wave/SIMD, registers, random, dependent triples", cus, 256, 150 * 1024);
+    run<0, 0, 1>("1 wave/SIMD, registers, ones, dependent triples", cus, 256, 150 * 1024);
     return 0;
 }
