@@ -7,6 +7,7 @@
 #include "conv_registry.h"
 #include "conv_direct.h"
 #include "conv_bf16x3.h"
+#include "conv_small.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -92,6 +93,7 @@ struct Launch {
 struct Plan {
     const ConvKernelInfo* k = nullptr;
     int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
+    bool small = false;            // conv_small_f32: narrow 3x3 layers on the vector ALUs
     bool bf3 = false;              // split-bf16 matrix path
     const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
@@ -151,6 +153,16 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.cin_pad = pl.nchunks * ci;
         pl.packed_floats = (long long)pl.cin_pad * K * K * pl.direct_cop;
         pl.stat_tiles = ((pl.Hout + 15) / 16) * ((pl.Wout + 63) / 64);
+        return AP_OK;
+    }
+    // narrow 3x3 layers (landmark encoder): memory streams, one lane per output pixel (conv_small.h)
+    if (!d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
+        d->w_layout == AP_W_OIHW && !d->w_flip && !env_int("APAMD_NO_SMALL", 0)) {
+        pl.small = true;
+        pl.nchunks = 1;
+        pl.cin_pad = pl.Cin;
+        pl.packed_floats = (long long)d->Cout * pl.Cin * 9;       // the OIHW weights as they are
+        pl.stat_tiles = ((pl.Hout + 7) / 8) * ((pl.Wout + 31) / 32);
         return AP_OK;
     }
     // split-bf16 matrix path (conv_bf16x3.h): wide 3x3 / transposed layers when the caller allows ~1e-4 relative error
@@ -481,6 +493,10 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         snprintf(buf, buflen, "DirectCfg<%d, %d>", d->KH, pl.direct_cop);
         return AP_OK;
     }
+    if (pl.small) {
+        snprintf(buf, buflen, "SmallCfg<%d, %d>", d->stride, d->Cout);
+        return AP_OK;
+    }
     if (pl.bf3) {
         snprintf(buf, buflen, "%s", pl.bk->name);
         return AP_OK;
@@ -495,6 +511,12 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!weight || !packed) return fail(AP_ERR_INVALID, "null weight/packed pointer");
+    if (pl.small) {
+        hipError_t e = hipMemcpyAsync(packed, weight, (size_t)pl.packed_floats * sizeof(float), hipMemcpyDeviceToDevice,
+                                      (hipStream_t)stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "pack (copy) weights: %s", hipGetErrorString(e));
+        return AP_OK;
+    }
     if (pl.direct_cop) {
         PackDirectParams p;
         memset(&p, 0, sizeof(p));
@@ -556,6 +578,23 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
+    }
+    if (pl.small) {
+        SmallKParams p;
+        memset(&p, 0, sizeof(p));
+        p.src.data = d->src[0].data; p.src.mean = d->src[0].mean; p.src.rstd = d->src[0].rstd;
+        p.src.C = d->src[0].C; p.src.act = d->src[0].act;
+        p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = pl.Cin; p.Cout = d->Cout; p.OH = pl.Hout; p.OW = pl.Wout;
+        p.pad = d->pad; p.pad_mode = d->pad_mode;
+        p.y = y; p.w = packed; p.bias = bias; p.act = d->act;
+        p.stats = stat_partials; p.stat_tiles = pl.stat_tiles;
+        p.tiles_x = (pl.Wout + 31) / 32; p.tiles_y = (pl.Hout + 7) / 8;
+        const dim3 grid((unsigned)((long long)d->N * p.tiles_y * p.tiles_x));
+        if (d->stride == 1 && d->Cout == 8) hipLaunchKernelGGL((conv_small_f32<SmallCfg<1, 8>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (d->stride == 1) hipLaunchKernelGGL((conv_small_f32<SmallCfg<1, 16>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (d->Cout == 8) hipLaunchKernelGGL((conv_small_f32<SmallCfg<2, 8>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_small_f32<SmallCfg<2, 16>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("conv_small_f32");
     }
     if (pl.bf3) {
         if (!d->presplit)

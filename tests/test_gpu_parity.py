@@ -240,6 +240,10 @@ CONV_CASES = [
     ([10, 6], 3, 7, 1, 3, 'reflect', False, 70, 33),
     ([5], 2, 7, 1, 3, 'zero', False, 16, 130),
     ([12], 20, 3, 2, 1, 'zero', False, 37, 41),
+    ([1], 8, 3, 1, 1, 'zero', False, 40, 70),          # landmark encoder: narrow layers on the vector-ALU kernel
+    ([8], 16, 3, 2, 1, 'zero', False, 37, 41),
+    ([16], 16, 3, 2, 1, 'zero', False, 64, 64),
+    ([5], 8, 3, 1, 1, 'reflect', False, 9, 33),
     ([2], 64, 4, 2, 1, 'zero', False, 64, 64),
     ([24], 96, 4, 2, 1, 'zero', False, 30, 34),
     ([16], 48, 4, 1, 1, 'zero', False, 32, 32),
