@@ -35,15 +35,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // K_ > 0: dense K x K taps.  K_ == 0: NTAP_ (1, 2 or 4) taps at run-time offsets inside a 2 x 2 window (the
 // sub-pixel phases of a stride-2 transposed convolution); the count is a template parameter so that the tap
 // loop unrolls with compile-time register buffers.
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0>
+// ROW_ = 1: a 1 x K kernel (K horizontal taps).  The 7x7 stems (3 input channels) run this way: their input is
+// expanded to "row channels" (ky, c) -- 21 of 32 channels of a split tensor -- so that the 49 x 3 products of a
+// pixel become 2 channel chunks x 7 taps (ap_split_prepass_rows).
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0>
 struct Bf3Cfg {
-    static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_;
-    static constexpr int TMAX = K > 0 ? K * K : NTAP_;
+    static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_;
+    static constexpr int TMAX = K > 0 ? (ROW ? K : K * K) : NTAP_;
     static_assert(TMAX >= 1, "K == 0 needs a tap count");
     static constexpr int EXT = K > 0 ? K - 1 : 1;
+    static constexpr int EXTY = (K > 0 && ROW) ? 0 : EXT;
     static constexpr int TH = WPX * NT;
     static constexpr int CO_TILE = WCO * MT * 32;
-    static constexpr int IH = (TH - 1) * S + EXT + 1;
+    static constexpr int IH = (TH - 1) * S + EXTY + 1;
     static constexpr int IW = 31 * S + EXT + 1;
     static constexpr int PLANE = IH * IW;                          // pixels of the staged tile
     static constexpr int XP = (2 * PLANE + 63) / 64 * 64;          // slots per part: [kgroup][pixel], padded to whole DMA pieces
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
         const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
         int toff;
-        if constexpr (K > 0) toff = (t / K) * IW + (t % K);
+        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
         const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
         int toff;
-        if constexpr (K > 0) toff = (t / K) * IW + (t % K);
+        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
         if (r < 2 * MT) {
             const int m = r >> 1;
@@ -616,11 +620,69 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
     }
 }
 
+// ---- row expansion for the K x K stems with <= 4 input channels (Bf3Cfg ROW mode): the split tensor of the
+// 32-channel map  R[ky * C + c][y][x] = act(IN(x))[c][y + ky - pad][x]   (vertical zero / reflection padding applied
+// here, channels >= K * C zero); the horizontal taps and padding are the 1 x K convolution's.  One lane per pixel;
+// every (part, channel group) plane is written as consecutive 16-byte slots.  grid: (ceil(HW / 256), N)
+struct SplitRowsParams {
+    const float* x;
+    const float* mean;
+    const float* rstd;
+    int act;
+    int N, C, H, W, K, pad, pad_mode;
+    uint4* out;               // XS[n][part][4][HW + 1]
+};
+
+template <int K, int CIN>
+__global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p) {
+    static_assert(K * CIN <= 32, "row channels must fit two 16-channel chunks");
+    const int n = blockIdx.y, HW = p.H * p.W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 8)   // the all-zero slot closing each of the 2 x 4 planes
+        p.out[((long long)(n * 2 + (threadIdx.x >> 2)) * 4 + (threadIdx.x & 3)) * (HW + 1) + HW] = make_uint4(0u, 0u, 0u, 0u);
+    if (pix >= HW) return;
+    const int y = pix / p.W, x = pix - y * p.W;
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        int sy = y + ky - p.pad;
+        bool ok = true;
+        if (p.pad_mode == 1) sy = reflect_clamp(sy, p.H);
+        else ok = sy >= 0 && sy < p.H;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            float t = 0.f;
+            if (ok) {
+                t = p.x[((long long)n * CIN + c) * HW + sy * p.W + x];
+                if (p.mean != nullptr) t = (t - p.mean[n * CIN + c]) * p.rstd[n * CIN + c];
+                t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+            }
+            v[ky * CIN + c] = t;
+        }
+    }
+#pragma unroll
+    for (int cg = 0; cg < 4; ++cg) {
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 h, l;
+            split_bf16(v[cg * 8 + j], h, l);
+            hv[j] = h;
+            lv[j] = l;
+        }
+        *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * 4 + cg) * (HW + 1) + pix) = hv;
+        *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * 4 + cg) * (HW + 1) + pix) = lv;
+    }
+}
+
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16
 struct PackBf3Params {
     const float* w;
     unsigned short* out;
     int Cin, Cout, K, layout, flip;
+    int KH;                                             // 0: square K x K weights; 1: 1 x K
     int nseg, segC[kMaxSeg], chunk_begin[kMaxSeg];
     int CO_TILE, nchunks, co_tiles;
     int ntaps, tap_ky[kMaxTaps], tap_kx[kMaxTaps];      // source tap of packed tap t (already flipped if needed)
@@ -650,8 +712,9 @@ static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
             int cin = cs;
             for (int j = 0; j < s; ++j) cin += p.segC[j];
             const int ky = p.tap_ky[t], kx = p.tap_kx[t];
-            const long long off = p.layout == 0 ? (((long long)co * p.Cin + cin) * p.K + ky) * p.K + kx
-                                                : (((long long)cin * p.Cout + co) * p.K + ky) * p.K + kx;
+            const int KH = p.KH > 0 ? p.KH : p.K;                  // KH != K: a 1 x K row kernel
+            const long long off = p.layout == 0 ? (((long long)co * p.Cin + cin) * KH + ky) * p.K + kx
+                                                : (((long long)cin * p.Cout + co) * KH + ky) * p.K + kx;
             v = p.w[off];
         }
         __bf16 h, l;

@@ -48,7 +48,7 @@ static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
 
 // split-bf16 kernels (conv_bf16x3.h)
 struct Bf3Kernel {
-    int S, K, CO_TILE, TH, TMAX;
+    int S, K, CO_TILE, TH, TMAX, ROW;
     const void* fn;
     int (*wfloats)(int);
     size_t (*lds_bytes)(int);
@@ -56,7 +56,7 @@ struct Bf3Kernel {
 };
 template <class C>
 static Bf3Kernel bk(const char* name) {
-    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, reinterpret_cast<const void*>(&conv_bf16x3<C>),
+    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, C::ROW, reinterpret_cast<const void*>(&conv_bf16x3<C>),
                      &C::wfloats, &C::lds_bytes, name};
 }
 static const std::vector<Bf3Kernel>& bf3_registry() {
@@ -64,6 +64,7 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
         bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
         bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
         bk<Bf3Cfg<1, 4, 1, 1, 4, 4>>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
+        bk<Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>>("Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>"),   // 1x7 over row channels (7x7 stems)
         // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
@@ -112,10 +113,25 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     if (!d) return fail(AP_ERR_INVALID, "null descriptor");
     if (d->nsrc < 1 || d->nsrc > kMaxSeg) return fail(AP_ERR_INVALID, "nsrc=%d out of range", d->nsrc);
     if (d->N < 1 || d->H < 1 || d->W < 1 || d->Cout < 1) return fail(AP_ERR_INVALID, "bad dims");
-    if (d->KH != d->KW || d->KH < 1 || d->KH > 7) return fail(AP_ERR_UNSUPPORTED, "kernel %dx%d", d->KH, d->KW);
-    const int K = d->KH;
+    // 1 x 7 over the row channels of a 7x7 stem (ap_split_prepass_rows): split-bf16 path only
+    const bool rowk = d->KH == 1 && d->KW == 7;
+    if (rowk) {
+        if (d->transposed || d->stride != 1 || d->pad != 3 || d->nsrc != 1 || d->src[0].C != 32 ||
+            d->precision != AP_PRECISION_BF16X3 || d->w_layout != AP_W_OIHW || d->w_flip)
+            return fail(AP_ERR_UNSUPPORTED, "1x7 kernels exist only as the row form of a 7x7 stem (one 32-channel "
+                                            "split source, stride 1, pad 3, split-bf16 precision)");
+        if (d->pad_mode == AP_PAD_REFLECT && d->pad >= d->W) return fail(AP_ERR_INVALID, "reflection pad %d >= width", d->pad);
+    } else if (d->KH != d->KW || d->KH < 1 || d->KH > 7) {
+        return fail(AP_ERR_UNSUPPORTED, "kernel %dx%d", d->KH, d->KW);
+    }
+    const int K = d->KW;
     int S, KT;   // kernel family: stride and dense tap count (0 = run-time taps)
-    if (!d->transposed) {
+    if (rowk) {
+        S = 1;
+        KT = K;
+        pl.Hout = d->H;
+        pl.Wout = d->W;
+    } else if (!d->transposed) {
         if (d->stride != 1 && d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "stride %d", d->stride);
         S = d->stride;
         KT = K;
@@ -142,7 +158,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         if (d->src[s].C < minC) minC = d->src[s].C;
     }
     // 1..4 output channels, 7x7 'same' convolution: vector-ALU direct kernel (conv_direct.h)
-    if (!d->transposed && d->stride == 1 && K == 7 && d->pad == 3 && d->Cout <= 4 && !env_int("APAMD_NO_DIRECT", 0)) {
+    if (rowk) {
+        for (const auto& k : bf3_registry())
+            if (k.ROW && k.K == K) pl.bk = &k;
+        if (!pl.bk) return fail(AP_ERR_UNSUPPORTED, "no 1x%d row kernel", K);
+    }
+    if (!rowk && !d->transposed && d->stride == 1 && K == 7 && d->pad == 3 && d->Cout <= 4 && !env_int("APAMD_NO_DIRECT", 0)) {
         pl.direct_cop = d->Cout == 1 ? 1 : 4;
         const int ci = 4;
         pl.nchunks = 0;
@@ -156,7 +177,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         return AP_OK;
     }
     // narrow 3x3 layers (landmark encoder): memory streams, one lane per output pixel (conv_small.h)
-    if (!d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
+    if (!rowk && !d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
         d->w_layout == AP_W_OIHW && !d->w_flip && !env_int("APAMD_NO_SMALL", 0)) {
         pl.small = true;
         pl.nchunks = 1;
@@ -166,12 +187,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         return AP_OK;
     }
     // split-bf16 matrix path (conv_bf16x3.h): wide 3x3 / transposed layers when the caller allows ~1e-4 relative error
-    if (d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
+    if (!rowk && d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
         if (seg_ok && (KT == 0 || K == 3 || (K == 4 && S == 1)))
             for (const auto& k : bf3_registry())
-                if (k.S == S && k.K == KT) pl.bk = &k;
+                if (k.S == S && k.K == KT && !k.ROW) pl.bk = &k;
         if (KT == 0 && K != 3 && K != 4) pl.bk = nullptr;
     }
     if (pl.bk) {
@@ -236,7 +257,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     };
     if (!d->transposed) {
         Launch L;
-        for (int ky = 0; ky < K; ++ky)
+        for (int ky = 0; ky < (rowk ? 1 : K); ++ky)
             for (int kx = 0; kx < K; ++kx) {
                 Tap t;
                 t.ly = ky;
@@ -246,7 +267,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 L.taps.push_back(t);
             }
         L.OH = pl.Hout; L.OW = pl.Wout;
-        L.dy0 = -d->pad; L.dx0 = -d->pad;
+        L.dy0 = rowk ? 0 : -d->pad; L.dx0 = -d->pad;
         L.osy = L.osx = 1; L.oy_off = L.ox_off = 0;
         finish(L);
         pl.launches.push_back(L);
@@ -479,6 +500,29 @@ int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t t
     return check_launch("norm_split_kernel");
 }
 
+int ap_split_prepass_rows(const ap_src* src, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad, int32_t pad_mode,
+                          void* out, ap_stream_t stream) {
+    if (!src || !src->data || !out) return fail(AP_ERR_INVALID, "split_prepass_rows: null pointer");
+    if (K != 7 || pad != 3 || src->C < 1 || src->C > 4)
+        return fail(AP_ERR_UNSUPPORTED, "split_prepass_rows: built for 7x7 stems with 1..4 input channels (K=%d, C=%d)", K, src->C);
+    if (N < 1 || N > 65535 || H < 1 || W < 1) return fail(AP_ERR_INVALID, "split_prepass_rows: bad sizes");
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "split_prepass_rows: mean/rstd mismatch");
+    if (pad_mode == AP_PAD_REFLECT && pad >= H) return fail(AP_ERR_INVALID, "split_prepass_rows: reflection pad %d >= height", pad);
+    SplitRowsParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = src->data; p.mean = src->mean; p.rstd = src->rstd; p.act = src->act;
+    p.N = N; p.C = src->C; p.H = H; p.W = W; p.K = K; p.pad = pad; p.pad_mode = pad_mode;
+    p.out = reinterpret_cast<uint4*>(out);
+    const dim3 grid((H * W + 255) / 256, N);
+    switch (src->C) {
+        case 1: hipLaunchKernelGGL((split_rows_kernel<7, 1>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        case 2: hipLaunchKernelGGL((split_rows_kernel<7, 2>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        case 3: hipLaunchKernelGGL((split_rows_kernel<7, 3>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+        default: hipLaunchKernelGGL((split_rows_kernel<7, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
+    }
+    return check_launch("split_rows_kernel");
+}
+
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {
     if (!src || !out) return fail(AP_ERR_INVALID, "split_prepass: null pointer");
     return ap_norm_apply_split(src, nullptr, 0, 0.f, nullptr, nullptr, nullptr, N, H, W, nullptr, out, stream);
@@ -533,7 +577,8 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
             memset(&p, 0, sizeof(p));
             p.w = weight;
             p.out = reinterpret_cast<unsigned short*>(packed + L.wp_off);
-            p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KH; p.layout = d->w_layout; p.flip = 0;
+            p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KW; p.layout = d->w_layout; p.flip = 0;
+            p.KH = d->KH != d->KW ? d->KH : 0;
             p.nseg = d->nsrc;
             for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
             p.CO_TILE = pl.bk->CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;

@@ -72,7 +72,7 @@ class BaseModel(ABC):
         for name in self.loss_names:
             v = getattr(self, 'loss_' + name, None)
             if v is not None:
-                out[name] = float(v)
+                out[name] = float(v.detach()) if torch.is_tensor(v) else float(v)
         return out
 
     def save_networks(self, epoch):                                   # :144-163

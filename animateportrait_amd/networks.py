@@ -49,6 +49,8 @@ class ConvLayer(nn.Module):
         self._packed = None
         self._packed_key = None
         self._packed_dgrad = {}
+        self._rows_spec = None
+        self._packed_rows = None
 
     def packed_dgrad(self, seg, spec, w):
         """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
@@ -73,9 +75,28 @@ class ConvLayer(nn.Module):
         both deferred to the consumer."""
         if not isinstance(srcs, (list, tuple)):
             srcs = [srcs]
+        spec, packed = self.spec, None
+        if ops.stem_rows_eligible(spec) and not srcs[0].is_split_only:
+            # 7x7 stem on <= 4 channels: 1x7 split-bf16 convolution over the row expansion of the input
+            spec, packed = self.rows_spec(), self.packed_rows()
+            srcs = [ops.presplit_rows(srcs[0], self.spec.k, self.spec.pad, self.spec.pad_mode)]
+        if packed is None:
+            packed = self.packed()
         if norm_act is None:
-            return ops.conv2d(self.spec, srcs, self.packed(), self.bias.detach(), act=act)
-        return ops.conv2d(self.spec, srcs, self.packed(), None, want_stats=True, out_act=norm_act)
+            return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act)
+        return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act)
+
+    def rows_spec(self):
+        if self._rows_spec is None:
+            self._rows_spec = ops.stem_rows_spec(self.spec)
+        return self._rows_spec
+
+    def packed_rows(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        if self._packed_rows is None or self._packed_rows[0] != key:
+            self._packed_rows = (key, ops.pack_weights(self.rows_spec(), ops.stem_rows_weight(w.detach())))
+        return self._packed_rows[1]
 
 
 def _seq(**children):

@@ -51,12 +51,13 @@ class Feat:
     A convolution hands its InstanceNorm statistics over as per-tile partial sums (``pending``); they are
     finalised by whichever consumer comes first -- inside the fused norm/residual/split pass when that is the
     consumer (ap_norm_apply_split), by a standalone ap_instnorm_finalize when ``mean`` / ``rstd`` are read."""
-    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending')
+    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows')
 
     def __init__(self, data, mean=None, rstd=None, act=ACT_NONE, pending=None):
         self.data, self._mean, self._rstd, self.act = data, mean, rstd, act
         self.pending = pending   # (partials [N*C, tiles, 2], tiles) of the producing convolution, or None
         self.xs = None           # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
+        self.xs_rows = None      # {(k, pad, pad_mode): row expansion for k x k stems (ap_split_prepass_rows)}
 
     @property
     def shape(self):
@@ -118,11 +119,12 @@ class ConvSpec:
         self.transposed, self.output_padding = transposed, output_padding
         self.w_layout, self.w_flip = w_layout, w_flip
         self.precision = DEFAULT_PRECISION
+        self.kh = None            # 1: the 1 x k row form of a k x k stem (see stem_rows_spec)
 
     def desc(self, n, h, w, srcs=None, act=ACT_NONE):
         d = C.ApConvDesc()
         d.N, d.H, d.W, d.Cout = n, h, w, self.cout
-        d.KH = d.KW = self.k
+        d.KH, d.KW = (self.kh or self.k), self.k
         d.stride, d.pad, d.pad_mode = self.stride, self.pad, self.pad_mode
         d.transposed, d.output_padding = int(self.transposed), self.output_padding
         d.w_layout, d.w_flip, d.act = self.w_layout, int(self.w_flip), act
@@ -187,6 +189,58 @@ def presplit(f):
     if f.xs is None:
         _norm_apply_split(f, None, want_y=False, want_xs=True)
     return f.xs
+
+
+ROW_CHANNELS = 32   # channels of the row expansion (k * C <= 32)
+
+
+def stem_rows_eligible(spec):
+    """7x7 'same' stems with <= 4 input channels (networks.py:1218, 1231, 1244) run as a 1x7 split-bf16 convolution
+    over the row expansion of their input."""
+    return (spec.precision == PRECISION_BF16X3 and spec.k == 7 and spec.stride == 1 and spec.pad == 3 and
+            not spec.transposed and len(spec.cin_segments) == 1 and spec.cin_segments[0] <= 4 and spec.cout >= 32 and
+            spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_STEM_ROWS'))
+
+
+def stem_rows_spec(spec):
+    s = ConvSpec([ROW_CHANNELS], spec.cout, spec.k, 1, spec.pad, spec.pad_mode)
+    s.kh = 1
+    s.precision = PRECISION_BF16X3
+    s.alg_macs = spec.cin_segments[0] * spec.k * spec.k     # algorithmic MACs per output value (profiler accounting)
+    return s
+
+
+def stem_rows_weight(weight):
+    """W[co][c][ky][kx] -> W'[co][ky*C + c][0][kx], zero for the unused row channels."""
+    co, c, k, _ = weight.shape
+    w = weight.permute(0, 2, 1, 3).reshape(co, k * c, 1, k)
+    out = torch.zeros((co, ROW_CHANNELS, 1, k), dtype=weight.dtype, device=weight.device)
+    out[:, :k * c] = w
+    return out
+
+
+def presplit_rows(f, k, pad, pad_mode):
+    """Row expansion of a (virtual) stem input as a split-only 32-channel Feat; cached on the source, so the three
+    stems of the generator share one pass."""
+    key = (k, pad, pad_mode)
+    if f.xs_rows is None:
+        f.xs_rows = {}
+    hit = f.xs_rows.get(key)
+    if hit is None:
+        x = f.data
+        n, c, h, w = x.shape
+        _require_device(x, 'stem input')
+        s = C.ApSrc()
+        s.data, s.C, s.act = x.data_ptr(), c, f.act
+        if f.virtual:
+            s.mean, s.rstd = f.mean.data_ptr(), f.rstd.data_ptr()
+        nbytes = C.check(C.lib().ap_split_prepass_bytes(n, ROW_CHANNELS, h, w), 'split_prepass_bytes')
+        xs = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        C.check(C.lib().ap_split_prepass_rows(ctypes.byref(s), n, h, w, k, pad, pad_mode, _ptr(xs), _stream()),
+                'split_prepass_rows')
+        hit = Feat.split_only((n, ROW_CHANNELS, h, w), xs)
+        f.xs_rows[key] = hit
+    return hit
 
 
 def _alloc_xs(x):
@@ -291,8 +345,8 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
         e1.record()
         # algorithmic FLOPs = 2 * MACs of the dense operator (transposed: every input pixel x k*k taps)
         px = h * w if spec.transposed else ho.value * wo.value
-        PROFILER.records.append((buf.value.decode(), 2.0 * n * px * spec.cout * sum(spec.cin_segments) * spec.k ** 2,
-                                 e0, e1))
+        macs = getattr(spec, 'alg_macs', None) or sum(spec.cin_segments) * spec.k ** 2
+        PROFILER.records.append((buf.value.decode(), 2.0 * n * px * spec.cout * macs, e0, e1))
     if not want_stats:
         return Feat(y)
     return Feat(y, act=out_act, pending=(partial, tiles))

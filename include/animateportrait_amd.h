@@ -110,6 +110,13 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
 int32_t ap_conv2d_wants_presplit(const ap_conv_desc* d);
 int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W);
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream);
+/* 7x7 stems with 1..4 input channels (networks.py:1218, 1231, 1244: ReflectionPad2d(3) + Conv2d(input_nc, ., 7)) on
+ * the split-bf16 path: the input is expanded to 32 "row channels" R[ky*C + c][y][x] = src[c][y + ky - pad][x]
+ * (vertical padding applied here; `out`: ap_split_prepass_bytes(N, 32, H, W) bytes), and the stem becomes a 1 x 7
+ * convolution over them: ap_conv2d_* with KH = 1, KW = 7, pad 3, one 32-channel source, presplit = 1 and weights
+ * W'[co][ky*C + c][0][kx] = W[co][c][ky][kx] (zero for the unused channels).  One expansion serves all three stems. */
+int ap_split_prepass_rows(const ap_src* src, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad, int32_t pad_mode,
+                          void* out, ap_stream_t stream);
 /* The whole step between two convolutions in one streaming pass (ResnetBlock: networks.py:2329-2360):
  *     v = act(IN(src)) [+ IN(residual)]      y = v as fp32 (NULL: skip)      xs = split-bf16 copy of v (NULL: skip)
  * The InstanceNorm statistics of `src` come finished (src->mean / rstd) or -- stat_partials != NULL, src->mean NULL --

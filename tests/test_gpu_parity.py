@@ -289,7 +289,8 @@ def test_conv_sweep_vs_oracle(dev, case):
     y = layer.run(feats, act=ops.ACT_LRELU)
     scale = float(ref.abs().max())
     assert y.data.shape == ref.shape
-    assert linf(y.data, F.leaky_relu(ref, 0.2)) < 2e-5 * max(scale, 1.0)
+    tol = 5e-5 if ops.stem_rows_eligible(layer.spec) else 2e-5       # 7x7 stems run on the split-bf16 path
+    assert linf(y.data, F.leaky_relu(ref, 0.2)) < tol * max(scale, 1.0)
     # statistics epilogue: IN of the bias-free output
     yn = layer.run(feats, norm_act=ops.ACT_NONE)
     refn = F.instance_norm(ref)
@@ -519,6 +520,45 @@ def test_conv_bf16x3_vs_oracle(dev, case):
         assert linf(got, refn) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
     assert errs[ops.PRECISION_FP32] < 2e-6
     assert errs[ops.PRECISION_BF16X3] < 5e-5, errs     # ~2^-17 per product, averaged down by the K-sum
+
+
+@pytest.mark.parametrize('case', [
+    # cin, cout, mode, H, W
+    (3, 64, 'reflect', 40, 40),
+    (3, 32, 'reflect', 33, 70),
+    (1, 48, 'zero', 16, 130),
+    (4, 100, 'reflect', 21, 37),
+])
+def test_stem7x7_rows_bf16x3(dev, case):
+    """7x7 stems (ReflectionPad2d(3) + Conv2d(input_nc, ., 7), networks.py:1218) as a 1x7 split-bf16 convolution over
+    the row expansion of the input: fp32-class result, same statistics epilogue; the exact-fp32 kernel beside it."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    cin, cout, mode, H, W = case
+    g = torch.Generator().manual_seed(sum(map(ord, str(case))))
+    n = 2
+    x = torch.randn(n, cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(cout, cin, 7, 7, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    xd = x.double()
+    ref = (F.conv2d(F.pad(xd, (3,) * 4, mode='reflect'), w.double(), b.double()) if mode == 'reflect'
+           else F.conv2d(xd, w.double(), b.double(), padding=3))
+    scale = float(ref.abs().max())
+    for prec, tol in ((ops.PRECISION_BF16X3, 5e-5), (ops.PRECISION_FP32, 2e-6)):
+        layer = ConvLayer([cin], cout, 7, 1, 3, ops.PAD_REFLECT if mode == 'reflect' else ops.PAD_ZERO).to(dev)
+        layer.spec.precision = prec
+        with torch.no_grad():
+            layer.weight.copy_(w); layer.bias.copy_(b)
+        assert ops.stem_rows_eligible(layer.spec) == (prec == ops.PRECISION_BF16X3)
+        src = ops.Feat(x.to(dev))
+        y = layer.run(src, act=ops.ACT_NONE)
+        assert y.data.shape == ref.shape
+        assert linf(y.data, ref) / scale < tol, (prec, linf(y.data, ref) / scale)
+        yn = layer.run(src, norm_act=ops.ACT_RELU)
+        got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
+        assert linf(got, F.instance_norm(ref.float())) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
+        if prec == ops.PRECISION_BF16X3:
+            assert len(src.xs_rows) == 1          # one expansion shared by both runs
 
 
 @pytest.mark.parametrize('blocks', [1, 7, 24])
