@@ -195,6 +195,29 @@ __global__ __launch_bounds__(256, C::NA <= 20 ? 2 : 1) void wgrad_igemm_f32(cons
 
 // dW[i] = sum_s partial[s][i]   (fixed order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, long long n, float* __restrict__ dw) {
+    if ((n & 3) == 0) {
+        // 16-byte lanes, four partial buffers in flight per step (the sum order k = 0, 1, 2, ... is unchanged)
+        const long long n4 = n >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(partial);
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= P; k += 4) {
+                const float4 a = p4[(long long)k * n4 + i], b = p4[(long long)(k + 1) * n4 + i];
+                const float4 c = p4[(long long)(k + 2) * n4 + i], d = p4[(long long)(k + 3) * n4 + i];
+                s.x = (((s.x + a.x) + b.x) + c.x) + d.x;
+                s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+                s.z = (((s.z + a.z) + b.z) + c.z) + d.z;
+                s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+            }
+            for (; k < P; ++k) {
+                const float4 a = p4[(long long)k * n4 + i];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            reinterpret_cast<float4*>(dw)[i] = s;
+        }
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < P; ++k) s += partial[(long long)k * n + i];
