@@ -66,6 +66,22 @@ __global__ __launch_bounds__(256) void instnorm_bwd_reduce_kernel(const float* _
     const float* yp = y + (long long)nc * HW;
     const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
     float s1 = 0.f, s2 = 0.f;
+    if (p1 == 0 && (HW & 3) == 0) {
+        // unfolded gradient: 16-byte lanes (same per-thread summation order is not required: block_sum is a tree)
+        const float4* y4 = reinterpret_cast<const float4*>(yp);
+        const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
+        const float4* gb = g2p ? reinterpret_cast<const float4*>(g2p) : nullptr;
+        for (int i = threadIdx.x; i < HW / 4; i += 256) {
+            const float4 yv = y4[i];
+            float4 gv = ga[i];
+            if (gb) { const float4 t = gb[i]; gv.x += t.x; gv.y += t.y; gv.z += t.z; gv.w += t.w; }
+            const float xh0 = (yv.x - m) * r, xh1 = (yv.y - m) * r, xh2 = (yv.z - m) * r, xh3 = (yv.w - m) * r;
+            const float a0 = gv.x * act_grad_from_xhat(xh0, act), a1 = gv.y * act_grad_from_xhat(xh1, act);
+            const float a2 = gv.z * act_grad_from_xhat(xh2, act), a3 = gv.w * act_grad_from_xhat(xh3, act);
+            s1 += (a0 + a1) + (a2 + a3);
+            s2 += (a0 * xh0 + a1 * xh1) + (a2 * xh2 + a3 * xh3);
+        }
+    } else
     for (int i = threadIdx.x; i < HW; i += 256) {
         const int yy = i / W, xx = i - yy * W;
         const float xh = (yp[i] - m) * r;
@@ -100,6 +116,24 @@ __global__ __launch_bounds__(256) void instnorm_bwd_apply_kernel(const float* __
     const float* yp = y + (long long)nc * HW;
     const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
     float* out = dy + (long long)nc * HW;
+    if (p1 == 0 && (HW & 3) == 0) {
+        const float4* y4 = reinterpret_cast<const float4*>(yp);
+        const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
+        const float4* gb = g2p ? reinterpret_cast<const float4*>(g2p) : nullptr;
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+            const float4 yv = y4[i];
+            float4 gv = ga[i];
+            if (gb) { const float4 t = gb[i]; gv.x += t.x; gv.y += t.y; gv.z += t.z; gv.w += t.w; }
+            float4 o;
+            float xh = (yv.x - m) * r; o.x = r * (gv.x * act_grad_from_xhat(xh, act) - a1 - xh * a2);
+            xh = (yv.y - m) * r; o.y = r * (gv.y * act_grad_from_xhat(xh, act) - a1 - xh * a2);
+            xh = (yv.z - m) * r; o.z = r * (gv.z * act_grad_from_xhat(xh, act) - a1 - xh * a2);
+            xh = (yv.w - m) * r; o.w = r * (gv.w * act_grad_from_xhat(xh, act) - a1 - xh * a2);
+            o4[i] = o;
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const int yy = i / W, xx = i - yy * W;
         const float xh = (yp[i] - m) * r;
@@ -120,6 +154,30 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     const float* op = outv ? outv + (long long)nc * HW : nullptr;
     const float* g2p = g2 ? g2 + (long long)nc * HW : nullptr;
     float* out = dy + (long long)nc * HW;
+    if (p1 == 0 && (HW & 3) == 0) {
+        const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
+        const float4* gb = g2p ? reinterpret_cast<const float4*>(g2p) : nullptr;
+        const float4* o4 = op ? reinterpret_cast<const float4*>(op) : nullptr;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < HW / 4; i += gridDim.x * 256) {
+            float4 gv = ga[i];
+            if (gb) { const float4 t = gb[i]; gv.x += t.x; gv.y += t.y; gv.z += t.z; gv.w += t.w; }
+            if (act != 0) {
+                const float4 ov = o4[i];
+                if (act == 1) {
+                    gv.x = ov.x > 0.f ? gv.x : 0.f; gv.y = ov.y > 0.f ? gv.y : 0.f;
+                    gv.z = ov.z > 0.f ? gv.z : 0.f; gv.w = ov.w > 0.f ? gv.w : 0.f;
+                } else if (act == 2) {
+                    gv.x = ov.x > 0.f ? gv.x : 0.2f * gv.x; gv.y = ov.y > 0.f ? gv.y : 0.2f * gv.y;
+                    gv.z = ov.z > 0.f ? gv.z : 0.2f * gv.z; gv.w = ov.w > 0.f ? gv.w : 0.2f * gv.w;
+                } else if (act == 3) {
+                    gv.x *= 1.f - ov.x * ov.x; gv.y *= 1.f - ov.y * ov.y;
+                    gv.z *= 1.f - ov.z * ov.z; gv.w *= 1.f - ov.w * ov.w;
+                }
+            }
+            reinterpret_cast<float4*>(out)[i] = gv;
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
         const int yy = i / W, xx = i - yy * W;
         float g = fr.at(yy, xx);
