@@ -414,9 +414,80 @@ __global__ __launch_bounds__(256) void warp_concat_bwd_tiled_kernel(const float*
     }
 }
 
+// ---- image-level helpers of the streaming-inference model (geomcgt_ifw_test_model.py:282-285, 294):
+// F.interpolate(mode='bilinear', align_corners=False) and F.grid_sample(bilinear, zeros padding).
+// grid: (ceil(OH*OW/256), N*C)
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                              int W, int OH, int OW) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= OH * OW) return;
+    const int oy = pix / OW, ox = pix - oy * OW;
+    const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;      // area_pixel_compute_scale
+    float fy = sh * ((float)oy + 0.5f) - 0.5f, fx = sw * ((float)ox + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    fx = fx < 0.f ? 0.f : fx;
+    int y0 = (int)fy, x0 = (int)fx;
+    y0 = y0 > H - 1 ? H - 1 : y0;
+    x0 = x0 > W - 1 ? W - 1 : x0;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, lx1 = fx - (float)x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    const float* p = x + (long long)blockIdx.y * H * W;
+    y[(long long)blockIdx.y * OH * OW + pix] =
+        ly0 * (lx0 * p[y0 * W + x0] + lx1 * p[y0 * W + x1]) + ly1 * (lx0 * p[y1 * W + x0] + lx1 * p[y1 * W + x1]);
+}
+
+// grid: (ceil(OH*OW/256), C, N); sampling grid (N, OH, OW, 2) in [-1, 1]
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ x, const float* __restrict__ grid,
+                                                          float* __restrict__ y, int C, int H, int W, int OH, int OW,
+                                                          int align_corners) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= OH * OW) return;
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float2 g = reinterpret_cast<const float2*>(grid)[(long long)n * OH * OW + pix];
+    float ix, iy;
+    if (align_corners) {
+        ix = (g.x + 1.f) / 2.f * (float)(W - 1);
+        iy = (g.y + 1.f) / 2.f * (float)(H - 1);
+    } else {
+        ix = ((g.x + 1.f) * (float)W - 1.f) / 2.f;
+        iy = ((g.y + 1.f) * (float)H - 1.f) / 2.f;
+    }
+    ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
+    iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float ex = fx + 1.f, ey = fy + 1.f;
+    const float* p = x + ((long long)n * C + c) * H * W;
+    auto at = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? p[yy * W + xx] : 0.f; };
+    float v = at(y0, x0) * ((ex - ix) * (ey - iy));
+    v += at(y0, x1) * ((ix - fx) * (ey - iy));
+    v += at(y1, x0) * ((ex - ix) * (iy - fy));
+    v += at(y1, x1) * ((ix - fx) * (iy - fy));
+    y[((long long)n * C + c) * OH * OW + pix] = v;
+}
+
 }  // namespace apamd
 
 using namespace apamd;
+
+extern "C" int ap_resize_bilinear(const float* x, int32_t NC, int32_t H, int32_t W, int32_t OH, int32_t OW, float* y,
+                                  ap_stream_t stream) {
+    if (!x || !y) return fail(AP_ERR_INVALID, "resize_bilinear: null pointer");
+    if (NC < 1 || NC > 65535 || H < 1 || W < 1 || OH < 1 || OW < 1) return fail(AP_ERR_INVALID, "resize_bilinear: bad sizes");
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((OH * OW + 255) / 256, NC), dim3(256), 0, (hipStream_t)stream, x, y, H,
+                       W, OH, OW);
+    return check_launch("resize_bilinear_kernel");
+}
+
+extern "C" int ap_grid_sample(const float* x, const float* grid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t OH,
+                              int32_t OW, int32_t align_corners, float* y, ap_stream_t stream) {
+    if (!x || !grid || !y) return fail(AP_ERR_INVALID, "grid_sample: null pointer");
+    if (N < 1 || N > 65535 || C < 1 || C > 65535 || H < 1 || W < 1 || OH < 1 || OW < 1)
+        return fail(AP_ERR_INVALID, "grid_sample: bad sizes");
+    hipLaunchKernelGGL(grid_sample_kernel, dim3((OH * OW + 255) / 256, C, N), dim3(256), 0, (hipStream_t)stream, x, grid,
+                       y, C, H, W, OH, OW, align_corners);
+    return check_launch("grid_sample_kernel");
+}
 
 extern "C" int ap_warp_concat_bwd(const float* gout, const float* motion, const float* flow, const float* ifmask,
                                   float* dx, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale,

@@ -21,10 +21,10 @@ from .autograd import (conv_forward, materialize_forward, warp_forward, batch_sp
 from .ops import (Feat, ConvSpec, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT,
                   W_OIHW, W_IOHW)
 
-GENERATOR_NAMES = ('resnet_9blocks_rcatland32_full_ifw',)
+GENERATOR_NAMES = ('resnet_9blocks_rcatland32_full_ifw', 'resnet_style2_9blocks')
 # names the reference registry knows (networks.py:152-199) but that are outside this build's hot path
 _REFERENCE_ONLY_G = (
-    'resnet_9blocks', 'resnet_style2_9blocks', 'resnet_9blocks_rcatland', 'resnet_9blocks_rcatland3',
+    'resnet_9blocks', 'resnet_9blocks_rcatland', 'resnet_9blocks_rcatland3',
     'resnet_9blocks_rcatland32', 'resnet_10blocks_rcatland32', 'resnet_9blocks_rcatland4',
     'resnet_9blocks_rcatland32_fw', 'resnet_9blocks_rcatland32_fw2', 'resnet_9blocks_rcatland32_ifw',
     'resnet_9blocks_rcatland32_ifw_single2', 'resnet_9blocks_rcatland32_full_ifw_colorcoded',
@@ -225,6 +225,54 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         return cf(tape, self.model3['7'], x, act=ACT_TANH)
 
 
+class ResnetStyle2Generator(nn.Module):
+    """networks.py:573-637 (``resnet_style2_9blocks``): the static drawing generator of the streaming-inference
+    model (geomcgt_ifw_test_model.py:225-227, 280-285).  Same ``state_dict`` keys as the reference
+    (``model0.{1,4,7}``, ``model.0``, ``model.{3..11}.conv_block.{1,5}``, ``model.{12,15,19}``).  The reference keeps it
+    frozen (``.eval()``, loaded from ``checkpoints/static/drawing.pth``), so only the forward pass is built."""
+
+    def __init__(self, input_nc, output_nc, ngf=64, norm='instance', use_dropout=False, n_blocks=6,
+                 padding_type='reflect', extra_channel=3, model0_res=0):
+        super().__init__()
+        if norm != 'instance':
+            raise NotImplementedError('normalization layer [%s] is not available on the HIP path' % norm)
+        if use_dropout:
+            raise NotImplementedError('dropout is not available on the HIP path')
+        if padding_type != 'reflect':
+            raise NotImplementedError('padding [%s] is not implemented' % padding_type)
+        if model0_res != 0:
+            raise NotImplementedError('model0_res != 0 is not used by any shipped configuration')
+        assert n_blocks >= 0
+        self.n_blocks = n_blocks
+        dim = ngf * 4
+        self.model0 = _seq(_1=ConvLayer([input_nc], ngf, 7, 1, 3, PAD_REFLECT),
+                           _4=ConvLayer([ngf], ngf * 2, 3, 2, 1), _7=ConvLayer([ngf * 2], dim, 3, 2, 1))
+        layers = {'0': ConvLayer([dim, extra_channel], dim, 3, 1, 1)}
+        for i in range(n_blocks):
+            layers[str(3 + i)] = ResnetBlock(dim)
+        j = 3 + n_blocks
+        layers[str(j)] = ConvLayer([dim], dim // 2, 3, 2, 1, transposed=True, output_padding=1)
+        layers[str(j + 3)] = ConvLayer([dim // 2], dim // 4, 3, 2, 1, transposed=True, output_padding=1)
+        layers[str(j + 7)] = ConvLayer([ngf], output_nc, 7, 1, 3, PAD_REFLECT)
+        self.model = nn.ModuleDict(layers)
+
+    def forward(self, input1, input2):
+        """G(input1, input2) -> (B, output_nc, S, S): f1 = model0(input1); model(cat[f1, input2]) (networks.py:632)."""
+        with torch.no_grad():
+            cf = conv_forward
+            x = cf(None, self.model0['1'], Feat(input1.contiguous()), norm_act=ACT_RELU)
+            x = cf(None, self.model0['4'], x, norm_act=ACT_RELU)
+            x = cf(None, self.model0['7'], x, norm_act=ACT_RELU)
+            x = cf(None, self.model['0'], [x, Feat(input2.contiguous())], norm_act=ACT_RELU)
+            x = materialize_forward(None, x)
+            for i in range(self.n_blocks):
+                x = self.model[str(3 + i)].run(x, None)
+            j = 3 + self.n_blocks
+            x = cf(None, self.model[str(j)], x, norm_act=ACT_RELU)
+            x = cf(None, self.model[str(j + 3)], x, norm_act=ACT_RELU)
+            return cf(None, self.model[str(j + 7)], x, act=ACT_TANH).data
+
+
 class NLayerDiscriminator(nn.Module):
     """70x70 PatchGAN, networks.py:2602-2647 (n_layers=3, instance norm)."""
 
@@ -321,6 +369,9 @@ def define_G(input_nc, output_nc, ngf, netG, norm='batch', use_dropout=False, in
     if netG == 'resnet_9blocks_rcatland32_full_ifw':
         net = ResnetConditionTriGenerator32_full_ifw(input_nc, output_nc, ngf, norm=norm, use_dropout=use_dropout,
                                                      n_blocks=9, div=div, disp=disp)
+    elif netG == 'resnet_style2_9blocks':                                   # networks.py:155-156
+        net = ResnetStyle2Generator(input_nc, output_nc, ngf, norm=norm, use_dropout=use_dropout, n_blocks=9,
+                                    model0_res=model0_res, extra_channel=extra_channel)
     elif netG in _REFERENCE_ONLY_G:
         raise NotImplementedError('Generator model name [%s] is outside the MI355X hot path '
                                   '(only %s is built)' % (netG, ', '.join(GENERATOR_NAMES)))

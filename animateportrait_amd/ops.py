@@ -410,6 +410,30 @@ def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True):
     return res
 
 
+def resize_bilinear(x, size):
+    """F.interpolate(x, size, mode='bilinear', align_corners=False) (geomcgt_ifw_test_model.py:283, 285)."""
+    _require_device(x, 'resize input')
+    n, c, h, w = x.shape
+    oh, ow = size
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    C.check(C.lib().ap_resize_bilinear(_ptr(x), n * c, h, w, oh, ow, _ptr(y), _stream()), 'resize_bilinear')
+    return y
+
+
+def grid_sample(x, grid, align_corners=False):
+    """F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=...) (geomcgt_ifw_test_model.py:294)."""
+    _require_device(x, 'grid_sample input')
+    _require_device(grid, 'grid_sample grid')
+    n, c, h, w = x.shape
+    if grid.dim() != 4 or grid.shape[0] != n or grid.shape[3] != 2:
+        raise ValueError('grid_sample: grid of shape %s for input %s' % (tuple(grid.shape), tuple(x.shape)))
+    oh, ow = grid.shape[1], grid.shape[2]
+    y = torch.empty((n, c, oh, ow), dtype=torch.float32, device=x.device)
+    C.check(C.lib().ap_grid_sample(_ptr(x), _ptr(grid), n, c, h, w, oh, ow, int(bool(align_corners)), _ptr(y), _stream()),
+            'grid_sample')
+    return y
+
+
 # =============================================================================== backward ops
 def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,

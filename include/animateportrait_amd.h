@@ -153,6 +153,13 @@ int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd,
                        const float* motion, const float* flow, const float* ifmask,
                        float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                        float flow_scale, ap_stream_t stream);
+/* Image-level helpers of the streaming-inference model (geomcgt_ifw_test_model.py:282-285, 294):
+ * y = F.interpolate(x, (OH, OW), mode='bilinear', align_corners=False) over NC planes, and
+ * y = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=...) with grid (N, OH, OW, 2). */
+int ap_resize_bilinear(const float* x, int32_t NC, int32_t H, int32_t W, int32_t OH, int32_t OW, float* y,
+                       ap_stream_t stream);
+int ap_grid_sample(const float* x, const float* grid, int32_t N, int32_t C, int32_t H, int32_t W, int32_t OH, int32_t OW,
+                   int32_t align_corners, float* y, ap_stream_t stream);
 /* Same operator with both outputs optional: out (fp32 [N, 2C, H, W]) and / or xs, the split-bf16 copy of that
  * tensor (ap_split_prepass layout, ap_split_prepass_bytes(N, 2C, H, W) bytes; needs C % 8 == 0) that the next
  * split-bf16 convolution stages -- an inference pass then never writes or re-reads the fp32 concat. */

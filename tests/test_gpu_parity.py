@@ -215,6 +215,95 @@ def test_generator_ngf64_headline_tolerance(dev, golden):
     assert torch.equal(y1, y[:1]), 'samples must be independent (InstanceNorm): B=1 == B=2[0] bitwise'
 
 
+def test_static_generator(dev, golden):
+    """resnet_style2_9blocks (networks.py:573-637) on the HIP path against the reference's
+    outputs; cat[f1, style] is a two-segment source of model.0, never a tensor."""
+    from animateportrait_amd import networks as N
+    from oracle import generator as og, static_generator as osg
+    gd = golden('static_gen.npz')
+    for tag, ngf, tol in (('ngf8', 8, 1e-4), ('ngf64', 64, 1e-3)):
+        size = int(gd['size_' + tag])
+        x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(int(gd['seed_' + tag]))) * 2 - 1
+        sd = og.init_params(osg.static_param_shapes(3, 1, ngf), seed=4321)
+        assert sd_sha(sd) == str(gd['weights_sha256_' + tag])
+        G = N.define_G(3, 1, ngf, 'resnet_style2_9blocks', 'instance', use_dropout=False, gpu_ids=[0])
+        G.load_state_dict(sd, strict=True)
+        style = osg.style_code(2, size // 4).to(dev)
+        y = G(x.to(dev), style)
+        y1 = G(x[:1].to(dev), style[:1])
+        err = linf(y, gd['y_' + tag])
+        print('static generator %s L-inf vs reference: %.3e' % (tag, err))
+        assert y.shape == (2, 1, size, size) and err < tol
+        assert torch.equal(y1, y[:1])
+
+
+def test_resize_and_grid_sample(dev):
+    """ap_resize_bilinear / ap_grid_sample == F.interpolate(bilinear, align_corners=False) / F.grid_sample(bilinear,
+    zeros), the image-level ops of geomcgt_ifw_test_model.py:282-285, 294."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 3, 37, 53, generator=g)
+    for size in ((74, 106), (512, 512), (19, 26), (37, 53), (40, 20)):
+        ref = F.interpolate(x, size=size, mode='bilinear', align_corners=False)
+        assert linf(ops.resize_bilinear(x.to(dev), size), ref) < 1e-5, size     # fp32 source-index rounding
+    grid = torch.rand(2, 29, 31, 2, generator=g) * 2.4 - 1.2           # some samples fall outside
+    for ac in (True, False):
+        ref = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=ac)
+        assert linf(ops.grid_sample(x.to(dev), grid.to(dev), align_corners=ac), ref) < 2e-5, ac   # fp32 coordinates
+
+
+def test_streaming_inference_model(dev):
+    """GeomCGTIFWTestModel (geomcgt_ifw_test_model.py:254-302, 'drawing' branch): masked photo -> hot-path generator,
+    static drawing at 512^2 (cached per photo), mask warped by the motion grid, blend -- against the oracle
+    composition with the same seeded weights."""
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.synthetic import make_generator_inputs
+    from oracle import generator as og, static_generator as osg
+    import contextlib
+    import io
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw',
+                               '--dataset_mode', 'synthetic', '--name', 'drawing_test', '--output_nc', '1', '--ngf', '8',
+                               '--netg_resb_div', '3', '--netg_resb_disp', '3', '--gpu_ids', '0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    sd_g = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=1234)
+    sd_s = og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321)
+    model.netG_A.load_state_dict(sd_g, strict=True)
+    model.net_staticG.load_state_dict(sd_s, strict=True)
+    n = 2
+    d = make_generator_inputs(n, seed=21)
+    gen = torch.Generator().manual_seed(5)
+    yy, xx = torch.meshgrid(torch.arange(256.), torch.arange(256.), indexing='ij')
+    matte = ((((yy - 128) / 90) ** 2 + ((xx - 120) / 70) ** 2) < 1).float().view(1, 1, 256, 256).repeat(n, 1, 1, 1)
+    matte = (matte * 0.9 + torch.rand(n, 1, 256, 256, generator=gen) * 0.05).contiguous()
+    batch = {'A': d['input'], 'warp_motion': d['motion'], 'A_lm': d['land1'], 'tB_lm': d['land2'],
+             'iw_flow': d['flow'], 'if_mask': d['ifmask'], 'matte': matte}
+    model.set_input(batch)
+    model.test()
+    with torch.no_grad():
+        static = osg.static_drawing(sd_s, d['input'])
+        fake, fore, mask1, masked = osg.streaming_forward(
+            lambda *a: og.generator_forward(sd_g, *a, div=3, disp=3), d['input'], matte, static, d['land1'], d['land2'],
+            d['motion'], d['flow'], d['ifmask'])
+    assert linf(model.fakeB_static, static) < 1e-3
+    assert linf(model.real_A, masked) < 1e-6
+    assert linf(model.mask1, mask1) < 1e-5
+    assert linf(model.fake_B_fore, fore) < 1e-3
+    assert linf(model.fake_B, fake) < 1e-3
+    # the static drawing is cached per photo: the next frame of the same clip (same photo tensor) does not recompute it
+    calls = []
+    orig = model.net_staticG.forward
+    model.net_staticG.forward = lambda *a: (calls.append(1), orig(*a))[1]
+    model.set_input(batch)
+    model.test()
+    assert not calls and linf(model.fake_B, fake) < 1e-3
+    batch2 = dict(batch, A=batch['A'].clone())
+    model.set_input(batch2)
+    model.test()
+    assert len(calls) == 1
+
+
 def test_patchgan(dev, golden):
     from animateportrait_amd import networks as N
     from oracle import generator as og, discriminator as od

@@ -61,6 +61,10 @@ def test_state_dict_keys_match_reference_layout():
         assert blocks2 == ([2, 5, 8] if disp == 1 else [0, 3, 6])
     G = N.define_G(3, 1, 64, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [], div=3, disp=3)
     assert sum(p.numel() for p in G.parameters()) == 15925553
+    from oracle import static_generator as osg
+    for ngf in (8, 64):
+        S = N.define_G(3, 1, ngf, 'resnet_style2_9blocks', 'instance', use_dropout=False, gpu_ids=[])
+        assert [(k, tuple(v.shape)) for k, v in S.state_dict().items()] == osg.static_param_shapes(3, 1, ngf)
     for cin, n in ((1, 2762689), (2, 2763713)):
         D = N.define_D(cin, 64, 'basic', 3, 'instance', 'normal', 0.02, [])
         assert [(k, tuple(v.shape)) for k, v in D.state_dict().items()] == od.patchgan_param_shapes(cin, 64)

@@ -114,6 +114,21 @@ def test_generator_ngf64(golden):
     assert linf(y, gd['y']) < 1e-4
 
 
+def test_static_generator(golden):
+    """ResnetStyle2Generator (networks.py:573-637) against the outputs of the reference's own
+    class (tests/golden/make_static_golden.py)."""
+    from oracle import static_generator as osg
+    gd = golden('static_gen.npz')
+    for tag, ngf in (('ngf8', 8), ('ngf64', 64)):
+        size = int(gd['size_' + tag])
+        x = torch.rand(2, 3, size, size, generator=torch.Generator().manual_seed(int(gd['seed_' + tag]))) * 2 - 1
+        sd = og.init_params(osg.static_param_shapes(3, 1, ngf), seed=4321)
+        assert sd_sha(sd) == str(gd['weights_sha256_' + tag])
+        with torch.no_grad():
+            y = osg.static_forward(sd, x, osg.style_code(2, size // 4))
+        assert linf(y, gd['y_' + tag]) < 1e-5
+
+
 def test_patchgan(golden):
     gd = golden('patchgan.npz')
     for cin in (1, 2):
