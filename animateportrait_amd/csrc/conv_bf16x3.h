@@ -57,7 +57,10 @@ struct Bf3Cfg {
     static constexpr int EPI_FLOATS = 4 * 32 * 36 + WPX * CO_TILE * 2;  // epilogue patches + statistics
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(CO_TILE % 16 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
-    static_assert(EPI_FLOATS * 4 <= X_SLOTS * 16, "the epilogue patches live in one activation stage buffer");
+    // the epilogue patches live in the (free) stage buffer of the tile's last chunk: its activation image, or --
+    // small pixel tiles -- its weight image
+    static constexpr bool EPI_IN_W = EPI_FLOATS * 4 > X_SLOTS * 16;
+    static_assert(!EPI_IN_W || EPI_FLOATS * 4 <= 2 * TMAX * 2 * CO_TILE * 16, "epilogue patches do not fit a stage buffer");
     static_assert(IH < 128 && IW < 256, "piece geometry is packed into 15 bits");
     static int wfloats(int ntaps) { return w_slots(ntaps) * 4; }   // floats per (cout tile, chunk) weight block
     static size_t lds_bytes(int ntaps) { return (size_t)2 * (X_SLOTS + w_slots(ntaps)) * 16; }   // two stages
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             // pixels of one cout row: 16-byte global stores (the dword-per-lane form is store-issue bound) and a
             // 3-step row reduction for the InstanceNorm statistics instead of a 5-step one per accumulator register.
             constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
-            float* const epi = reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
+            float* const epi = C::EPI_IN_W ? reinterpret_cast<float*>(wbuf + pl * W_SLOTS)
+                                           : reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
             float* const patch = epi + wave * (32 * TS);
             float* const sred = epi + 4 * 32 * TS;                             // [WPX][CO_TILE][2]
             const int n = cur.n, cot = cur.cot;

@@ -61,6 +61,7 @@ static Bf3Kernel bk(const char* name) {
 }
 static const std::vector<Bf3Kernel>& bf3_registry() {
     static std::vector<Bf3Kernel> v = {
+        bk<Bf3Cfg<1, 3, 1, 2, 4, 1>>("Bf3Cfg<1, 3, 1, 2, 4, 1>"),      // 3x3 s1, small batches: 64 couts x 4 rows
         bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
         bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
         bk<Bf3Cfg<1, 4, 1, 1, 4, 4>>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
@@ -108,6 +109,8 @@ static int env_int(const char* name, int dflt) {
     const char* s = getenv(name);
     return s ? atoi(s) : dflt;
 }
+
+static int num_cus();
 
 static int make_plan(const ap_conv_desc* d, Plan& pl) {
     if (!d) return fail(AP_ERR_INVALID, "null descriptor");
@@ -190,9 +193,23 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     if (!rowk && d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
-        if (seg_ok && (KT == 0 || K == 3 || (K == 4 && S == 1)))
+        if (seg_ok && (KT == 0 || K == 3 || (K == 4 && S == 1))) {
+            // several tile heights of a family: the tallest one (best operand reuse) unless its tile list leaves
+            // most CUs idle (streaming inference at batch 1..4), then the shortest
+            const Bf3Kernel* tall = nullptr;
+            const Bf3Kernel* small = nullptr;
             for (const auto& k : bf3_registry())
-                if (k.S == S && k.K == KT && !k.ROW) pl.bk = &k;
+                if (k.S == S && k.K == KT && !k.ROW) {
+                    if (!tall || k.TH >= tall->TH) tall = &k;
+                    if (!small || k.TH < small->TH) small = &k;
+                }
+            pl.bk = tall;
+            if (tall && small != tall && KT != 0) {
+                const long long tiles = (long long)d->N * ((pl.Hout + tall->TH - 1) / tall->TH) * ((pl.Wout + 31) / 32) *
+                                        ((d->Cout + tall->CO_TILE - 1) / tall->CO_TILE);
+                if (tiles * 2 <= num_cus() && !env_int("APAMD_NO_SMALL_TILES", 0)) pl.bk = small;
+            }
+        }
         if (KT == 0 && K != 3 && K != 4) pl.bk = nullptr;
     }
     if (pl.bk) {

@@ -569,12 +569,15 @@ BF3_CASES = [
 ]
 
 
+@pytest.mark.parametrize('tall', [0, 1])
 @pytest.mark.parametrize('case', BF3_CASES)
-def test_conv_bf16x3_vs_oracle(dev, case):
+def test_conv_bf16x3_vs_oracle(dev, case, tall, monkeypatch):
     """Wide 3x3 layers on the bf16 matrix pipe (operands split into bf16 head + tail): fp32-class accuracy, and the
-    exact-fp32 kernel on the same data for comparison."""
+    exact-fp32 kernel on the same data for comparison.  tall = 1 forces the 16-row tiles of full batches; otherwise the
+    plan picks 4-row tiles for these small problems."""
     from animateportrait_amd import ops
     from animateportrait_amd.networks import ConvLayer
+    monkeypatch.setenv('APAMD_NO_SMALL_TILES', str(tall))
     segs, cout, mode, H, W = case
     g = torch.Generator().manual_seed(sum(map(ord, str(case))))
     n = 2
@@ -650,13 +653,16 @@ def test_stem7x7_rows_bf16x3(dev, case):
             assert len(src.xs_rows) == 1          # one expansion shared by both runs
 
 
+@pytest.mark.parametrize('tall', [0, 1])
 @pytest.mark.parametrize('blocks', [1, 7, 24])
-def test_conv_bf16x3_persistent_walk(dev, blocks, monkeypatch):
+def test_conv_bf16x3_persistent_walk(dev, blocks, tall, monkeypatch):
     """The split-bf16 kernel's workgroups are persistent: each walks several (image, pixel tile, cout tile) entries
     with the LDS stages of consecutive tiles overlapped.  Force small grids (also ones that are not a multiple of
-    the 8 XCDs) and compare bit-for-bit with the default launch of the same layer."""
+    the 8 XCDs) and compare bit-for-bit with the default launch of the same layer -- for the 16-row tiles of full
+    batches (tall) and for the 4-row tiles the plan picks when the tile list would leave most CUs idle."""
     from animateportrait_amd import ops
     from animateportrait_amd.networks import ConvLayer
+    monkeypatch.setenv('APAMD_NO_SMALL_TILES', str(tall))
     g = torch.Generator().manual_seed(77 + blocks)
     n, H, W = 3, 50, 70
     segs, cout = [64, 48], 136
