@@ -466,9 +466,76 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
     y[((long long)n * C + c) * OH * OW + pix] = v;
 }
 
+// ---- motion grid of the data layer (Module2/data/umlvd_ifw_dataset.py:60-74, umlvdfw_test_dataset.py:67-81:
+// scipy.interpolate.griddata(destination, source, grid, method='linear')): piecewise-linear interpolation of the
+// source landmark positions over the Delaunay triangulation of the destination landmarks (+ 8 border points), evaluated
+// at every pixel and normalised to grid_sample coordinates.  The triangulation (76 points) comes from the host; the
+// kernel rasterises it: one lane per pixel, triangles in LDS, the triangle that contains the pixel best (largest
+// minimum barycentric coordinate -- on shared edges both candidates give the same value) is interpolated.
+// pts: [N][P][2] destination (row, col); val: [N][P][2] source (row, col); tri: [N][T][3] point indices (-1: unused)
+// out: [N][S][S][2] = (col, row) / ((S-1)/2) - 1.   grid: (ceil(S*S/256), N)
+__global__ __launch_bounds__(256) void motion_grid_kernel(const float* __restrict__ pts, const float* __restrict__ val,
+                                                          const int* __restrict__ tri, int P, int T, int S,
+                                                          float* __restrict__ out) {
+    extern __shared__ float tsm[];                       // per triangle: 3 x (row, col) destination, 3 x (row, col) source
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const int a = tri[((long long)n * T + i) * 3], b = tri[((long long)n * T + i) * 3 + 1],
+                  c = tri[((long long)n * T + i) * 3 + 2];
+        float* t = tsm + i * 12;
+        if (a < 0 || b < 0 || c < 0 || a >= P || b >= P || c >= P) {
+            for (int k = 0; k < 12; ++k) t[k] = 0.f;     // degenerate: never selected (zero area)
+        } else {
+            const int idx[3] = {a, b, c};
+            for (int k = 0; k < 3; ++k) {
+                t[k * 2] = pts[((long long)n * P + idx[k]) * 2];
+                t[k * 2 + 1] = pts[((long long)n * P + idx[k]) * 2 + 1];
+                t[6 + k * 2] = val[((long long)n * P + idx[k]) * 2];
+                t[6 + k * 2 + 1] = val[((long long)n * P + idx[k]) * 2 + 1];
+            }
+        }
+    }
+    __syncthreads();
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= S * S) return;
+    const float pr = (float)(pix / S), pc = (float)(pix % S);
+    float best = -1e30f, vr = 0.f, vc = 0.f;
+    for (int i = 0; i < T; ++i) {
+        const float* t = tsm + i * 12;
+        const float r0 = t[0], c0 = t[1], r1 = t[2], c1 = t[3], r2 = t[4], c2 = t[5];
+        const float det = (r1 - r0) * (c2 - c0) - (r2 - r0) * (c1 - c0);
+        if (det == 0.f) continue;
+        const float l1 = ((pr - r0) * (c2 - c0) - (r2 - r0) * (pc - c0)) / det;
+        const float l2 = ((r1 - r0) * (pc - c0) - (pr - r0) * (c1 - c0)) / det;
+        const float l0 = 1.f - l1 - l2;
+        const float m = fminf(l0, fminf(l1, l2));
+        if (m > best) {
+            best = m;
+            vr = l0 * t[6] + l1 * t[8] + l2 * t[10];
+            vc = l0 * t[7] + l1 * t[9] + l2 * t[11];
+        }
+    }
+    const float half = (float)(S - 1) / 2.f;              // 127.5 for 256
+    float2 o;
+    o.x = vc / half - 1.f;
+    o.y = vr / half - 1.f;
+    reinterpret_cast<float2*>(out)[(long long)n * S * S + pix] = o;
+}
+
 }  // namespace apamd
 
 using namespace apamd;
+
+extern "C" int ap_motion_grid(const float* pts, const float* val, const int32_t* tri, int32_t N, int32_t P, int32_t T,
+                              int32_t S, float* out, ap_stream_t stream) {
+    if (!pts || !val || !tri || !out) return fail(AP_ERR_INVALID, "motion_grid: null pointer");
+    if (N < 1 || N > 65535 || P < 3 || T < 1 || S < 2) return fail(AP_ERR_INVALID, "motion_grid: bad sizes");
+    const size_t lds = (size_t)T * 12 * sizeof(float);
+    if (lds > 60 * 1024) return fail(AP_ERR_UNSUPPORTED, "motion_grid: %d triangles do not fit the LDS table", T);
+    hipLaunchKernelGGL(motion_grid_kernel, dim3((S * S + 255) / 256, N), dim3(256), lds, (hipStream_t)stream, pts, val, tri,
+                       P, T, S, out);
+    return check_launch("motion_grid_kernel");
+}
 
 extern "C" int ap_resize_bilinear(const float* x, int32_t NC, int32_t H, int32_t W, int32_t OH, int32_t OW, float* y,
                                   ap_stream_t stream) {

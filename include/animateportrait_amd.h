@@ -153,6 +153,13 @@ int ap_warp_concat_fwd(const float* x, const float* x_mean, const float* x_rstd,
                        const float* motion, const float* flow, const float* ifmask,
                        float* out, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                        float flow_scale, ap_stream_t stream);
+/* Motion grid of the data layer (cal_motion256: Module2/data/umlvd_ifw_dataset.py:60-74, umlvdfw_test_dataset.py:67-81 =
+ * scipy.interpolate.griddata(destination, source, 256x256 grid, method='linear')): rasterises the piecewise-linear map
+ * defined by a triangulation.  pts / val: [N][P][2] destination / source points as (row, col); tri: [N][T][3] indices
+ * into the P points (Delaunay simplices from the host; -1 entries are ignored); out: [N][S][S][2] in grid_sample
+ * coordinates ((col, row) / ((S-1)/2) - 1), i.e. the `warp_motion` input of the generator. */
+int ap_motion_grid(const float* pts, const float* val, const int32_t* tri, int32_t N, int32_t P, int32_t T, int32_t S,
+                   float* out, ap_stream_t stream);
 /* Image-level helpers of the streaming-inference model (geomcgt_ifw_test_model.py:282-285, 294):
  * y = F.interpolate(x, (OH, OW), mode='bilinear', align_corners=False) over NC planes, and
  * y = F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=...) with grid (N, OH, OW, 2). */

@@ -252,6 +252,25 @@ def test_resize_and_grid_sample(dev):
         assert linf(ops.grid_sample(x.to(dev), grid.to(dev), align_corners=ac), ref) < 2e-5, ac   # fp32 coordinates
 
 
+def test_motion_grid_rasteriser(dev, golden):
+    """ap_motion_grid (host Delaunay + device rasterisation) against the reference's
+    cal_motion256 (scipy griddata, fp64): the grid agrees to fp32 rounding of the barycentric weights, batched."""
+    from animateportrait_amd.data.motion import cal_motion256
+    gd = golden('motion.npz')
+    lm0 = np.stack([gd['lm0_%d' % i].numpy() for i in range(2)])
+    lm = np.stack([gd['lm_%d' % i].numpy() for i in range(2)])
+    got = cal_motion256(lm0, lm, device=dev)
+    assert got.shape == (2, 256, 256, 2) and got.is_cuda
+    for i in range(2):
+        assert linf(got[i], gd['motion_%d' % i]) < 2e-5          # 2.5e-3 px
+    one = cal_motion256(lm0[1], lm[1], device=dev)
+    assert torch.equal(one[0], got[1])
+    ident = cal_motion256(lm[0], lm[0], device=dev)              # identical landmarks: the identity grid
+    ax = torch.arange(256., device=dev) / 127.5 - 1
+    assert linf(ident[0, :, :, 0], ax.view(1, 256).expand(256, 256)) < 1e-5
+    assert linf(ident[0, :, :, 1], ax.view(256, 1).expand(256, 256)) < 1e-5
+
+
 def test_streaming_inference_model(dev):
     """GeomCGTIFWTestModel (geomcgt_ifw_test_model.py:254-302, 'drawing' branch): masked photo -> hot-path generator,
     static drawing at 512^2 (cached per photo), mask warped by the motion grid, blend -- against the oracle

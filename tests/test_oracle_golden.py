@@ -129,6 +129,16 @@ def test_static_generator(golden):
         assert linf(y, gd['y_' + tag]) < 1e-5
 
 
+def test_motion_grid(golden):
+    """cal_motion256 (griddata over the landmark triangulation) against the output of the
+    reference's own function (tests/golden/make_motion_golden.py)."""
+    from oracle import motion as om
+    gd = golden('motion.npz')
+    for i in range(2):
+        got = om.cal_motion256(gd['lm0_%d' % i].numpy(), gd['lm_%d' % i].numpy())
+        assert got.shape == (256, 256, 2) and float(np.abs(got - gd['motion_%d' % i].numpy()).max()) == 0.0
+
+
 def test_patchgan(golden):
     gd = golden('patchgan.npz')
     for cin in (1, 2):
