@@ -135,6 +135,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32 comparison leg')
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
     a = ap.parse_args()
 
@@ -228,6 +229,36 @@ def main():
         except Exception:
             pass
 
+    # ---- the same workload with every product on the exact-fp32 MFMA (APAMD_PRECISION=fp32): reported next to the
+    # headline so that the split-bf16 arithmetic (3 bf16 MFMAs per fp32 product, fp32 accumulate) is an explicit,
+    # measured choice -- and the largest output difference between the two paths on this batch
+    exact = None
+    if not a.no_exact_fp32:
+        old = ops.DEFAULT_PRECISION
+        ops.DEFAULT_PRECISION = ops.PRECISION_FP32
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                G32 = build_generator(dev)                       # same seed -> same weights
+        finally:
+            ops.DEFAULT_PRECISION = old
+        with torch.no_grad():
+            y32 = G32(*args)
+            diff = float((y32 - y).abs().max())
+            for _ in range(2):
+                G32(*args)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n32 = min(a.steps, 5)
+            for _ in range(n32):
+                G32(*args)
+            torch.cuda.synchronize()
+            dt32 = (time.perf_counter() - t1) / n32
+        exact = {'value': round(BATCH / dt32, 2), 'unit': 'frames/s per GPU', 'ms_per_step': round(dt32 * 1e3, 3),
+                 'steps': n32, 'max_abs_diff_vs_headline_output': diff,
+                 'note': 'all convolutions on v_mfma_f32_32x32x2_f32 (APAMD_PRECISION=fp32); the headline path differs '
+                         'from it by max_abs_diff on outputs in [-1, 1] (budget 1e-3)'}
+        del G32, y32
+
     # ---- second half of the BASELINE metric: "train step ms" -- the geomgm_ifw_fore drawing-config step
     # (G + 5 PatchGAN D's, warp / coherence losses, Adam), B=16 per GPU, fp32, gradients all-reduced over RCCL
     train = None
@@ -250,6 +281,8 @@ def main():
                'whole_generator_algorithmic_tflops': round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
                'vs_fp32_mfma_conv_roofline': round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                'roofline': roofline}
+        if exact is not None:
+            out['exact_fp32'] = exact
         if train is not None:
             out['train_step'] = train
         if not a.no_cpu_baseline and world == 1:
