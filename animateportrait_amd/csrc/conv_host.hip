@@ -8,6 +8,7 @@
 #include "conv_direct.h"
 #include "conv_bf16x3.h"
 #include "conv_small.h"
+#include "conv_head.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -96,6 +97,8 @@ struct Plan {
     const ConvKernelInfo* k = nullptr;
     int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
     bool small = false;            // conv_small_f32: narrow 3x3 layers on the vector ALUs
+    bool head = false;             // conv_head_fwd_kernel: one output channel, 4x4, narrow map
+    long long head_w_off = -1;     // >= 0: OIHW copy of the weights at this offset of the packed image
     bool bf3 = false;              // split-bf16 matrix path
     const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
@@ -181,6 +184,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.stat_tiles = ((pl.Hout + 15) / 16) * ((pl.Wout + 63) / 64);
         return AP_OK;
     }
+    // PatchGAN output layer (one output channel, 4x4 pad 1; conv_head.h).  The weight image must not depend on the map
+    // size (weights are packed once per layer): layers of this shape carry their OIHW weights behind the regular image,
+    // and maps narrow enough for the half-wave row kernel use those.
+    const bool head_w = !rowk && !d->transposed && d->stride == 1 && K == 4 && d->Cout == 1 && d->nsrc == 1 && pl.Cin >= 64 &&
+                        d->w_layout == AP_W_OIHW && !d->w_flip && d->pad == 1;
+    pl.head = head_w && d->W <= kHeadMaxW && !env_int("APAMD_NO_HEAD", 0);
     // narrow 3x3 layers (landmark encoder): memory streams, one lane per output pixel (conv_small.h)
     if (!rowk && !d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
         d->w_layout == AP_W_OIHW && !d->w_flip && !env_int("APAMD_NO_SMALL", 0)) {
@@ -192,7 +201,10 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         return AP_OK;
     }
     // split-bf16 matrix path (conv_bf16x3.h): wide 3x3 / transposed layers when the caller allows ~1e-4 relative error
-    if (!rowk && d->precision == AP_PRECISION_BF16X3 && d->Cout >= 48 && pl.Cin >= 32 && !env_int("APAMD_NO_BF16X3", 0)) {
+    // (>= 48 outputs fill most of a 64-cout tile; with >= 128 inputs even a 16-output layer -- the data gradient of a
+    // ResnetBlock2 convolution w.r.t. its 16-channel landmark segments -- is 3x faster here than on the fp32 pipe)
+    if (!rowk && d->precision == AP_PRECISION_BF16X3 && (d->Cout >= 48 || (d->Cout >= 16 && pl.Cin >= 128)) && pl.Cin >= 32 &&
+        !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
         if (seg_ok && (KT == 0 || K == 3 || (K == 4 && S == 1))) {
@@ -322,6 +334,10 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 finish(L);
                 pl.launches.push_back(L);
             }
+    }
+    if (head_w) {
+        pl.head_w_off = (pl.packed_floats + 3) & ~3LL;            // float4 loads
+        pl.packed_floats = pl.head_w_off + (long long)pl.Cin * K * K;
     }
     return AP_OK;
 }
@@ -560,6 +576,10 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         snprintf(buf, buflen, "SmallCfg<%d, %d>", d->stride, d->Cout);
         return AP_OK;
     }
+    if (pl.head) {
+        snprintf(buf, buflen, "HeadCfg<%d>", d->KH);
+        return AP_OK;
+    }
     if (pl.bf3) {
         snprintf(buf, buflen, "%s", pl.bk->name);
         return AP_OK;
@@ -627,6 +647,11 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
         rc = check_launch("pack_weights_kernel");
         if (rc) return rc;
     }
+    if (pl.head_w_off >= 0) {
+        hipError_t e = hipMemcpyAsync(packed + pl.head_w_off, weight, (size_t)pl.Cin * d->KH * d->KW * sizeof(float),
+                                      hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "pack (head copy) weights: %s", hipGetErrorString(e));
+    }
     return AP_OK;
 }
 
@@ -642,6 +667,17 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
+    }
+    if (pl.head && !stat_partials) {      // (with a statistics epilogue wanted the layer stays on the general kernel)
+        HeadParams p;
+        memset(&p, 0, sizeof(p));
+        p.src.data = d->src[0].data; p.src.mean = d->src[0].mean; p.src.rstd = d->src[0].rstd;
+        p.src.C = d->src[0].C; p.src.act = d->src[0].act;
+        p.N = d->N; p.C = pl.Cin; p.H = d->H; p.W = d->W; p.OH = pl.Hout; p.OW = pl.Wout;
+        p.w = packed + pl.head_w_off; p.bias = bias; p.act = d->act; p.y = y;
+        hipLaunchKernelGGL(conv_head_fwd_kernel<kHeadBand>, dim3(d->N, (pl.Hout + kHeadBand - 1) / kHeadBand), dim3(1024), 0,
+                           (hipStream_t)stream, p);
+        return check_launch("conv_head_fwd_kernel");
     }
     if (pl.small) {
         SmallKParams p;

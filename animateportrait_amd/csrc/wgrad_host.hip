@@ -4,6 +4,7 @@
 //                   -> wgrad_igemm_f32 (split over pixels) -> wgrad_reduce_kernel.
 // The caller provides ONE workspace; its layout is  [A padded][G padded (optional)][partials].
 #include "common.h"
+#include "conv_head.h"
 #include "wgrad_bf16x3.h"
 #include "wgrad_igemm.h"
 
@@ -208,6 +209,23 @@ int ap_pad_materialize(const ap_src* src, int32_t nsrc, int32_t N, int32_t H, in
         C += src[s].C;
     }
     return launch_pad(src, nsrc, N, C, H, W, pad, pad_mode, Hp, Wp, out, (hipStream_t)stream);
+}
+
+int ap_conv_head_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
+                       float* dw, ap_stream_t stream) {
+    if (!src || !src->data || !g || !dw) return fail(AP_ERR_INVALID, "conv_head_wgrad: null pointer");
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "conv_head_wgrad: mean/rstd mismatch");
+    const int OH = H + 2 * pad - K + 1, OW = W + 2 * pad - K + 1;
+    if (K != 4 || pad != 1 || N < 1 || src->C < 1 || src->C > 65535 || OH < 1 || OW < 1 || W > kHeadMaxW || H > kHeadMaxH)
+        return fail(AP_ERR_UNSUPPORTED, "conv_head_wgrad: built for 4x4 pad-1 heads on maps up to %dx%d (K=%d, pad=%d, %dx%d)",
+                    kHeadMaxH, kHeadMaxW, K, pad, H, W);
+    HeadParams p;
+    memset(&p, 0, sizeof(p));
+    p.src.data = src->data; p.src.mean = src->mean; p.src.rstd = src->rstd; p.src.C = src->C; p.src.act = src->act;
+    p.N = N; p.C = src->C; p.H = H; p.W = W; p.OH = OH; p.OW = OW;
+    p.g = g; p.dw = dw;
+    hipLaunchKernelGGL(conv_head_wgrad_kernel, dim3(src->C), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("conv_head_wgrad_kernel");
 }
 
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {

@@ -441,6 +441,21 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
     precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers)."""
     n, m, gh, gw = g.data.shape
     cin = sum(f.data.shape[1] for f in srcs)
+    if (m == 1 and k == 4 and stride == 1 and len(srcs) == 1 and cin >= 64 and not g.virtual and g.act == ACT_NONE and
+            tuple(out_shape) == (1, cin, k, k) and srcs[0].data.shape[2] <= 32 and srcs[0].data.shape[3] <= 31 and
+            pad == 1 and pad_mode == PAD_ZERO and not os.environ.get('APAMD_NO_HEAD')):
+        # PatchGAN output layer: one workgroup per input channel (conv_head.h)
+        f = srcs[0]
+        _require_device(f.data, 'wgrad source')
+        _require_device(g.data, 'wgrad gradient')
+        s = C.ApSrc()
+        s.data, s.C, s.act = f.data.data_ptr(), cin, f.act
+        if f.virtual:
+            s.mean, s.rstd = f.mean.data_ptr(), f.rstd.data_ptr()
+        dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+        C.check(C.lib().ap_conv_head_wgrad(ctypes.byref(s), _ptr(g.data), n, f.data.shape[2], f.data.shape[3], k, pad,
+                                           _ptr(dw), _stream()), 'conv_head_wgrad')
+        return dw
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
         return _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
     d = C.ApWgradDesc()

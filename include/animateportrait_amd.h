@@ -203,6 +203,11 @@ typedef struct ap_wgrad_desc {
     ap_src g;             /* g.C is ignored (M is used) */
     ap_src src[3];
 } ap_wgrad_desc;
+/* Weight gradient of a one-output-channel 4x4 stride-1 layer on a small map (the PatchGAN output layer,
+ * networks.py:2643): dw[0][c][ky][kx] = sum_{n,oy,ox} g[n,0,oy,ox] * act(IN(src))[n,c,oy+ky-pad,ox+kx-pad].  One workgroup
+ * per input channel, fixed summation order, no workspace.  (Its forward is a plan of ap_conv2d_fwd.) */
+int ap_conv_head_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
+                       float* dw, ap_stream_t stream);
 /* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
  * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);

@@ -356,6 +356,8 @@ CONV_CASES = [
     ([24], 96, 4, 2, 1, 'zero', False, 30, 34),
     ([16], 48, 4, 1, 1, 'zero', False, 32, 32),
     ([32], 1, 4, 1, 1, 'zero', False, 31, 31),
+    ([96], 1, 4, 1, 1, 'zero', False, 31, 31),         # PatchGAN output layer: half-wave row kernel (conv_head.h)
+    ([70], 1, 4, 1, 1, 'zero', False, 45, 23),
     ([16], 24, 3, 2, 1, 'zero', True, 9, 21),
     ([10], 12, 4, 2, 1, 'zero', True, 15, 16),
 ]
@@ -417,6 +419,8 @@ BWD_CASES = [
     ([2], 64, 4, 2, 1, 'zero', False, 64, 64),
     ([16], 48, 4, 1, 1, 'zero', False, 32, 32),
     ([32], 1, 4, 1, 1, 'zero', False, 31, 31),
+    ([96], 1, 4, 1, 1, 'zero', False, 31, 31),
+    ([70], 1, 4, 1, 1, 'zero', False, 32, 23),
     ([16], 24, 3, 2, 1, 'zero', True, 9, 21),
 ]
 
