@@ -57,6 +57,8 @@ SIGNATURES = {
     'ap_split_prepass_rows': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                              ctypes.c_void_p]),
+    'ap_split_prepass_s2d': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
     'ap_norm_apply_split': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p,
                                            ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            c_f32p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -681,6 +681,51 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
     }
 }
 
+// ---- space-to-depth split copy for the 4x4 stride-2 pad-1 layers of the PatchGAN (networks.py:2620-2636):
+//   X'[(ry*2 + rx)*C + c][qy][qx] = pad1(act(IN(x)))[c][2 qy + ry][2 qx + rx]        (H/2 + 1) x (W/2 + 1), 4C channels
+// so that the layer is the stride-1 2 x 2 convolution  y[co][oy][ox] = sum W'[co][c'][ty][tx] X'[c'][oy + ty][ox + tx]
+// with W'[co][(ry*2+rx)*C + c][ty][tx] = W[co][c][2 ty + ry][2 tx + rx], which the run-time-tap kernel computes.
+struct SplitS2dParams {
+    const float* x;
+    const float* mean;
+    const float* rstd;
+    int act;
+    int N, C, H, W;           // source
+    uint4* out;               // XS[n][part][4C/8][H'W' + 1]
+};
+
+// grid: (ceil(H'W' / 256), 4C/8, N)
+static __global__ __launch_bounds__(256) void split_s2d_kernel(const SplitS2dParams p) {
+    const int n = blockIdx.z, g2 = blockIdx.y, G = p.C >> 3;
+    const int r = g2 / G, g = g2 - r * G, ry = r >> 1, rx = r & 1;
+    const int H2 = p.H / 2 + 1, W2 = p.W / 2 + 1, HW2 = H2 * W2, HW = p.H * p.W;
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    uint4* const hi = p.out + ((long long)(n * 2 + 0) * (4 * G) + g2) * (HW2 + 1);
+    uint4* const lo = p.out + ((long long)(n * 2 + 1) * (4 * G) + g2) * (HW2 + 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) hi[HW2] = lo[HW2] = make_uint4(0u, 0u, 0u, 0u);
+    if (pix >= HW2) return;
+    const int qy = pix / W2, qx = pix - qy * W2;
+    const int sy = 2 * qy + ry - 1, sx = 2 * qx + rx - 1;
+    bf16x8 hv, lv;
+    const bool ok = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = 0.f;
+        if (ok) {
+            const int c = g * 8 + j;
+            t = p.x[((long long)n * p.C + c) * HW + sy * p.W + sx];
+            if (p.mean != nullptr) t = (t - p.mean[n * p.C + c]) * p.rstd[n * p.C + c];
+            t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+        }
+        __bf16 h, l;
+        split_bf16(t, h, l);
+        hv[j] = h;
+        lv[j] = l;
+    }
+    *reinterpret_cast<bf16x8*>(hi + pix) = hv;
+    *reinterpret_cast<bf16x8*>(lo + pix) = lv;
+}
+
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16
 struct PackBf3Params {
     const float* w;

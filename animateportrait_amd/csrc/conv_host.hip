@@ -141,7 +141,15 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         if (d->stride != 1 && d->stride != 2) return fail(AP_ERR_UNSUPPORTED, "stride %d", d->stride);
         S = d->stride;
         KT = K;
-        if (K != 3 && K != 4 && K != 7) return fail(AP_ERR_UNSUPPORTED, "kernel size %d (built: 3, 4, 7)", K);
+        if (K == 2) {
+            // the space-to-depth form of a 4x4 stride-2 layer (ap_split_prepass_s2d): 4 run-time taps, split-bf16 only
+            if (d->stride != 1 || d->pad != 0 || d->precision != AP_PRECISION_BF16X3 || d->w_layout != AP_W_OIHW || d->w_flip)
+                return fail(AP_ERR_UNSUPPORTED, "2x2 kernels exist only as the space-to-depth form of a 4x4 stride-2 layer "
+                                                "(stride 1, pad 0, split-bf16 precision)");
+            KT = 0;
+        } else if (K != 3 && K != 4 && K != 7) {
+            return fail(AP_ERR_UNSUPPORTED, "kernel size %d (built: 3, 4, 7)", K);
+        }
         pl.Hout = (d->H + 2 * d->pad - K) / S + 1;
         pl.Wout = (d->W + 2 * d->pad - K) / S + 1;
         if (d->pad_mode == AP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
@@ -224,7 +232,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 if (tiles * 2 <= num_cus() && !env_int("APAMD_NO_SMALL_TILES", 0)) pl.bk = small;
             }
         }
-        if (KT == 0 && K != 3 && K != 4) pl.bk = nullptr;
+        if (KT == 0 && K != 2 && K != 3 && K != 4) pl.bk = nullptr;
     }
     if (pl.bk) {
         pl.bf3 = true;
@@ -556,6 +564,24 @@ int ap_split_prepass_rows(const ap_src* src, int32_t N, int32_t H, int32_t W, in
         default: hipLaunchKernelGGL((split_rows_kernel<7, 4>), grid, dim3(256), 0, (hipStream_t)stream, p); break;
     }
     return check_launch("split_rows_kernel");
+}
+
+int ap_split_prepass_s2d(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {
+    if (!src || !src->data || !out) return fail(AP_ERR_INVALID, "split_prepass_s2d: null pointer");
+    if (src->C < 8 || src->C % 8 != 0 || H < 2 || W < 2 || (H & 1) || (W & 1))
+        return fail(AP_ERR_UNSUPPORTED, "split_prepass_s2d: needs channels in multiples of 8 and an even map (C=%d, %dx%d)",
+                    src->C, H, W);
+    if (N < 1 || N > 65535 || src->C / 2 > 65535) return fail(AP_ERR_INVALID, "split_prepass_s2d: bad sizes");
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "split_prepass_s2d: mean/rstd mismatch");
+    if (src->act < 0 || src->act > 2) return fail(AP_ERR_INVALID, "split_prepass_s2d: act %d", src->act);
+    SplitS2dParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = src->data; p.mean = src->mean; p.rstd = src->rstd; p.act = src->act;
+    p.N = N; p.C = src->C; p.H = H; p.W = W;
+    p.out = reinterpret_cast<uint4*>(out);
+    const int HW2 = (H / 2 + 1) * (W / 2 + 1);
+    hipLaunchKernelGGL(split_s2d_kernel, dim3((HW2 + 255) / 256, src->C / 2, N), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("split_s2d_kernel");
 }
 
 int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream) {

@@ -51,6 +51,8 @@ class ConvLayer(nn.Module):
         self._packed_dgrad = {}
         self._rows_spec = None
         self._packed_rows = None
+        self._s2d_spec = None
+        self._packed_s2d = None
 
     def packed_dgrad(self, seg, spec, w):
         """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
@@ -80,11 +82,27 @@ class ConvLayer(nn.Module):
             # 7x7 stem on <= 4 channels: 1x7 split-bf16 convolution over the row expansion of the input
             spec, packed = self.rows_spec(), self.packed_rows()
             srcs = [ops.presplit_rows(srcs[0], self.spec.k, self.spec.pad, self.spec.pad_mode)]
+        elif not srcs[0].is_split_only and ops.s2d_eligible(spec, *srcs[0].data.shape[2:]):
+            # 4x4 stride-2 PatchGAN layer: 2x2 split-bf16 convolution over the space-to-depth copy of the input
+            spec, packed = self.s2d_spec(), self.packed_s2d()
+            srcs = [ops.presplit_s2d(srcs[0])]
         if packed is None:
             packed = self.packed()
         if norm_act is None:
             return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act)
         return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act)
+
+    def s2d_spec(self):
+        if self._s2d_spec is None:
+            self._s2d_spec = ops.s2d_spec(self.spec)
+        return self._s2d_spec
+
+    def packed_s2d(self):
+        w = self.weight
+        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        if self._packed_s2d is None or self._packed_s2d[0] != key:
+            self._packed_s2d = (key, ops.pack_weights(self.s2d_spec(), ops.s2d_weight(w.detach())))
+        return self._packed_s2d[1]
 
     def rows_spec(self):
         if self._rows_spec is None:

@@ -243,6 +243,43 @@ def presplit_rows(f, k, pad, pad_mode):
     return hit
 
 
+def s2d_eligible(spec, h, w):
+    """4x4 stride-2 pad-1 layers with >= 32 input channels (PatchGAN body, networks.py:2620-2636) run as a 2x2
+    stride-1 split-bf16 convolution over the space-to-depth copy of their input."""
+    return (spec.precision == PRECISION_BF16X3 and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and
+            spec.pad_mode == PAD_ZERO and not spec.transposed and len(spec.cin_segments) == 1 and
+            spec.cin_segments[0] >= 32 and spec.cin_segments[0] % 8 == 0 and spec.cout >= 48 and h % 2 == 0 and
+            w % 2 == 0 and spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_S2D'))
+
+
+def s2d_spec(spec):
+    s = ConvSpec([4 * spec.cin_segments[0]], spec.cout, 2, 1, 0, PAD_ZERO)
+    s.precision = PRECISION_BF16X3
+    return s
+
+
+def s2d_weight(weight):
+    """W[co][c][2 ty + ry][2 tx + rx] -> W'[co][(ry*2 + rx)*C + c][ty][tx]."""
+    co, c = weight.shape[:2]
+    return weight.reshape(co, c, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * c, 2, 2).contiguous()
+
+
+def presplit_s2d(f):
+    """Space-to-depth split copy of a (virtual) feature as a split-only Feat of shape (N, 4C, H/2 + 1, W/2 + 1)."""
+    x = f.data
+    n, c, h, w = x.shape
+    _require_device(x, 'space-to-depth source')
+    s = C.ApSrc()
+    s.data, s.C, s.act = x.data_ptr(), c, f.act
+    if f.virtual:
+        s.mean, s.rstd = f.mean.data_ptr(), f.rstd.data_ptr()
+    shape = (n, 4 * c, h // 2 + 1, w // 2 + 1)
+    nbytes = C.check(C.lib().ap_split_prepass_bytes(*shape), 'split_prepass_bytes')
+    xs = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    C.check(C.lib().ap_split_prepass_s2d(ctypes.byref(s), n, h, w, _ptr(xs), _stream()), 'split_prepass_s2d')
+    return Feat.split_only(shape, xs)
+
+
 def _alloc_xs(x):
     n, c, h, w = x.shape
     nbytes = C.check(C.lib().ap_split_prepass_bytes(n, c, h, w), 'split_prepass_bytes')

@@ -117,6 +117,12 @@ int ap_split_prepass(const ap_src* src, int32_t N, int32_t H, int32_t W, void* o
  * W'[co][ky*C + c][0][kx] = W[co][c][ky][kx] (zero for the unused channels).  One expansion serves all three stems. */
 int ap_split_prepass_rows(const ap_src* src, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad, int32_t pad_mode,
                           void* out, ap_stream_t stream);
+/* 4x4 stride-2 pad-1 layers (PatchGAN body, networks.py:2620-2636) on the split-bf16 path, as space-to-depth:
+ *     X'[(ry*2 + rx)*C + c][qy][qx] = pad1(act(IN(src)))[c][2 qy + ry][2 qx + rx]      ((H/2 + 1) x (W/2 + 1), 4C channels)
+ * (`out`: ap_split_prepass_bytes(N, 4C, H/2 + 1, W/2 + 1) bytes; C % 8 == 0, H and W even), and the layer becomes
+ * ap_conv2d_* with KH = KW = 2, stride 1, pad 0, one 4C-channel source, presplit = 1 and weights
+ * W'[co][(ry*2 + rx)*C + c][ty][tx] = W[co][c][2 ty + ry][2 tx + rx]. */
+int ap_split_prepass_s2d(const ap_src* src, int32_t N, int32_t H, int32_t W, void* out, ap_stream_t stream);
 /* The whole step between two convolutions in one streaming pass (ResnetBlock: networks.py:2329-2360):
  *     v = act(IN(src)) [+ IN(residual)]      y = v as fp32 (NULL: skip)      xs = split-bf16 copy of v (NULL: skip)
  * The InstanceNorm statistics of `src` come finished (src->mean / rstd) or -- stat_partials != NULL, src->mean NULL --

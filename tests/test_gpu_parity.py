@@ -676,6 +676,48 @@ def test_stem7x7_rows_bf16x3(dev, case):
             assert len(src.xs_rows) == 1          # one expansion shared by both runs
 
 
+@pytest.mark.parametrize('case', [
+    # cin, cout, H, W, virtual source
+    (64, 128, 64, 64, True),
+    (32, 48, 36, 70, False),
+    (128, 130, 30, 34, True),
+    (40, 64, 2, 66, True),
+])
+def test_conv4x4s2_space_to_depth_bf16x3(dev, case):
+    """PatchGAN body layers (Conv2d(c, 2c, 4, stride 2, pad 1), networks.py:2620-2636) as a 2x2 stride-1 split-bf16
+    convolution over the space-to-depth copy of the input: fp32-class result; the exact-fp32 kernel beside it."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    cin, cout, H, W, virt = case
+    g = torch.Generator().manual_seed(sum(map(ord, str(case))))
+    n = 2
+    x = torch.randn(n, cin, H, W, generator=g) * 1.5 + 0.2
+    w = torch.randn(cout, cin, 4, 4, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    if virt:
+        m = x.mean((2, 3)).reshape(-1)
+        r = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+        src = ops.Feat(x.to(dev), m.to(dev), r.to(dev), ops.ACT_LRELU)
+        xd = F.leaky_relu(F.instance_norm(x), 0.2).double()
+    else:
+        src = ops.Feat(x.to(dev))
+        xd = x.double()
+    ref = F.conv2d(xd, w.double(), b.double(), stride=2, padding=1)
+    scale = float(ref.abs().max())
+    for prec, tol in ((ops.PRECISION_BF16X3, 5e-5), (ops.PRECISION_FP32, 2e-6)):
+        layer = ConvLayer([cin], cout, 4, 2, 1, ops.PAD_ZERO).to(dev)
+        layer.spec.precision = prec
+        with torch.no_grad():
+            layer.weight.copy_(w); layer.bias.copy_(b)
+        assert ops.s2d_eligible(layer.spec, H, W) == (prec == ops.PRECISION_BF16X3)
+        y = layer.run(src, act=ops.ACT_LRELU)
+        assert y.data.shape == ref.shape
+        assert linf(y.data, F.leaky_relu(ref, 0.2)) / scale < tol, (prec, linf(y.data, F.leaky_relu(ref, 0.2)) / scale)
+        yn = layer.run(src, norm_act=ops.ACT_RELU)
+        got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
+        assert linf(got, F.instance_norm(ref.float())) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
+
+
 @pytest.mark.parametrize('tall', [0, 1])
 @pytest.mark.parametrize('blocks', [1, 7, 24])
 def test_conv_bf16x3_persistent_walk(dev, blocks, tall, monkeypatch):
