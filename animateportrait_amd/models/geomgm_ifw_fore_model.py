@@ -365,8 +365,9 @@ class GeomGMIFWForeModel(BaseModel):
         self.set_requires_grad(nets_D, False)
         self.optimizer_G.zero_grad()
         self.backward_G()
-        parallel.allreduce_optimizer_grads(self.optimizer_G)
-        self.optimizer_G.step()
+        # G's gradients travel (one RCCL all-reduce over xGMI) while the D backward passes run: those read only the
+        # frames generated in forward() and the D weights, so deferring G's update behind them changes no value
+        g_work = parallel.allreduce_optimizer_grads(self.optimizer_G, async_op=True)
         self.set_requires_grad(nets_D, True)
         self.optimizer_D.zero_grad()
         self.backward_D_A()
@@ -378,5 +379,7 @@ class GeomGMIFWForeModel(BaseModel):
             self.backward_D_A_ll()
         if o.coherent:
             self.backward_D_A_coh()
+        parallel.wait_work(g_work)
+        self.optimizer_G.step()
         parallel.allreduce_optimizer_grads(self.optimizer_D)
         self.optimizer_D.step()

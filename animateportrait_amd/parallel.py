@@ -81,13 +81,23 @@ def allreduce_gradients(params, bucket_bytes=32 << 20):
             bucket, size = [], 0
 
 
-def allreduce_optimizer_grads(optimizer, params=None):
-    """One collective when the optimiser keeps a flat gradient buffer, bucketed otherwise."""
+def allreduce_optimizer_grads(optimizer, params=None, async_op=False):
+    """One collective when the optimiser keeps a flat gradient buffer, bucketed otherwise.
+
+    async_op=True (flat buffers only): the collective is enqueued and its work handle returned; the caller keeps
+    launching independent work (the D backward passes while G's gradients travel) and calls ``wait_work`` before it
+    reads the gradients."""
     flat = getattr(optimizer, 'flat_grad', None)
     if flat is not None:
         if hasattr(optimizer, '_rebind'):
             optimizer._rebind()
-        allreduce_flat_(flat)
-    else:
-        allreduce_gradients(params if params is not None else
-                            [p for g in optimizer.param_groups for p in g['params']])
+        return allreduce_flat_(flat, async_op=async_op)
+    allreduce_gradients(params if params is not None else
+                        [p for g in optimizer.param_groups for p in g['params']])
+    return None
+
+
+def wait_work(work):
+    """Order the current stream (RCCL) / block the host (gloo) behind an asynchronous collective; None is a no-op."""
+    if work is not None:
+        work.wait()

@@ -22,7 +22,19 @@ def _worker(rank, world, port, q):
     parallel.allreduce_gradients(params, bucket_bytes=4096)        # several buckets
     flat = torch.randn(5000, generator=g)
     parallel.allreduce_flat_(flat)
-    batch = {'x': torch.arange(8).view(8, 1), 'name': 'n'}
+
+    # the train step's form: flat-gradient optimiser, collective in flight while other work runs, then wait
+    class _Opt:
+        flat_grad = torch.randn(3000, generator=g)
+    local = _Opt.flat_grad.clone()
+    work = parallel.allreduce_optimizer_grads(_Opt, async_op=True)
+    busy = torch.randn(64, 64, generator=g) @ torch.randn(64, 64, generator=g)      # independent work meanwhile
+    parallel.wait_work(work)
+    parallel.wait_work(None)
+    both = [torch.zeros(3000) for _ in range(world)]
+    dist.all_gather(both, local)
+    assert torch.allclose(_Opt.flat_grad, sum(both) / world, atol=1e-6) and busy.shape == (64, 64)
+    batch ={'x': torch.arange(8).view(8, 1), 'name': 'n'}
     shard = parallel.shard_batch(batch, rank, world)
     q.put((rank, [p.grad.clone() for p in params], flat.clone(), shard['x'].clone()))
     dist.barrier()
