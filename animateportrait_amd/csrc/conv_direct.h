@@ -10,6 +10,10 @@
 #pragma once
 #include "conv_igemm.h"
 
+#ifndef APAMD_DIRECT_B128
+#define APAMD_DIRECT_B128 1       // 0: compiler-generated window reads (kept for A/B measurements only)
+#endif
+
 namespace apamd {
 
 struct DirectKParams {
@@ -142,22 +146,61 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
         const bool more = chunk + 1 < p.nchunks;
         if (more) issue(chunk + 1);
         const float* X = xbuf + cur * XE + ty * IWS + tx * 4;
-        const float* wc = p.wp + (long long)chunk * CI * K * K * COP;
+        // constant address space: the weights stay scalar loads (s_load -> SGPR operands) although the hand-issued
+        // LDS reads below count as memory-clobbering statements for the compiler
+        typedef const float __attribute__((address_space(4))) cfloat;
+        const cfloat* wc = (const cfloat*)(uintptr_t)(p.wp + (long long)chunk * CI * K * K * COP);
 #pragma unroll 1
         for (int ci = 0; ci < CI; ++ci) {   // rolled: 49 weights per channel fit the SGPR file, 196 do not
+            // one output channel: the 49 weights of the channel are fetched (scalar loads) ahead of the window reads, so
+            // that one wait covers both
+            float wreg[COP == 1 ? K * K : 1];
+            if constexpr (COP == 1) {
+#pragma unroll
+                for (int t = 0; t < K * K; ++t) wreg[t] = wc[ci * K * K + t];
+            }
+#if APAMD_DIRECT_B128
+            // The window rows are read as whole 16-byte lanes, issued here by hand: left to itself the compiler drops
+            // the unused edge elements and splits every float4 into b64 / b32 pieces, and those, at the strips'
+            // 16-byte lane stride, hit 8 of the 32 banks -- a 4-way conflict on every read (the kernel ran 4x the
+            // LDS time of the conflict-free form).  All K rows of a channel are in flight before the single wait.
+            // (No "memory" clobber: the statements are ordered against the barriers that publish / recycle the
+            // stage buffer as side-effecting asm; a clobber would turn the scalar weight loads into vector loads.)
+            static_assert(NV == 3 && K == 7, "hand-issued window reads are written for 7x7");
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v q[K][NV];
+            {
+                const unsigned a0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(X + ci * PLANE);
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const unsigned a = a0 + ky * IWS * 4;
+                    asm volatile("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32"
+                                 : "=&v"(q[ky][0]), "=&v"(q[ky][1]), "=&v"(q[ky][2]) : "v"(a));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(q[0][0]), "+v"(q[0][1]), "+v"(q[0][2]), "+v"(q[1][0]), "+v"(q[1][1]), "+v"(q[1][2]),
+                               "+v"(q[2][0]), "+v"(q[2][1]), "+v"(q[2][2]), "+v"(q[3][0]), "+v"(q[3][1]), "+v"(q[3][2]),
+                               "+v"(q[4][0]), "+v"(q[4][1]), "+v"(q[4][2]), "+v"(q[5][0]), "+v"(q[5][1]), "+v"(q[5][2]),
+                               "+v"(q[6][0]), "+v"(q[6][1]), "+v"(q[6][2]));
+            }
+#endif
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 float win[NV * 4];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
+#if APAMD_DIRECT_B128
+                    win[v * 4 + 0] = q[ky][v].x; win[v * 4 + 1] = q[ky][v].y; win[v * 4 + 2] = q[ky][v].z; win[v * 4 + 3] = q[ky][v].w;
+#else
                     const float4 q = *reinterpret_cast<const float4*>(X + ci * PLANE + ky * IWS + v * 4);
                     win[v * 4 + 0] = q.x; win[v * 4 + 1] = q.y; win[v * 4 + 2] = q.z; win[v * 4 + 3] = q.w;
+#endif
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
 #pragma unroll
                     for (int c = 0; c < COP; ++c) {
-                        const float w = wc[((ci * K + ky) * K + kx) * COP + c];   // wave-uniform -> SGPR
+                        const float w = COP == 1 ? wreg[ky * K + kx] : wc[((ci * K + ky) * K + kx) * COP + c];   // wave-uniform -> SGPR
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[c][j] = fmaf(w, win[C::LPAD + j + kx], acc[c][j]);
                     }
