@@ -154,7 +154,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         t_ /= p.tiles_x;
         t.ty = t_ % p.tiles_y;
         t.n = t_ / p.tiles_y;
-        const int iy0 = t.ty * C::TH * S + p.dy0, ix0 = t.tx * 32 * S + p.dx0;
+        int dy0 = p.dy0, dx0 = p.dx0;
+        if (p.nphase > 1) {                                    // fused sub-pixel phases: the phase sets the window origin
+            const int ph = t.cot / p.co_tiles_phase;
+            dy0 = p.ph_dy0[ph];
+            dx0 = p.ph_dx0[ph];
+        }
+        const int iy0 = t.ty * C::TH * S + dy0, ix0 = t.tx * 32 * S + dx0;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) {
             int gy = iy0 + ((pgeo[k] >> 8) & 127), gx = ix0 + (pgeo[k] & 255);
@@ -365,11 +371,19 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                                            : reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
             float* const patch = epi + wave * (32 * TS);
             float* const sred = epi + 4 * 32 * TS;                             // [WPX][CO_TILE][2]
-            const int n = cur.n, cot = cur.cot;
+            const int n = cur.n;
+            int cot = cur.cot, oy_off = p.oy_off, ox_off = p.ox_off, stat_off = p.stat_tile_off;
+            if (p.nphase > 1) {                                // fused sub-pixel phases: (phase, cout tile of the phase)
+                const int ph = cot / p.co_tiles_phase;
+                cot -= ph * p.co_tiles_phase;
+                oy_off = p.ph_oy[ph];
+                ox_off = p.ph_ox[ph];
+                stat_off = p.ph_stat[ph];
+            }
             const int oy0 = cur.ty * C::TH, ox0 = cur.tx * 32;
             const int co_base = cot * CO_TILE + wco * MT * 32;
             const bool want_stats = p.stats != nullptr;
-            const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && p.ox_off == 0;
+            const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && ox_off == 0;
             const int prow = lane >> 3, pcol = (lane & 7) * 4;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
@@ -390,7 +404,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                         const int oxv = ox0 + pcol;
                         if (cok) {
                             float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
-                                         (long long)(oy * p.osy + p.oy_off) * p.o_rstride + oxv * p.osx + p.ox_off;
+                                         (long long)(oy * p.osy + oy_off) * p.o_rstride + oxv * p.osx + ox_off;
 #pragma unroll
                             for (int j = 0; j < 4; ++j)
                                 if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                             s += sred[(w * CO_TILE + tid) * 2];
                             q2 += sred[(w * CO_TILE + tid) * 2 + 1];
                         }
-                        float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + p.stat_tile_off +
+                        float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + stat_off +
                                               cur.ty * p.tiles_x + cur.tx) * 2;
                         d[0] = s;
                         d[1] = q2;
@@ -757,7 +771,7 @@ static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
         if (p.nseg > 2 && chunk >= p.chunk_begin[2]) s = 2;
         const int cs = (chunk - p.chunk_begin[s]) * 16 + kg * 8 + c;
         float v = 0.f;
-        if (cs < p.segC[s] && co < p.Cout) {
+        if (cs < p.segC[s] && co < p.Cout && p.tap_ky[t] >= 0) {   // tap_ky < 0: a window position this phase does not have
             int cin = cs;
             for (int j = 0; j < s; ++j) cin += p.segC[j];
             const int ky = p.tap_ky[t], kx = p.tap_kx[t];

@@ -100,6 +100,7 @@ struct Plan {
     bool head = false;             // conv_head_fwd_kernel: one output channel, 4x4, narrow map
     long long head_w_off = -1;     // >= 0: OIHW copy of the weights at this offset of the packed image
     bool bf3 = false;              // split-bf16 matrix path
+    bool fused_phases = false;     // transposed, split-bf16: the four sub-pixel phases are one launch
     const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
     int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
@@ -312,6 +313,10 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         pl.launches.push_back(L);
     } else {
         // y[co, 2q+ph] = sum over taps k with (ph + pad - k) even of x[ci, q + (ph + pad - k)/2] * w[ci,co,k]
+        // Split-bf16 path, even output size: the four phases share one pixel-tile grid and run as ONE launch whose
+        // cout tiles enumerate (phase, cout tile) -- the activation tile is fetched from HBM once instead of four
+        // times and the interleaved output lines of the phases meet in the XCD's L2 (conv_bf16x3.h, ConvKParams.nphase).
+        const bool fuse = pl.bk != nullptr && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 && !env_int("APAMD_NO_FUSED_PHASES", 0);
         for (int phy = 0; phy < 2; ++phy)
             for (int phx = 0; phx < 2; ++phx) {
                 Launch L;
@@ -339,9 +344,18 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                     }
                 L.dy0 = miny; L.dx0 = minx;
                 L.osy = L.osx = 2; L.oy_off = phy; L.ox_off = phx;
+                if (fuse) {
+                    // one launch for the four phases: every phase carries the whole 2 x 2 window (positions it does
+                    // not have get zero weights), in the fixed order t = ly * 2 + lx
+                    std::vector<Tap> win(4, Tap{-1, -1, 0, 0});
+                    for (int t = 0; t < 4; ++t) { win[t].ly = t >> 1; win[t].lx = t & 1; }
+                    for (const auto& t : L.taps) { win[t.ly * 2 + t.lx].ky = t.ky; win[t.ly * 2 + t.lx].kx = t.kx; }
+                    L.taps = win;
+                }
                 finish(L);
                 pl.launches.push_back(L);
             }
+        pl.fused_phases = fuse && pl.launches.size() == 4;
     }
     if (head_w) {
         pl.head_w_off = (pl.packed_floats + 3) & ~3LL;            // float4 loads
@@ -752,6 +766,18 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             p.cin_pad = pl.cin_pad;
             p.wfloats = pl.bk->wfloats(p.ntaps);
             p.ablate = env_int("APAMD_ABLATE", 0);
+            if (pl.fused_phases) {
+                // this launch (the geometry of phase 0, shared by all) covers the four phases: their weight blocks
+                // follow each other in the packed image, so the virtual cout tile indexes them directly
+                p.nphase = 4;
+                p.co_tiles_phase = pl.co_tiles;
+                p.co_tiles = 4 * pl.co_tiles;
+                for (int ph = 0; ph < 4; ++ph) {
+                    const Launch& Lp = pl.launches[ph];
+                    p.ph_dy0[ph] = Lp.dy0; p.ph_dx0[ph] = Lp.dx0; p.ph_oy[ph] = Lp.oy_off; p.ph_ox[ph] = Lp.ox_off;
+                    p.ph_stat[ph] = Lp.stat_tile_off;
+                }
+            }
             p.tap_bits = 0;
             if (pl.bk->K == 0) {
                 if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);
@@ -764,12 +790,13 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes
                 return fail(AP_ERR_UNSUPPORTED, "split-bf16 path: %d x %d planes are too large", d->H, d->W);
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
-            long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * pl.co_tiles;
+            long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * p.co_tiles;
             const int cus = env_int("APAMD_BF3_BLOCKS", num_cus());
             if (nblk > cus) nblk = cus;
             void* args[] = {&p};
             hipError_t e = hipLaunchKernel(kern->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
             if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
+            if (pl.fused_phases) break;
         }
         return AP_OK;
     }

@@ -66,6 +66,11 @@ struct ConvKParams {
     int wfloats;          // floats of one packed (co_tile, chunk) weight block, padded to 256
     int ablate;           // debugging/ablation only (APAMD_ABLATE): 1 no refill, 2 no barrier, 4 MFMA-only, 8 no epilogue
     unsigned tap_bits;    // K == 0 kernels only (sub-pixel phases, <= 4 taps): bit 2t = ly, bit 2t+1 = lx of tap t
+    // conv_bf16x3 only: the four sub-pixel phases of a stride-2 transposed convolution as ONE launch.  The cout tile
+    // index runs over nphase * co_tiles_phase "virtual" tiles (phase-major); phase ph overrides dy0 / dx0 / oy_off /
+    // ox_off / stat_tile_off with its table entry.  nphase <= 1: plain launch, the scalar fields above apply.
+    int nphase, co_tiles_phase;
+    int ph_dy0[4], ph_dx0[4], ph_oy[4], ph_ox[4], ph_stat[4];
 };
 
 // K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a
