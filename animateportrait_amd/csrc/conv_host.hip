@@ -9,6 +9,7 @@
 #include "conv_bf16x3.h"
 #include "conv_small.h"
 #include "conv_head.h"
+#include "conv_tsmall.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -98,7 +99,8 @@ struct Plan {
     int direct_cop = 0;            // > 0: conv_direct_f32<K, direct_cop> instead of the implicit-GEMM kernel
     bool small = false;            // conv_small_f32: narrow 3x3 layers on the vector ALUs
     bool head = false;             // conv_head_fwd_kernel: one output channel, 4x4, narrow map
-    long long head_w_off = -1;     // >= 0: OIHW copy of the weights at this offset of the packed image
+    bool tsmall = false;           // conv_tsmall_f32: transposed 4x4 stride 2 with 1..4 output channels
+    long long head_w_off = -1;     // >= 0: plain copy of the caller's weights at this offset of the packed image
     bool bf3 = false;              // split-bf16 matrix path
     bool fused_phases = false;     // transposed, split-bf16: the four sub-pixel phases are one launch
     const Bf3Kernel* bk = nullptr;
@@ -199,6 +201,10 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     const bool head_w = !rowk && !d->transposed && d->stride == 1 && K == 4 && d->Cout == 1 && d->nsrc == 1 && pl.Cin >= 64 &&
                         d->w_layout == AP_W_OIHW && !d->w_flip && d->pad == 1;
     pl.head = head_w && d->W <= kHeadMaxW && !env_int("APAMD_NO_HEAD", 0);
+    // ConvTranspose2d(C, 1..4, 4, 2, 1): the data gradient of the PatchGAN's first layer w.r.t. the frame (conv_tsmall.h);
+    // same arrangement -- the IOHW weights ride behind the regular image
+    pl.tsmall = !rowk && d->transposed && d->stride == 2 && K == 4 && d->pad == 1 && d->output_padding == 0 && d->Cout <= 4 &&
+                d->nsrc == 1 && d->w_layout == AP_W_IOHW && !d->w_flip && !env_int("APAMD_NO_TSMALL", 0);
     // narrow 3x3 layers (landmark encoder): memory streams, one lane per output pixel (conv_small.h)
     if (!rowk && !d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
         d->w_layout == AP_W_OIHW && !d->w_flip && !env_int("APAMD_NO_SMALL", 0)) {
@@ -357,9 +363,9 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
             }
         pl.fused_phases = fuse && pl.launches.size() == 4;
     }
-    if (head_w) {
+    if (head_w || pl.tsmall) {
         pl.head_w_off = (pl.packed_floats + 3) & ~3LL;            // float4 loads
-        pl.packed_floats = pl.head_w_off + (long long)pl.Cin * K * K;
+        pl.packed_floats = pl.head_w_off + (long long)pl.Cin * d->Cout * K * K;
     }
     return AP_OK;
 }
@@ -620,6 +626,10 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         snprintf(buf, buflen, "HeadCfg<%d>", d->KH);
         return AP_OK;
     }
+    if (pl.tsmall) {
+        snprintf(buf, buflen, "TSmallCfg<%d>", d->Cout);
+        return AP_OK;
+    }
     if (pl.bf3) {
         snprintf(buf, buflen, "%s", pl.bk->name);
         return AP_OK;
@@ -688,7 +698,7 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
         if (rc) return rc;
     }
     if (pl.head_w_off >= 0) {
-        hipError_t e = hipMemcpyAsync(packed + pl.head_w_off, weight, (size_t)pl.Cin * d->KH * d->KW * sizeof(float),
+        hipError_t e = hipMemcpyAsync(packed + pl.head_w_off, weight, (size_t)pl.Cin * d->Cout * d->KH * d->KW * sizeof(float),
                                       hipMemcpyDeviceToDevice, (hipStream_t)stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "pack (head copy) weights: %s", hipGetErrorString(e));
     }
@@ -707,6 +717,20 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "segment %d: mean and rstd must be given together", s);
         if (d->src[s].act < 0 || d->src[s].act > 2) return fail(AP_ERR_INVALID, "segment %d: act %d", s, d->src[s].act);
+    }
+    if (pl.tsmall && !stat_partials) {
+        TSmallParams p;
+        memset(&p, 0, sizeof(p));
+        p.src.data = d->src[0].data; p.src.mean = d->src[0].mean; p.src.rstd = d->src[0].rstd;
+        p.src.C = d->src[0].C; p.src.act = d->src[0].act;
+        p.N = d->N; p.C = pl.Cin; p.H = d->H; p.W = d->W; p.Cout = d->Cout;
+        p.w = packed + pl.head_w_off; p.bias = bias; p.act = d->act; p.y = y;
+        if (d->N > 65535 || (d->H + 7) / 8 > 65535) return fail(AP_ERR_UNSUPPORTED, "conv_tsmall: grid too large");
+        const dim3 grid((d->W + 31) / 32, (d->H + 7) / 8, d->N);
+        if (d->Cout == 1) hipLaunchKernelGGL((conv_tsmall_f32<1>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (d->Cout == 2) hipLaunchKernelGGL((conv_tsmall_f32<2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_tsmall_f32<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("conv_tsmall_f32");
     }
     if (pl.head && !stat_partials) {      // (with a statistics epilogue wanted the layer stays on the general kernel)
         HeadParams p;

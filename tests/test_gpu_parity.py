@@ -360,6 +360,9 @@ CONV_CASES = [
     ([70], 1, 4, 1, 1, 'zero', False, 45, 23),
     ([16], 24, 3, 2, 1, 'zero', True, 9, 21),
     ([10], 12, 4, 2, 1, 'zero', True, 15, 16),
+    ([24], 2, 4, 2, 1, 'zero', True, 17, 45),          # few-output transposed 4x4 (D first-layer data gradient): conv_tsmall.h
+    ([64], 1, 4, 2, 1, 'zero', True, 32, 32),
+    ([9], 3, 4, 2, 1, 'zero', True, 8, 33),
 ]
 
 
