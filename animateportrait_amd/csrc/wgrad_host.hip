@@ -7,7 +7,9 @@
 #include "conv_head.h"
 #include "wgrad_bf16x3.h"
 #include "wgrad_igemm.h"
+#include "wgrad_narrow.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -44,6 +46,8 @@ struct WgradPlan {
     // split-bf16 kernel (wgrad_bf16x3.h): operands as [n][part][row][x/8][channel] pixel-octet slots
     bool bf3 = false;
     int c_tiles = 0, Mp = 0, Cp = 0, GX8 = 0, AX8 = 0;
+    // streaming kernel for 1..2 input channels (wgrad_narrow.h): > 0 = output channels per workgroup
+    int narrow_cob = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
 };
 
 // split-bf16 instantiations by kernel size (stride 1)
@@ -89,6 +93,31 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     }
     const int S = d->stride, K = d->K;
     pl.Q = pl.Cin * K * K;
+    // 1..2 input channels (landmark encoder / PatchGAN first layer): one streaming pass, no operand copies (wgrad_narrow.h)
+    {
+        const char* nn = getenv("APAMD_NO_NARROW_WGRAD");
+        int cob = 0;
+        if (d->nsrc == 1 && d->g.mean == nullptr && d->g.act == AP_ACT_NONE && !(nn && atoi(nn))) {
+            if (K == 3 && S == 1 && pl.Cin == 1) cob = 8;
+            else if (K == 4 && S == 2 && pl.Cin == 1) cob = 4;
+            else if (K == 4 && S == 2 && pl.Cin == 2) cob = 4;
+        }
+        if (cob) {
+            pl.narrow_cob = cob;
+            const int groups = (d->M + cob - 1) / cob;
+            int gwc = 1, sh = 0;
+            while (gwc < d->GW && gwc < 256) { gwc <<= 1; ++sh; }
+            pl.gwc = gwc; pl.gwc_shift = sh; pl.rpi = 256 / gwc;
+            const long long total_rows = (long long)d->N * d->GH;
+            long long P = std::max<long long>(1, 1024 / groups);
+            long long rpb = (total_rows + P - 1) / P;
+            rpb = (rpb + pl.rpi - 1) / pl.rpi * pl.rpi;
+            pl.rows_per_block = (int)rpb;
+            pl.P = (int)((total_rows + rpb - 1) / rpb);
+            pl.part_floats = (long long)pl.P * d->M * pl.Q;
+            return AP_OK;
+        }
+    }
     const char* nob = getenv("APAMD_NO_BF16X3");
     if (d->precision == AP_PRECISION_BF16X3 && S == 1 && (K == 3 || K == 4) && d->M >= 48 && pl.Cin >= 32 &&
         !(nob && atoi(nob))) {
@@ -246,6 +275,26 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
+    }
+    if (pl.narrow_cob) {
+        WgradNarrowParams p;
+        memset(&p, 0, sizeof(p));
+        p.src.data = d->src[0].data; p.src.mean = d->src[0].mean; p.src.rstd = d->src[0].rstd;
+        p.src.C = d->src[0].C; p.src.act = d->src[0].act;
+        p.g = d->g.data;
+        p.N = d->N; p.M = d->M; p.GH = d->GH; p.GW = d->GW; p.H = d->H; p.W = d->W; p.pad = d->pad; p.pad_mode = d->pad_mode;
+        p.rows_per_block = pl.rows_per_block; p.gwc = pl.gwc; p.gwc_shift = pl.gwc_shift; p.rpi = pl.rpi;
+        p.partial = workspace;
+        const dim3 grid(pl.P, (d->M + pl.narrow_cob - 1) / pl.narrow_cob);
+        if (d->K == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, 1, 1, 8>), grid, dim3(256), 0, stream, p);
+        else if (pl.Cin == 1) hipLaunchKernelGGL((wgrad_narrow_kernel<4, 2, 1, 4>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((wgrad_narrow_kernel<4, 2, 2, 4>), grid, dim3(256), 0, stream, p);
+        rc = check_launch("wgrad_narrow_kernel");
+        if (rc) return rc;
+        const long long n = (long long)d->M * pl.Q;
+        int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.P, n, dw);
+        return check_launch("wgrad_reduce_kernel");
     }
     if (pl.bf3) {
         const WgradBf3Kernel* bk = nullptr;

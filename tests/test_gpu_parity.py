@@ -419,7 +419,9 @@ BWD_CASES = [
     ([3], 64, 7, 1, 3, 'reflect', False, 40, 40),
     ([16], 1, 7, 1, 3, 'reflect', False, 20, 50),
     ([12], 20, 3, 2, 1, 'zero', False, 36, 40),
-    ([2], 64, 4, 2, 1, 'zero', False, 64, 64),
+    ([2], 64, 4, 2, 1, 'zero', False, 64, 64),         # 1..2 input channels: streaming weight gradient (wgrad_narrow.h)
+    ([1], 64, 4, 2, 1, 'zero', False, 36, 40),
+    ([1], 8, 3, 1, 1, 'zero', False, 40, 70),
     ([16], 48, 4, 1, 1, 'zero', False, 32, 32),
     ([32], 1, 4, 1, 1, 'zero', False, 31, 31),
     ([96], 1, 4, 1, 1, 'zero', False, 31, 31),

@@ -16,6 +16,13 @@ LAYERS = [
     ('final 64->1 k7 @256', [64], 1, 7, 1, 3, ops.PAD_REFLECT, 256),
     ('D 256->512 k4 @32', [256], 512, 4, 1, 1, ops.PAD_ZERO, 32),
     ('D 1->64 k4s2 @256', [1], 64, 4, 2, 1, ops.PAD_ZERO, 256),
+    ('D 2->64 k4s2 @256', [2], 64, 4, 2, 1, ops.PAD_ZERO, 256),
+    ('D 64->128 k4s2 @128', [64], 128, 4, 2, 1, ops.PAD_ZERO, 128),
+    ('stem 3->32 k7 @256', [3], 32, 7, 1, 3, ops.PAD_REFLECT, 256),
+    ('land 1->8 k3 @256 (x2 batch)', [1], 8, 3, 1, 1, ops.PAD_ZERO, 256),
+    ('land 8->16 k3s2 @256', [8], 16, 3, 2, 1, ops.PAD_ZERO, 256),
+    ('land 16->16 k3s2 @128', [16], 16, 3, 2, 1, ops.PAD_ZERO, 128),
+    ('down 128->256 k3s2 @128', [128], 256, 3, 2, 1, ops.PAD_ZERO, 128),
 ]
 
 
