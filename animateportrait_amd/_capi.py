@@ -83,6 +83,9 @@ SIGNATURES = {
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
     'ap_conv_head_wgrad': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_conv_final_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
+    'ap_conv_final_wgrad': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.POINTER(ApWgradDesc)]),
     'ap_pad_materialize': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -8,6 +8,7 @@
 #include "wgrad_bf16x3.h"
 #include "wgrad_igemm.h"
 #include "wgrad_narrow.h"
+#include "wgrad_final.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -255,6 +256,49 @@ int ap_conv_head_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, 
     p.g = g; p.dw = dw;
     hipLaunchKernelGGL(conv_head_wgrad_kernel, dim3(src->C), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("conv_head_wgrad_kernel");
+}
+
+// pixel-tile split of wgrad_final_kernel: ~1024 workgroups in all
+static void final_split(int N, int C, int H, int W, int& tiles_x, int& tiles_y, int& tpb, int& P) {
+    tiles_x = (W + 63) / 64;
+    tiles_y = (H + 16 * kFinalStrips - 1) / (16 * kFinalStrips);
+    const long long total = (long long)N * tiles_x * tiles_y;
+    long long want = std::max<long long>(1, 1024 / std::max(C, 1));
+    if (want > total) want = total;
+    tpb = (int)((total + want - 1) / want);
+    P = (int)((total + tpb - 1) / tpb);
+}
+
+int64_t ap_conv_final_wgrad_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W) {
+    if (N < 1 || C < 1 || H < 1 || W < 1) return fail(AP_ERR_INVALID, "conv_final_wgrad: bad sizes");
+    int tx, ty, tpb, P;
+    final_split(N, C, H, W, tx, ty, tpb, P);
+    return (int64_t)P * C * 49;
+}
+
+int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
+                        int32_t pad_mode, float* workspace, float* dw, ap_stream_t stream_) {
+    if (!src || !src->data || !g || !workspace || !dw) return fail(AP_ERR_INVALID, "conv_final_wgrad: null pointer");
+    if ((src->mean == nullptr) != (src->rstd == nullptr)) return fail(AP_ERR_INVALID, "conv_final_wgrad: mean/rstd mismatch");
+    if (K != 7 || pad != 3 || N < 1 || src->C < 1 || src->C > 65535 || H < 1 || W < 1)
+        return fail(AP_ERR_UNSUPPORTED, "conv_final_wgrad: built for 7x7 pad-3 layers with one output channel (K=%d, pad=%d)", K, pad);
+    if (pad_mode == AP_PAD_REFLECT && (pad >= H || pad >= W)) return fail(AP_ERR_INVALID, "conv_final_wgrad: reflection pad too large");
+    if (src->act < 0 || src->act > 2) return fail(AP_ERR_INVALID, "conv_final_wgrad: act %d", src->act);
+    hipStream_t stream = (hipStream_t)stream_;
+    WgradFinalParams p;
+    memset(&p, 0, sizeof(p));
+    p.src.data = src->data; p.src.mean = src->mean; p.src.rstd = src->rstd; p.src.C = src->C; p.src.act = src->act;
+    p.g = g; p.N = N; p.C = src->C; p.H = H; p.W = W; p.pad_mode = pad_mode;
+    int P;
+    final_split(N, src->C, H, W, p.tiles_x, p.tiles_y, p.tiles_per_block, P);
+    p.partial = workspace;
+    hipLaunchKernelGGL(wgrad_final_kernel, dim3(P, src->C), dim3(256), 0, stream, p);
+    int rc = check_launch("wgrad_final_kernel");
+    if (rc) return rc;
+    const long long n = (long long)src->C * 49;
+    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, P, n, dw);
+    return check_launch("wgrad_reduce_kernel");
 }
 
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {

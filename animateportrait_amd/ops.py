@@ -493,6 +493,23 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
         C.check(C.lib().ap_conv_head_wgrad(ctypes.byref(s), _ptr(g.data), n, f.data.shape[2], f.data.shape[3], k, pad,
                                            _ptr(dw), _stream()), 'conv_head_wgrad')
         return dw
+    if (m == 1 and k == 7 and stride == 1 and pad == 3 and len(srcs) == 1 and cin >= 16 and not g.virtual and
+            g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k) and not os.environ.get('APAMD_NO_FINAL_WGRAD')):
+        # the generator's last layer: vector-ALU kernel, window through LDS (wgrad_final.h)
+        f = srcs[0]
+        _require_device(f.data, 'wgrad source')
+        _require_device(g.data, 'wgrad gradient')
+        s = C.ApSrc()
+        s.data, s.C, s.act = f.data.data_ptr(), cin, f.act
+        if f.virtual:
+            s.mean, s.rstd = f.mean.data_ptr(), f.rstd.data_ptr()
+        h, w = f.data.shape[2:]
+        ws = torch.empty(C.check(C.lib().ap_conv_final_wgrad_workspace_floats(n, cin, h, w), 'conv_final_wgrad_ws'),
+                         dtype=torch.float32, device=g.data.device)
+        dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+        C.check(C.lib().ap_conv_final_wgrad(ctypes.byref(s), _ptr(g.data), n, h, w, k, pad, pad_mode, _ptr(ws), _ptr(dw),
+                                            _stream()), 'conv_final_wgrad')
+        return dw
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
         return _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
     d = C.ApWgradDesc()

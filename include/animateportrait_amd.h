@@ -214,6 +214,12 @@ typedef struct ap_wgrad_desc {
  * per input channel, fixed summation order, no workspace.  (Its forward is a plan of ap_conv2d_fwd.) */
 int ap_conv_head_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
                        float* dw, ap_stream_t stream);
+/* Weight gradient of a one-output-channel 7x7 pad-3 layer (the generator's last layer, networks.py:1277-1279):
+ * dw[0][c][ky][kx] = sum_{n,y,x} g[n,0,y,x] * pad3(act(IN(src)))[n,c,y+ky,x+kx]  (reflection or zero padding), on the vector
+ * ALUs with the input window staged through LDS; workspace: ap_conv_final_wgrad_workspace_floats() floats. */
+int64_t ap_conv_final_wgrad_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
+int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
+                        int32_t pad_mode, float* workspace, float* dw, ap_stream_t stream);
 /* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
  * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);

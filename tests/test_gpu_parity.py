@@ -417,7 +417,8 @@ BWD_CASES = [
     ([6, 3], 40, 3, 1, 1, 'reflect', False, 33, 31),
     ([8, 16, 8], 130, 3, 1, 1, 'zero', False, 12, 70),
     ([3], 64, 7, 1, 3, 'reflect', False, 40, 40),
-    ([16], 1, 7, 1, 3, 'reflect', False, 20, 50),
+    ([16], 1, 7, 1, 3, 'reflect', False, 20, 50),      # last layer of the generator: wgrad_final.h
+    ([24], 1, 7, 1, 3, 'zero', False, 33, 64),
     ([12], 20, 3, 2, 1, 'zero', False, 36, 40),
     ([2], 64, 4, 2, 1, 'zero', False, 64, 64),         # 1..2 input channels: streaming weight gradient (wgrad_narrow.h)
     ([1], 64, 4, 2, 1, 'zero', False, 36, 40),
