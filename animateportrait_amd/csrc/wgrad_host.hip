@@ -34,6 +34,9 @@ static const std::vector<WgradKernel>& wgrad_registry() {
     static std::vector<WgradKernel> v = {
         wk<WgradCfg<1, 3, 2, 4, 2>>(), wk<WgradCfg<1, 4, 2, 4, 2>>(), wk<WgradCfg<1, 7, 2, 4, 2>>(),
         wk<WgradCfg<2, 3, 2, 4, 1>>(), wk<WgradCfg<2, 4, 2, 4, 1>>(),
+        wk<WgradCfg<1, 7, 1, 3, 2>>(),                 // 64 x 192 tiles: the 7x7 stems (Cin = 3: Q = 147)
+        wk<WgradCfg<2, 3, 1, 1, 1>>(),                 // 64 x 64 tiles: the landmark encoder's 8 -> 16 -> 16 layers
+        wk<WgradCfg<2, 3, 1, 4, 1>>(),                 // 64 x 256 tiles: 64-output stride-2 layers
     };
     return v;
 }
@@ -78,8 +81,20 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     if (!d) return fail(AP_ERR_INVALID, "wgrad: null descriptor");
     if (d->nsrc < 1 || d->nsrc > kMaxSeg) return fail(AP_ERR_INVALID, "wgrad: nsrc=%d", d->nsrc);
     if (d->N < 1 || d->M < 1 || d->GH < 1 || d->GW < 1 || d->H < 1 || d->W < 1) return fail(AP_ERR_INVALID, "wgrad: bad dims");
-    for (const auto& k : wgrad_registry())
-        if (k.S == d->stride && k.K == d->K) pl.k = &k;
+    {
+        // several tile shapes of a family: the one whose padded (M x Q) tile grid wastes least (the 7x7 stems are
+        // M = 32..64 by Q = 147: 64 x 192 tiles are 77 % full where 128 x 256 ones are 29 %)
+        int cin = 0;
+        for (int s = 0; s < d->nsrc; ++s) cin += d->src[s].C;
+        const long long Q = (long long)cin * d->K * d->K;
+        long long best = -1;
+        for (const auto& k : wgrad_registry())
+            if (k.S == d->stride && k.K == d->K) {
+                const long long padded = ((d->M + k.M_TILE - 1) / k.M_TILE) * (long long)k.M_TILE *
+                                         (((Q + k.Q_TILE - 1) / k.Q_TILE) * k.Q_TILE);
+                if (best < 0 || padded < best) { best = padded; pl.k = &k; }
+            }
+    }
     if (!pl.k) return fail(AP_ERR_UNSUPPORTED, "wgrad: no kernel for stride %d, k %d", d->stride, d->K);
     if (d->pad_mode == AP_PAD_REFLECT && (d->pad >= d->H || d->pad >= d->W))
         return fail(AP_ERR_INVALID, "wgrad: reflection pad %d >= input size", d->pad);

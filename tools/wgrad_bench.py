@@ -23,6 +23,7 @@ LAYERS = [
     ('land 8->16 k3s2 @256', [8], 16, 3, 2, 1, ops.PAD_ZERO, 256),
     ('land 16->16 k3s2 @128', [16], 16, 3, 2, 1, ops.PAD_ZERO, 128),
     ('down 128->256 k3s2 @128', [128], 256, 3, 2, 1, ops.PAD_ZERO, 128),
+    ('down 64->64 k3s2 @256', [64], 64, 3, 2, 1, ops.PAD_ZERO, 256),
 ]
 
 
