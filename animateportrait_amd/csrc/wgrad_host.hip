@@ -92,7 +92,8 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             if (k.S == d->stride && k.K == d->K) {
                 const long long padded = ((d->M + k.M_TILE - 1) / k.M_TILE) * (long long)k.M_TILE *
                                          (((Q + k.Q_TILE - 1) / k.Q_TILE) * k.Q_TILE);
-                if (best < 0 || padded < best) { best = padded; pl.k = &k; }
+                // (a smaller tile re-reads its operands more often: it must save at least 30 % of the padded work)
+                if (best < 0 || padded * 10 < best * 7) { best = padded; pl.k = &k; }
             }
     }
     if (!pl.k) return fail(AP_ERR_UNSUPPORTED, "wgrad: no kernel for stride %d, k %d", d->stride, d->K);
