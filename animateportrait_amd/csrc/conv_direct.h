@@ -10,10 +10,6 @@
 #pragma once
 #include "conv_igemm.h"
 
-#ifndef APAMD_DIRECT_B128
-#define APAMD_DIRECT_B128 1       // 0: compiler-generated window reads (kept for A/B measurements only)
-#endif
-
 namespace apamd {
 
 struct DirectKParams {
@@ -159,11 +155,10 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
 #pragma unroll
                 for (int t = 0; t < K * K; ++t) wreg[t] = wc[ci * K * K + t];
             }
-#if APAMD_DIRECT_B128
             // The window rows are read as whole 16-byte lanes, issued here by hand: left to itself the compiler drops
-            // the unused edge elements and splits every float4 into b64 / b32 pieces, and those, at the strips'
-            // 16-byte lane stride, hit 8 of the 32 banks -- a 4-way conflict on every read (the kernel ran 4x the
-            // LDS time of the conflict-free form).  All K rows of a channel are in flight before the single wait.
+            // the unused edge elements and splits every float4 into b64 / b32 pieces (48 LDS instructions per channel
+            // instead of 21, at a 16-byte lane stride that those narrower reads serve with bank conflicts): 396 us
+            // against 240 us for this form at B=16.  All K rows of a channel are in flight before the single wait.
             // (No "memory" clobber: the statements are ordered against the barriers that publish / recycle the
             // stage buffer as side-effecting asm; a clobber would turn the scalar weight loads into vector loads.)
             static_assert(NV == 3 && K == 7, "hand-issued window reads are written for 7x7");
@@ -183,18 +178,12 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
                                "+v"(q[4][0]), "+v"(q[4][1]), "+v"(q[4][2]), "+v"(q[5][0]), "+v"(q[5][1]), "+v"(q[5][2]),
                                "+v"(q[6][0]), "+v"(q[6][1]), "+v"(q[6][2]));
             }
-#endif
 #pragma unroll
             for (int ky = 0; ky < K; ++ky) {
                 float win[NV * 4];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-#if APAMD_DIRECT_B128
                     win[v * 4 + 0] = q[ky][v].x; win[v * 4 + 1] = q[ky][v].y; win[v * 4 + 2] = q[ky][v].z; win[v * 4 + 3] = q[ky][v].w;
-#else
-                    const float4 q = *reinterpret_cast<const float4*>(X + ci * PLANE + ky * IWS + v * 4);
-                    win[v * 4 + 0] = q.x; win[v * 4 + 1] = q.y; win[v * 4 + 2] = q.z; win[v * 4 + 3] = q.w;
-#endif
                 }
 #pragma unroll
                 for (int kx = 0; kx < K; ++kx) {
