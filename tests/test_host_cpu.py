@@ -41,6 +41,41 @@ def test_planning_queries_need_no_gpu():
     assert ops.ConvSpec([3], 64, 7, 1, 3, ops.PAD_REFLECT).out_size(256, 256) == (256, 256)
 
 
+def test_plans_of_the_special_layers_need_no_gpu():
+    """Host-side planning of the layers with their own kernels: packed-image sizes are independent of the map size
+    (weights are packed once per layer), workspaces are sized by the plan, unsupported forms are errors."""
+    from animateportrait_amd import ops, _capi
+    lib = _capi.lib()
+
+    def packed_floats(spec, h, w):
+        d = spec.desc(1, h, w)
+        return _capi.check(lib.ap_conv2d_packed_floats(ctypes.byref(d)), 'packed_floats')
+
+    head = ops.ConvSpec([512], 1, 4, 1, 1)                         # PatchGAN output layer: OIHW copy rides behind the image
+    assert packed_floats(head, 31, 31) == packed_floats(head, 64, 64) >= 512 * 16
+    first_dgrad = ops.ConvSpec([64], 2, 4, 2, 1, ops.PAD_ZERO, True, 0, ops.W_IOHW, False)
+    assert packed_floats(first_dgrad, 128, 128) == packed_floats(first_dgrad, 16, 16) >= 64 * 2 * 16
+    s2d = ops.s2d_spec(ops.ConvSpec([64], 128, 4, 2, 1))           # space-to-depth form: 2x2 stride 1 over 4C channels
+    assert s2d.cin_segments == (256,) and s2d.k == 2 and s2d.out_size(65, 65) == (64, 64)
+    with pytest.raises(RuntimeError, match='space-to-depth'):
+        ops.ConvSpec([64], 64, 2, 2, 0).out_size(16, 16)
+    assert ops.s2d_eligible(ops.ConvSpec([64], 128, 4, 2, 1), 128, 128)
+    assert not ops.s2d_eligible(ops.ConvSpec([2], 64, 4, 2, 1), 256, 256)
+    w = ops.s2d_weight(ops.torch.arange(2 * 3 * 16, dtype=ops.torch.float32).view(2, 3, 4, 4))
+    assert w.shape == (2, 12, 2, 2) and float(w[1, (1 * 2 + 0) * 3 + 2, 1, 0]) == float(48 + 2 * 16 + (2 * 1 + 1) * 4 + 0)
+    # weight-gradient workspaces: the streaming kernels need partial sums only
+    n = _capi.check(lib.ap_conv_final_wgrad_workspace_floats(32, 64, 256, 256), 'final_ws')
+    assert n % (64 * 49) == 0 and 0 < n <= 64 * 64 * 49
+    d = _capi.ApWgradDesc()
+    d.N, d.M, d.GH, d.GW, d.H, d.W, d.K, d.stride, d.pad, d.pad_mode, d.nsrc = 64, 8, 256, 256, 256, 256, 3, 1, 1, 0, 1
+    d.precision = ops.PRECISION_BF16X3
+    d.src[0].C = 1
+    narrow = _capi.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_ws')
+    assert narrow % (8 * 9) == 0 and narrow < 64 * 256 * 256            # no padded operand copies
+    d.src[0].C = 16
+    assert _capi.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_ws') > 64 * 16 * 256 * 256
+
+
 def test_planning_errors_are_reported():
     from animateportrait_amd import ops, _capi
     with pytest.raises(RuntimeError, match='stride'):
