@@ -35,6 +35,12 @@ class ApConvDesc(ctypes.Structure):
                 ('src', ApSrc * 3)]
 
 
+class ApOutView(ctypes.Structure):
+    _fields_ = [('nstride', ctypes.c_int64), ('cstride', ctypes.c_int64), ('rstride', ctypes.c_int32),
+                ('xstride', ctypes.c_int32), ('y_off', ctypes.c_int32), ('x_off', ctypes.c_int32),
+                ('OH', ctypes.c_int32), ('OW', ctypes.c_int32)]
+
+
 class ApWgradDesc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int32), ('M', ctypes.c_int32), ('GH', ctypes.c_int32), ('GW', ctypes.c_int32),
                 ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('K', ctypes.c_int32), ('stride', ctypes.c_int32),
@@ -65,6 +71,8 @@ SIGNATURES = {
     'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
     'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_fwd_view': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ApOutView), c_f32p, c_f32p, c_f32p,
+                                          ctypes.c_void_p]),
     'ap_instnorm_finalize': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                             c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,

@@ -91,7 +91,12 @@ def conv_backward(tape, layer, srcs, out, norm, act):
             if len(srcs) > 1:
                 w = (w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]).contiguous()
             packed = layer.packed_dgrad(i, spec, w)
-            g = ops.conv2d(spec, [gfeat], packed, None).data
+            if fold_pad and ops.dgrad_strip_eligible(spec, gfeat):
+                # 66-column padded gradient: two whole tile columns + a transposed 2-column strip (ops.conv2d_dgrad_strip)
+                packed_t = layer.packed_dgrad((i, 'T'), spec, lambda: w.transpose(2, 3).contiguous())
+                g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t)
+            else:
+                g = ops.conv2d(spec, [gfeat], packed, None).data
             tape.add(f, g, fold_pad)
         c0 += c
 

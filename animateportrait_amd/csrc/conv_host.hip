@@ -236,7 +236,8 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
             if (tall && small != tall && KT != 0) {
                 const long long tiles = (long long)d->N * ((pl.Hout + tall->TH - 1) / tall->TH) * ((pl.Wout + 31) / 32) *
                                         ((d->Cout + tall->CO_TILE - 1) / tall->CO_TILE);
-                if (tiles * 2 <= num_cus() && !env_int("APAMD_NO_SMALL_TILES", 0)) pl.bk = small;
+                // (also for maps no taller than the short tile: the column strip of a reflection-padded data gradient)
+                if ((tiles * 2 <= num_cus() || pl.Hout <= small->TH) && !env_int("APAMD_NO_SMALL_TILES", 0)) pl.bk = small;
             }
         }
         if (KT == 0 && K != 2 && K != 3 && K != 4) pl.bk = nullptr;
@@ -705,12 +706,32 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
     return AP_OK;
 }
 
+static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
+                           float* stat_partials, ap_stream_t stream);
+
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream) {
+    return conv2d_fwd_impl(d, nullptr, packed, bias, y, stat_partials, stream);
+}
+
+int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
+                       ap_stream_t stream) {
+    if (!view) return fail(AP_ERR_INVALID, "conv2d_fwd_view: null view");
+    return conv2d_fwd_impl(d, view, packed, bias, y, nullptr, stream);
+}
+
+static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
+                           float* stat_partials, ap_stream_t stream) {
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
+    if (view) {
+        if (!pl.bf3 || pl.fused_phases || pl.launches.size() != 1)
+            return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_view: only single-launch split-bf16 plans take an output window");
+        if (view->OH < 1 || view->OW < 1 || view->OH > pl.Hout || view->OW > pl.Wout)
+            return fail(AP_ERR_INVALID, "conv2d_fwd_view: window %dx%d outside the %dx%d output", view->OH, view->OW, pl.Hout, pl.Wout);
+    }
     if (d->presplit && !pl.bf3) return fail(AP_ERR_INVALID, "desc.presplit set for a layer that does not take split sources");
     for (int s = 0; s < d->nsrc; ++s) {
         if (!d->src[s].data) return fail(AP_ERR_INVALID, "segment %d: null data", s);
@@ -790,6 +811,15 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             p.cin_pad = pl.cin_pad;
             p.wfloats = pl.bk->wfloats(p.ntaps);
             p.ablate = env_int("APAMD_ABLATE", 0);
+            if (view) {
+                // output window: a sub-grid of the output, stored with the caller's strides (ap_out_view)
+                p.OH = view->OH; p.OW = view->OW;
+                p.tiles_x = (view->OW + 31) / 32;
+                p.tiles_y = (view->OH + pl.bk->TH - 1) / pl.bk->TH;
+                p.o_nstride = view->nstride; p.o_cstride = view->cstride; p.o_rstride = view->rstride;
+                p.osy = 1; p.oy_off = view->y_off;
+                p.osx = view->xstride; p.ox_off = view->x_off * view->xstride;
+            }
             if (pl.fused_phases) {
                 // this launch (the geometry of phase 0, shared by all) covers the four phases: their weight blocks
                 // follow each other in the packed image, so the virtual cout tile indexes them directly
@@ -814,7 +844,7 @@ int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias,
             if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes
                 return fail(AP_ERR_UNSUPPORTED, "split-bf16 path: %d x %d planes are too large", d->H, d->W);
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
-            long long nblk = (long long)d->N * L.tiles_y * L.tiles_x * p.co_tiles;
+            long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * p.co_tiles;
             const int cus = env_int("APAMD_BF3_BLOCKS", num_cus());
             if (nblk > cus) nblk = cus;
             void* args[] = {&p};

@@ -59,7 +59,7 @@ class ConvLayer(nn.Module):
         key = (self.weight._version, self.weight.data_ptr(), ops.WEIGHTS_EPOCH)
         hit = self._packed_dgrad.get(seg)
         if hit is None or hit[0] != key:
-            hit = (key, ops.pack_weights(spec, w))
+            hit = (key, ops.pack_weights(spec, w() if callable(w) else w))     # callable: built on a miss only
             self._packed_dgrad[seg] = hit
         return hit[1]
 

@@ -389,6 +389,57 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
     return Feat(y, act=out_act, pending=(partial, tiles))
 
 
+def _conv2d_view(spec, srcs, packed, out, view):
+    """ap_conv2d_fwd_view: the split-bf16 convolution ``spec`` of ``srcs`` into a window of ``out`` (no bias, no
+    activation, no statistics)."""
+    x0 = srcs[0].data
+    n, _, h, w = x0.shape
+    d = spec.desc(n, h, w, None, ACT_NONE)
+    d.presplit = 1
+    for i, f in enumerate(srcs):
+        d.src[i].data = presplit(f).data_ptr()
+        d.src[i].mean = d.src[i].rstd = None
+        d.src[i].act = ACT_NONE
+    C.check(C.lib().ap_conv2d_fwd_view(ctypes.byref(d), ctypes.byref(view), _ptr(packed), None, _ptr(out), _stream()),
+            'conv2d_fwd_view')
+
+
+def dgrad_strip_eligible(spec, g):
+    """spec: data-gradient operator of a reflection-padded 3x3 stride-1 layer (full correlation, pad 2), g: the plain
+    gradient Feat.  True when the padded-coordinate output is 32 m + 2 columns wide (the 64 x 64 maps of the ResNet
+    blocks: 66) and the operator runs on the split-bf16 path: see conv2d_dgrad_strip."""
+    if (spec.precision != PRECISION_BF16X3 or spec.k != 3 or spec.stride != 1 or spec.pad != 2 or spec.transposed or
+            len(spec.cin_segments) != 1 or g.virtual or os.environ.get('APAMD_NO_DGRAD_STRIP')):
+        return False
+    n, c, h, w = g.data.shape
+    if (w + 2) % 32 != 2 or w < 32 or h < 4 or c % 8:
+        return False
+    d = spec.desc(n, h, w, None, ACT_NONE)
+    return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
+
+
+def conv2d_dgrad_strip(spec, g, packed, packed_t):
+    """Padded-coordinate data gradient (N, Cin, H+2, W+2) of a reflection-padded 3x3 layer in two launches instead of a
+    three-tile-column one: W+2 = 32 m + 2, so the last tile column of a plain launch would hold 2 of 32 columns.
+    * the two last padded columns depend on the two last gradient columns only: the same operator on their
+      TRANSPOSE (N, C, 2, H) with transposed taps (``packed_t``) yields a (4, H+2) map whose rows are the padded
+      columns W-2 .. W+1; it is stored transposed into place (rows 0, 1 are partial sums of columns W-2, W-1);
+    * the main launch then writes columns 0 .. W-1 (whole tile columns), overwriting those two."""
+    n, c, h, w = g.data.shape
+    hp, wp = h + 2, w + 2
+    out = torch.empty((n, spec.cout, hp, wp), dtype=torch.float32, device=g.data.device)
+    t = Feat(g.data[:, :, :, w - 2:].transpose(2, 3).contiguous())
+    v = C.ApOutView()
+    v.nstride, v.cstride = spec.cout * hp * wp, hp * wp
+    v.rstride, v.xstride, v.y_off, v.x_off, v.OH, v.OW = 1, wp, w - 2, 0, 4, hp
+    _conv2d_view(spec, [t], packed_t, out, v)
+    v2 = C.ApOutView()
+    v2.nstride, v2.cstride = spec.cout * hp * wp, hp * wp
+    v2.rstride, v2.xstride, v2.y_off, v2.x_off, v2.OH, v2.OW = wp, 1, 0, 0, hp, w
+    _conv2d_view(spec, [g], packed, out, v2)
+    return out
+
+
 def materialize(f, residual=None, emit_xs=None):
     """out = act(IN(f.data)) [+ residual]; residual may itself be a virtual Feat (act must be NONE).
     emit_xs: also write the split-bf16 copy of ``out`` in the same pass (default: when a split-bf16 convolution

@@ -101,6 +101,19 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
  * pre-activation output for every (n, cout) (InstanceNorm2d statistics, networks.py:33-34). */
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream);
+/* ap_conv2d_fwd into a window: only output pixels oy < OH, ox < OW are computed, and y[n][co][oy][ox] is stored at
+ *     y + n*nstride + co*cstride + (oy + y_off)*rstride + (ox + x_off)*xstride          (elements).
+ * Split-bf16 single-launch plans only (stride-1 / stride-2 convolutions, not transposed), no statistics epilogue.
+ * Used for the data gradient of the reflection-padded 3x3 layers (networks.py:2329-2421), whose padded-coordinate
+ * output is 66 = 2 x 32 + 2 columns wide: the main launch computes columns 0..63 (two tile columns instead of
+ * three), a second launch on the transposed last gradient columns writes the 2-column rest (rstride = 1,
+ * xstride = row length). */
+typedef struct ap_out_view {
+    int64_t nstride, cstride;
+    int32_t rstride, xstride, y_off, x_off, OH, OW;
+} ap_out_view;
+int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
+                       ap_stream_t stream);
 
 /* Split-bf16 path (precision = AP_PRECISION_BF16X3, wide 3x3 layers): the convolution consumes its sources as
  * split tensors XS[n][head|tail][C/8][H*W + 1][8 x bf16] (the last 16-byte slot of every plane is all-zero and

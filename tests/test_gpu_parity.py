@@ -428,6 +428,9 @@ BWD_CASES = [
     ([96], 1, 4, 1, 1, 'zero', False, 31, 31),
     ([70], 1, 4, 1, 1, 'zero', False, 32, 23),
     ([16], 24, 3, 2, 1, 'zero', True, 9, 21),
+    # reflection-padded 3x3 on the split-bf16 path, padded gradient 32 m + 2 columns wide: main launch + transposed strip
+    ([64], 64, 3, 1, 1, 'reflect', False, 32, 32),
+    ([48, 16], 96, 3, 1, 1, 'reflect', False, 20, 64),
 ]
 
 
