@@ -230,6 +230,28 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
 
     f32x16 acc[MT][NT];
     bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    // Dense stride-1 taps share activation fragments vertically: the fragment of pixel row q at tap (ky+1, kx) is the
+    // one of row q+1 at tap (ky, kx).  With the taps walked column by column (kx outer, ky inner) a wave keeps a sliding
+    // window of NT + K - 1 row fragments per kx and reads ONE new row per tap (NT at a column change) instead of NT.
+    // Used for the 4x4 layers (MT = 1: 22 instead of 40 ds_read_b128 per tap column, 196 -> 170..185 us on the
+    // PatchGAN's 256 -> 512 layer); the 3x3 kernel (MT = 2: 72 instead of 108 per chunk) measured no faster with it --
+    // its fragment reads already hide under the MFMAs -- and keeps the plain tap order.
+    constexpr bool WIN = K == 4 && !C::ROW && S == 1;
+    constexpr int WR = WIN ? NT + K - 1 : 1;
+    bf16x8 wh[2][WR], wl[2][WR];                                   // [kx parity][window row]
+    auto fetch_a = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
+        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
+            al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+        }
+    };
+    auto fetch_brow = [&](int stage_buf, int kx, int j, int wb) __attribute__((always_inline)) {
+        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot + j * IW + kx;
+        wh[wb][j] = *reinterpret_cast<const bf16x8*>(Xc);
+        wl[wb][j] = *reinterpret_cast<const bf16x8*>(Xc + XP);
+    };
     auto fetch = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
         const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
         const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
@@ -265,6 +287,20 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             else bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
         }
     };
+    // the same for the windowed form: fragment r of tap (0, 0) -- weights into buffer `buf`, window rows into `wb`
+    auto fetch_one_win = [&](int stage_buf, int buf, int wb, int r) __attribute__((always_inline)) {
+        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
+        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
+        if (r < 2 * MT) {
+            const int m = r >> 1;
+            if (r & 1) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + 0) * 2) * CO_TILE + m * 32);
+            else ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + 0) * 2) * CO_TILE + m * 32);
+        } else {
+            const int q = (r - 2 * MT) >> 1;
+            if (r & 1) wl[wb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + q * IW);
+            else wh[wb][q] = *reinterpret_cast<const bf16x8*>(Xc + q * IW);
+        }
+    };
 
     Bf3Tile cur, nxt;
     int cgoff[NIT], ngoff[NIT];
@@ -288,31 +324,66 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         auto stage = [&](auto ptag, int c) __attribute__((always_inline)) {
             constexpr int P = decltype(ptag)::value;
             constexpr int FP = (XPF && (TMAX & 1)) ? P : 0;        // register buffer of tap 0
-            if (!XPF || c == 0) fetch(P, 0, FP);
+            constexpr int WP = (XPF && (K & 1)) ? P : 0;           // window buffer of kx = 0
+            if (!XPF || c == 0) {
+                if constexpr (WIN) {
+                    fetch_a(P, 0, FP);
 #pragma unroll
-            for (int t = 0; t < TMAX; ++t) {
-                const int cb = (t + FP) & 1;
-                const bool last = t == TMAX - 1;
+                    for (int q = 0; q < NT; ++q) fetch_brow(P, 0, q, WP & 1);
+                } else {
+                    fetch(P, 0, FP);
+                }
+            }
+#pragma unroll
+            for (int tp = 0; tp < TMAX; ++tp) {
+                // windowed form: taps column by column; t = the tap's index in the weight image
+                const int kx = WIN ? tp / K : 0, ky = WIN ? tp % K : 0;
+                const int t = WIN ? ky * K + kx : tp;
+                const int cb = (tp + FP) & 1, wb = (kx + WP) & 1;
+                const bool last = tp == TMAX - 1;
                 auto mfma_one = [&](int i) __attribute__((always_inline)) {
                     // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
                     // never wait on each other's result (small terms first)
                     const int g = i / (MT * NT), m = (i % (MT * NT)) / NT, q = i % NT;
-                    if (g == 0) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
-                    else if (g == 1) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bl[cb][q], acc[m][q], 0, 0, 0);
-                    else acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], bh[cb][q], acc[m][q], 0, 0, 0);
+                    const bf16x8 xh = WIN ? wh[wb][WIN ? ky + q : 0] : bh[cb][q];
+                    const bf16x8 xl = WIN ? wl[wb][WIN ? ky + q : 0] : bl[cb][q];
+                    if (g == 0) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], xh, acc[m][q], 0, 0, 0);
+                    else if (g == 1) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], xl, acc[m][q], 0, 0, 0);
+                    else acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], xh, acc[m][q], 0, 0, 0);
                 };
                 constexpr int NM = 3 * MT * NT, NRD = 2 * MT + 2 * NT;
                 if (!last) {
-                    fetch(P, t + 1, cb ^ 1);
+                    int nrd = NRD;                                  // LDS reads issued for the next tap
+                    if constexpr (WIN) {
+                        const int kx2 = (tp + 1) / K, ky2 = (tp + 1) % K;
+                        fetch_a(P, ky2 * K + kx2, cb ^ 1);
+                        if (kx2 == kx) {
+                            fetch_brow(P, kx, ky2 + NT - 1, wb);
+                            nrd = 2 * MT + 2;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < NT; ++q) fetch_brow(P, kx2, q, wb ^ 1);
+                        }
+                    } else {
+                        fetch(P, t + 1, cb ^ 1);
+                    }
 #pragma unroll
                     for (int i = 0; i < NM; ++i) mfma_one(i);
                     // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
                     // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
-                    constexpr int PER = (NM + NRD - 1) / NRD;
+                    constexpr int PER = (NM + NRD - 1) / NRD, NRD1 = 2 * MT + 2, PER1 = (NM + NRD1 - 1) / NRD1;
+                    if (nrd == NRD) {
 #pragma unroll
-                    for (int i = 0; i < NRD; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
-                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // PER MFMAs
+                        for (int i = 0; i < NRD; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one LDS read
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);    // PER MFMAs
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NRD1; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER1, 0);
+                        }
                     }
                 } else {
                     // every fragment of this stage is in registers: the stage buffer can be refilled, and the
@@ -342,7 +413,10 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                         if (XPF && do_fetch && i >= R0) {
 #pragma unroll
                             for (int rr = 0; rr < RPS; ++rr)
-                                if ((i - R0) * RPS + rr < NRD) fetch_one(P ^ 1, 0, cb ^ 1, (i - R0) * RPS + rr);
+                                if ((i - R0) * RPS + rr < NRD) {
+                                    if constexpr (WIN) fetch_one_win(P ^ 1, cb ^ 1, ((K & 1) ? (P ^ 1) : 0) & 1, (i - R0) * RPS + rr);
+                                    else fetch_one(P ^ 1, 0, cb ^ 1, (i - R0) * RPS + rr);
+                                }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
