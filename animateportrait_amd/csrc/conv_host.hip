@@ -68,6 +68,9 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
         bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
         bk<Bf3Cfg<1, 4, 1, 1, 4, 4>>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
         bk<Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>>("Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>"),   // 1x7 over row channels (7x7 stems)
+        // ... and its half-size tile (32 couts x 8 rows, 70 KB of LDS): two workgroups per CU, so that the output
+        // burst of one tile's epilogue runs under the other workgroup's MFMAs (the stems are write-bound: 2 chunks of K)
+        bk<Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>>("Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>"),
         // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
@@ -176,8 +179,9 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     }
     // 1..4 output channels, 7x7 'same' convolution: vector-ALU direct kernel (conv_direct.h)
     if (rowk) {
+        const bool two_per_cu = env_int("APAMD_STEM_SMALL", 1) != 0;
         for (const auto& k : bf3_registry())
-            if (k.ROW && k.K == K) pl.bk = &k;
+            if (k.ROW && k.K == K && (!pl.bk || (two_per_cu ? k.TH < pl.bk->TH : k.TH > pl.bk->TH))) pl.bk = &k;
         if (!pl.bk) return fail(AP_ERR_UNSUPPORTED, "no 1x%d row kernel", K);
     }
     // (the PatchGAN's 4x4 pad-1 head, 512 -> 1 on 30 x 30 outputs, was tried here too: 160 workgroups of 128 chunks
@@ -845,7 +849,8 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 return fail(AP_ERR_UNSUPPORTED, "split-bf16 path: %d x %d planes are too large", d->H, d->W);
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
             long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * p.co_tiles;
-            const int cus = env_int("APAMD_BF3_BLOCKS", num_cus());
+            // (two per CU when two stage sets fit its 160 KB of LDS)
+            const int cus = env_int("APAMD_BF3_BLOCKS", num_cus() * (2 * lds <= 160 * 1024 ? 2 : 1));
             if (nblk > cus) nblk = cus;
             void* args[] = {&p};
             hipError_t e = hipLaunchKernel(kern->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
