@@ -75,6 +75,9 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
         bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 4>"),
+        // the 4-tap form with a half-height tile (64 couts x 8 rows, 74 KB of LDS): two workgroups per CU for the
+        // launches whose tiles are short in K and heavy in output (fused phases, space-to-depth layers)
+        bk<Bf3Cfg<1, 0, 1, 2, 4, 2, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 2, 4>"),
     };
     return v;
 }
@@ -82,7 +85,7 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
 static const Bf3Kernel* bf3_for_taps(const Bf3Kernel* k, int ntaps) {
     if (k->K != 0) return k;
     for (const auto& e : bf3_registry())
-        if (e.K == 0 && e.S == k->S && e.TMAX == ntaps) return &e;
+        if (e.K == 0 && e.S == k->S && e.TMAX == ntaps && e.TH == k->TH) return &e;
     return nullptr;
 }
 
@@ -106,6 +109,7 @@ struct Plan {
     long long head_w_off = -1;     // >= 0: plain copy of the caller's weights at this offset of the packed image
     bool bf3 = false;              // split-bf16 matrix path
     bool fused_phases = false;     // transposed, split-bf16: the four sub-pixel phases are one launch
+    bool k0_small = false;         // run-time-tap family: the half-height 4-tap instantiation (two workgroups per CU)
     const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
     int Cin = 0, nchunks = 0, cin_pad = 0, co_tiles = 0;
@@ -237,6 +241,13 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                     if (!small || k.TH < small->TH) small = &k;
                 }
             pl.bk = tall;
+            if (KT == 0) {
+                // every launch of these plans has 4 taps (2x2 layers, 4x4 phases, fused 3x3 phases of an even output)
+                const bool all4 = K == 2 || K == 4 || (d->transposed && K == 3 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 &&
+                                                        !env_int("APAMD_NO_FUSED_PHASES", 0));
+                pl.k0_small = all4 && env_int("APAMD_K0_SMALL", 1) != 0;
+                if (pl.k0_small) pl.bk = small;
+            }
             if (tall && small != tall && KT != 0) {
                 const long long tiles = (long long)d->N * ((pl.Hout + tall->TH - 1) / tall->TH) * ((pl.Wout + 31) / 32) *
                                         ((d->Cout + tall->CO_TILE - 1) / tall->CO_TILE);
