@@ -54,7 +54,11 @@ struct Bf3Cfg {
     static constexpr int X_SLOTS = 2 * XP;                         // [part][kgroup][pixel]
     static int w_slots(int ntaps) { return 2 * ntaps * 2 * CO_TILE; }   // [part][tap][kgroup][cout], multiple of 64
     static constexpr int NIT = XP / 256 + (XP % 256 ? 1 : 0);      // DMA pieces per thread and part
-    static constexpr int EPI_FLOATS = 4 * 32 * 36 + WPX * CO_TILE * 2;  // epilogue patches + statistics
+    // epilogue: 32 x 36-float transposition patches (NPATCH per wave, so that two accumulator tiles are in flight
+    // between the LDS write and read phases) + statistics; they live in the free stage buffer of the tile's last chunk
+    static constexpr int W_BYTES_MAX = 2 * TMAX * 2 * CO_TILE * 16;
+    static constexpr int NPATCH = (NT % 2 == 0 && (8 * 32 * 36 + WPX * CO_TILE * 2) * 4 <= (2 * XP * 16 > W_BYTES_MAX ? 2 * XP * 16 : W_BYTES_MAX)) ? 2 : 1;
+    static constexpr int EPI_FLOATS = 4 * NPATCH * 32 * 36 + WPX * CO_TILE * 2;
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(CO_TILE % 16 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
     // the epilogue patches live in the (free) stage buffer of the tile's last chunk: its activation image, or --
@@ -443,8 +447,9 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
             float* const epi = C::EPI_IN_W ? reinterpret_cast<float*>(wbuf + pl * W_SLOTS)
                                            : reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
-            float* const patch = epi + wave * (32 * TS);
-            float* const sred = epi + 4 * 32 * TS;                             // [WPX][CO_TILE][2]
+            constexpr int NP = C::NPATCH;
+            float* const patch0 = epi + wave * (NP * 32 * TS);
+            float* const sred = epi + 4 * NP * 32 * TS;                        // [WPX][CO_TILE][2]
             const int n = cur.n;
             int cot = cur.cot, oy_off = p.oy_off, ox_off = p.ox_off, stat_off = p.stat_tile_off;
             if (p.nphase > 1) {                                // fused sub-pixel phases: (phase, cout tile of the phase)
@@ -458,37 +463,58 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             const int co_base = cot * CO_TILE + wco * MT * 32;
             const bool want_stats = p.stats != nullptr;
             const bool vec_ok = (p.o_rstride & 3) == 0 && p.osx == 1 && ox_off == 0;
+            const bool full = vec_ok && ox0 + 32 <= p.OW;                      // whole 32-pixel rows: no per-element edge tests
             const int prow = lane >> 3, pcol = (lane & 7) * 4;
+            const int oxv = ox0 + pcol;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+                float bvv[4];
+                long long cbase[4];
+                bool cokc[4];
 #pragma unroll
-                for (int q = 0; q < NT; ++q) {
+                for (int ps = 0; ps < 4; ++ps) {
+                    const int co = co_base + m * 32 + ps * 8 + prow;
+                    cokc[ps] = co < p.Cout;
+                    bvv[ps] = (p.bias != nullptr && cokc[ps]) ? p.bias[co] : 0.f;
+                    cbase[ps] = (long long)n * p.o_nstride + (long long)co * p.o_cstride + oxv * p.osx + ox_off;
+                }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q][r];
-                    const int oy = oy0 + wpx * NT + q;
+                for (int q0 = 0; q0 < NT; q0 += NP) {
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const int row = ps * 8 + prow;
-                        const int co = co_base + m * 32 + row;
-                        float4 v = *reinterpret_cast<const float4*>(patch + row * TS + pcol);
-                        const bool cok = co < p.Cout && oy < p.OH;
-                        const float bv = (p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f;
-                        float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
-                        const int oxv = ox0 + pcol;
-                        if (cok) {
-                            float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
-                                         (long long)(oy * p.osy + oy_off) * p.o_rstride + oxv * p.osx + ox_off;
+                    for (int b = 0; b < NP; ++b)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
-                            if (vec_ok && oxv + 3 < p.OW) {
-                                *reinterpret_cast<float4*>(dst) =
-                                    make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
-                            } else {
+                        for (int r = 0; r < 16; ++r)
+                            patch0[b * (32 * TS) + ((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q0 + b][r];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (oxv + j < p.OW) dst[j * p.osx] = actf(vv[j]);
+                    for (int b = 0; b < NP; ++b) {
+                        const int oy = oy0 + wpx * NT + q0 + b;
+                        const long long rowoff = (long long)(oy * p.osy + oy_off) * p.o_rstride;
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps) {
+                            const float4 v = *reinterpret_cast<const float4*>(patch0 + b * (32 * TS) + (ps * 8 + prow) * TS + pcol);
+                            const float bv = bvv[ps];
+                            const float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
+                            if (cokc[ps] && oy < p.OH) {
+                                float* dst = p.y + cbase[ps] + rowoff;
+                                if (full) {
+                                    s4[ps] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
+                                    q4[ps] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
+                                    *reinterpret_cast<float4*>(dst) =
+                                        make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
+                                    if (vec_ok && oxv + 3 < p.OW) {
+                                        *reinterpret_cast<float4*>(dst) =
+                                            make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
+                                    } else {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            if (oxv + j < p.OW) dst[j * p.osx] = actf(vv[j]);
+                                    }
+                                }
                             }
                         }
                     }
