@@ -169,6 +169,13 @@ def batch_split_forward(tape, f, b):
 
 
 # ------------------------------------------------------------------------------ autograd.Function wrappers
+def _weights_stamp(params):
+    """What the backward pass assumes unchanged since forward: it reads ``layer.weight`` live (the packed copies are
+    rebuilt from it), so an optimiser step in between would silently give gradients of a different network, where
+    torch.autograd raises its saved-tensor version error."""
+    return (ops.WEIGHTS_EPOCH, tuple(p._version for p in params))
+
+
 class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, n_inputs, input_needs_grad, *tensors):
@@ -178,12 +185,20 @@ class _NetFn(torch.autograd.Function):
             out = net._run(tape, input_needs_grad, *inputs)
         ctx.tape, ctx.net, ctx.out_feat = tape, net, out
         ctx.n_inputs, ctx.params = n_inputs, params
+        ctx.stamp = _weights_stamp(params)
         ctx.in_feat = getattr(net, '_last_input_feat', None)
         return out.data
 
     @staticmethod
     def backward(ctx, gout):
         tape = ctx.tape
+        if tape is None:
+            raise RuntimeError('animateportrait_amd: backward through this network a second time: the layer tape is '
+                               'freed after the first pass (retain_graph is not supported); run forward again')
+        if _weights_stamp(ctx.params) != ctx.stamp:
+            raise RuntimeError('animateportrait_amd: a parameter of %s was modified (optimizer.step / in-place write) '
+                               'between forward and backward; its gradients would belong to different weights'
+                               % type(ctx.net).__name__)
         with torch.no_grad():
             tape.add(ctx.out_feat, gout.contiguous(), 0)
             tape.backward()
@@ -199,8 +214,16 @@ class _NetFn(torch.autograd.Function):
 
 
 def generator_apply(net, input, land1, land2, motion, flow, ifmask):
+    """The reference generator is differentiable w.r.t. every input; this path defines the gradient w.r.t. the image
+    ``input`` (the three stems' data gradients) and refuses the others instead of silently returning zeros: no caller
+    on the hot path asks for them (land / motion / flow / ifmask come from the data layer and netF under no_grad,
+    geomgm_ifw_fore_model.py:443-505), and ap_warp_concat_bwd has no gradient w.r.t. the sampling grid."""
+    for t, name in ((land1, 'land1'), (land2, 'land2'), (motion, 'motion'), (flow, 'flow'), (ifmask, 'ifmask')):
+        if t.requires_grad:
+            raise NotImplementedError('animateportrait_amd generator: gradient w.r.t. %s is not defined on the HIP '
+                                      'path (detach it)' % name)
     params = [p for p in net.parameters()]
-    return _NetFn.apply(net, 6, False, input, land1, land2, motion, flow, ifmask, *params)
+    return _NetFn.apply(net, 6, bool(input.requires_grad), input, land1, land2, motion, flow, ifmask, *params)
 
 
 def discriminator_apply(net, input):

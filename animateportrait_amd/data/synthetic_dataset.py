@@ -32,7 +32,7 @@ def make_train_batch(batch, seed=1234, rank=0, size=256):
         'iw_flow': d['flow'], 'if_mask': d['ifmask'],
         'fakeB_static': torch.rand(batch, 1, size, size, generator=gen) * 2 - 1,
         'mask': make_ifmask(batch, gen, size),
-        'image_paths': ['synthetic_%d_%d' % (rank, i) for i in range(batch)],
+        'image_paths': ['synthetic_r%d_s%d_%d' % (rank, seed, i) for i in range(batch)],
     }
     m2 = make_ifmask(batch, gen, size)
     out['if_mask2'] = m2

@@ -7,7 +7,7 @@ from collections import OrderedDict
 
 import torch
 
-from .. import networks
+from .. import networks, parallel
 
 
 class BaseModel(ABC):
@@ -45,6 +45,9 @@ class BaseModel(ABC):
         if not self.isTrain or opt.continue_train:
             load_suffix = 'iter_%d' % opt.load_iter if opt.load_iter > 0 else opt.epoch
             self.load_networks(load_suffix)
+        # one process per GPU: every rank built (and randomly initialised) its own replica; start all of them from
+        # rank 0's weights, as the reference's single replicated nn.DataParallel module does (networks.py:115-118)
+        parallel.broadcast_model(self)
         self.print_networks(opt.verbose)
 
     def eval(self):
@@ -68,6 +71,8 @@ class BaseModel(ABC):
         return OrderedDict((n, getattr(self, n)) for n in self.visual_names if hasattr(self, n))
 
     def get_current_losses(self):                                     # :136-142
+        from .sparse_image_warp import check_status
+        check_status()      # deferred singular-TPS check: this is a natural sync point (the floats below sync anyway)
         out = OrderedDict()
         for name in self.loss_names:
             v = getattr(self, 'loss_' + name, None)

@@ -54,12 +54,30 @@ class GeomCGTIFWTestModel(BaseModel):
         self.net_staticG.eval()
         self._static_key = None
         self._style = None
+        self._static_loaded = False
+
+    STATIC_CHECKPOINT = 'checkpoints/static/drawing.pth'                              # :226
+
+    def setup(self, opt):
+        """base_model.py:79-90 plus the static generator's checkpoint, which the reference loads unconditionally in
+        __init__ (:226).  A missing file is an error unless --allow_random_init (smoke mode) is set."""
+        if not self._static_loaded:
+            import os
+            if os.path.exists(self.STATIC_CHECKPOINT):
+                self.load_static(self.STATIC_CHECKPOINT)
+            elif not getattr(opt, 'allow_random_init', False):
+                raise FileNotFoundError('%s (static drawing generator) not found; load it with load_static(path) '
+                                        'before setup() or pass --allow_random_init' % self.STATIC_CHECKPOINT)
+            else:
+                print('WARNING: --allow_random_init: static drawing generator runs with RANDOM weights')
+        BaseModel.setup(self, opt)
 
     def load_static(self, path):
         """checkpoints/static/drawing.pth (:226): same key names, strict."""
         sd = torch.load(path, map_location=self.device)
         self.net_staticG.load_state_dict(sd, strict=True)
         self._static_key = None
+        self._static_loaded = True
 
     # ------------------------------------------------------------------------------------------------ input
     def set_input(self, input):                                                      # :254-274

@@ -203,7 +203,7 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
 
     def forward(self, input, land1, land2, motion, flow, ifmask):
         """G(input, land1, land2, motion, flow, ifmask) -> (B, output_nc, S, S)   (networks.py:1315)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and (input.requires_grad or any(p.requires_grad for p in self.parameters())):
             return generator_apply(self, input, land1, land2, motion, flow, ifmask)
         return self.forward_inference(input, land1, land2, motion, flow, ifmask)
 
@@ -214,6 +214,9 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         """The layer schedule.  tape=None: inference; otherwise every step also records its backward."""
         b = input.shape[0]
         inp = Feat(input.contiguous())
+        if tape is not None and input_needs_grad:
+            tape.track(inp)
+        self._last_input_feat = inp if tape is not None else None
         motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
         cf, dfw = conv_forward, self.double_feature_warping
         x1 = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)

@@ -111,6 +111,9 @@ class TestOptions(BaseOptions):
         p.add_argument('--eval', action='store_true')
         p.add_argument('--num_test', type=int, default=50)
         p.add_argument('--imagefolder', type=str, default='images')
+        p.add_argument('--allow_random_init', action='store_true',
+                       help='smoke mode (not in the reference): run with freshly initialised weights when a checkpoint '
+                            'is missing instead of failing')
         p.set_defaults(model='geomgm_ifw_fore')
         p.set_defaults(load_size=p.get_default('crop_size'))
         self.isTrain = False

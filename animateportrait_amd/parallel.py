@@ -97,6 +97,64 @@ def allreduce_optimizer_grads(optimizer, params=None, async_op=False):
     return None
 
 
+def broadcast_model(model, src=0):
+    """Make every rank start from rank ``src``'s weights (the reference's nn.DataParallel replicates ONE module,
+    networks.py:115-118; here every rank built its own).  A ``FlatAdam`` optimiser owns its parameters as one flat
+    buffer: one broadcast per optimiser; networks outside any optimiser (inference models) are broadcast tensor by
+    tensor.  Call after ``create_model`` / ``setup`` -- ``BaseModel.setup`` does."""
+    if world_size() == 1:
+        return
+    from . import ops
+    covered = set()
+    for opt in getattr(model, 'optimizers', []):
+        flat = getattr(opt, 'flat', None)
+        if flat is not None:
+            dist.broadcast(flat, src=src)
+            for extra in ('exp_avg', 'exp_avg_sq'):
+                dist.broadcast(getattr(opt, extra), src=src)
+            covered.update(id(p) for p in opt._params)
+        else:
+            for g in opt.param_groups:
+                for p in g['params']:
+                    dist.broadcast(p.data, src=src)
+                    covered.add(id(p))
+    for name in getattr(model, 'model_names', []):
+        net = getattr(model, 'net' + name)
+        for p in net.parameters():
+            if id(p) not in covered:
+                dist.broadcast(p.data, src=src)
+        for b in net.buffers():
+            dist.broadcast(b.data, src=src)
+    ops.WEIGHTS_EPOCH += 1          # parameters changed through raw storage: packed-weight caches are stale
+
+
+def state_fingerprint(model):
+    """(sum, sum of squares) over all parameters of the model's networks as a 2-element fp64 tensor: equal on every
+    rank iff the replicas hold the same weights (used by the tests and by ``assert_replicas_in_sync``)."""
+    acc = torch.zeros(2, dtype=torch.float64)
+    for name in getattr(model, 'model_names', []):
+        for p in getattr(model, 'net' + name).parameters():
+            d = p.detach().double()
+            acc += torch.stack([d.sum(), (d * d).sum()]).cpu()
+    return acc
+
+
+def assert_replicas_in_sync(model, tol=0.0):
+    """Raise when the ranks' weights differ (a data-parallel run whose replicas drifted is not SGD on one model)."""
+    w = world_size()
+    if w == 1:
+        return
+    fp = state_fingerprint(model)
+    dev = next(getattr(model, 'net' + model.model_names[0]).parameters()).device
+    mine = fp.to(dev) if dist.get_backend() == 'nccl' else fp
+    both = [torch.zeros_like(mine) for _ in range(w)]
+    dist.all_gather(both, mine)
+    for r, other in enumerate(both):
+        if float((other.cpu() - fp).abs().max()) > tol * max(1.0, float(fp.abs().max())):
+            raise RuntimeError('data-parallel replicas diverged: rank %d fingerprint %s vs local %s'
+                               % (r, other.cpu().tolist(), fp.tolist()))
+
+
 def wait_work(work):
     """Order the current stream (RCCL) / block the host (gloo) behind an asynchronous collective; None is a no-op."""
     if work is not None:

@@ -18,9 +18,11 @@ def main(argv=None):
     dataset = create_dataset(opt)
     model = create_model(opt)
     try:
-        model.setup(opt)
-    except FileNotFoundError as e:
-        print('no checkpoint (%s): running with freshly initialised weights' % e)
+        model.setup(opt)                       # loads '<epoch>_net_G_A.pth'; a missing file is an error, as in test.py:48
+    except FileNotFoundError:
+        if not opt.allow_random_init:
+            raise
+        print('WARNING: --allow_random_init: no checkpoint found, the frames below come from RANDOM weights')
     if opt.eval:
         model.eval()
     out_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.epoch), opt.imagefolder)

@@ -24,7 +24,7 @@ def main(argv=None):
     dataset = create_dataset(opt)
     print('The number of training images = %d' % len(dataset))
     model = create_model(opt)
-    model.setup(opt)
+    model.setup(opt)            # also broadcasts rank 0's initial weights / optimiser state to every rank
     total_iters = 0
     for epoch in range(opt.epoch_count, opt.niter + opt.niter_decay + 1):
         epoch_start = time.time()
@@ -47,6 +47,7 @@ def main(argv=None):
         if rank == 0:
             print('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.niter + opt.niter_decay, time.time() - epoch_start))
         model.update_learning_rate()
+        parallel.assert_replicas_in_sync(model, tol=1e-9)      # identical updates on identical weights: any drift is a bug
 
 
 if __name__ == '__main__':

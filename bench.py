@@ -3,9 +3,12 @@
 
 One "step" = one forward pass of the full-width generator (ngf=64, fp32,
 resnet_9blocks_rcatland32_full_ifw, disp=div=3) over a batch of 16 synthetic 256x256 frames that is
-already resident in HBM (BASELINE config 2).  N > 1: one process per GPU (launched by
-torch.distributed.run), frame batches shard by sample with no data-path collective
-(InstanceNorm makes samples independent) -> weak scaling; only the timing uses a collective.
+already resident in HBM (BASELINE config 2).  N > 1: one process per GPU, frame batches shard by sample with
+no data-path collective (InstanceNorm makes samples independent) -> weak scaling; only the timing uses a
+collective.  The train-step leg (BASELINE configs 2-3: bs=16 per GPU, gradients all-reduced over RCCL) runs on
+the same ranks.  Launch: either through ``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N``
+or plainly as ``python bench.py --gpus N`` -- without WORLD_SIZE in the environment bench.py re-executes itself
+under torch.distributed.run with N ranks.  A world size that differs from --gpus is a hard error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying also
   "roofline":     dominant kernel (conv_igemm_f32 instantiation with the largest total time),
@@ -63,28 +66,43 @@ def host_cores():
     return int(forced) if forced else n
 
 
-def cpu_baseline(budget_s=15.0):
-    """Oracle generator forward on the host cores: bounded sample (B=4 batches until ~budget_s)."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except Exception:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(warmup=3, iters=5):
+    """Oracle generator forward on the host cores, BASELINE.md section 3 protocol: fp32, B=1 and B=16, 3 warm-up +
+    5 timed iterations each, median; all physical cores.  ~25-40 s of CPU work in total."""
+    import statistics
     from oracle import generator as og
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
     cores = host_cores()
     torch.set_num_threads(cores)
     sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
-    b = 4
-    args = generator_args(make_generator_inputs(b, seed=1234))
+    res = {}
+    t_all = time.time()
     with torch.no_grad():
-        og.generator_forward(sd, *args, div=3, disp=3)          # warm-up (oneDNN primitive creation)
-        t0 = time.time()
-        n = 0
-        while True:
-            og.generator_forward(sd, *args, div=3, disp=3)
-            n += b
-            if time.time() - t0 > budget_s or n >= 1024:
-                break
-        dt = time.time() - t0
-    return {'value': round(n / dt, 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle.generator_forward ngf=64 fp32, %d frames in batches of %d (%.1f s), torch CPU %d threads'
-                      % (n, b, dt, cores)}
+        for b in (1, BATCH):
+            args = generator_args(make_generator_inputs(b, seed=1234))
+            for _ in range(warmup if b == 1 else 1):          # B=16: one warm-up (2-3 s each) keeps the leg bounded
+                og.generator_forward(sd, *args, div=3, disp=3)
+            ts = []
+            for _ in range(iters):
+                t0 = time.perf_counter()
+                og.generator_forward(sd, *args, div=3, disp=3)
+                ts.append(time.perf_counter() - t0)
+            res[b] = b / statistics.median(ts)
+    return {'value': round(res[BATCH], 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'bs1_frames_per_s': round(res[1], 3), 'cpu_model': cpu_model(),
+            'sample': 'oracle.generator_forward ngf=64 fp32, B=1 (3 warm-up) and B=16 (1 warm-up), median of %d timed '
+                      'iterations each (%.1f s in total), torch CPU %d threads; value = B=16 rate'
+                      % (iters, time.time() - t_all, cores)}
 
 
 def train_step_ms(dev, rank, world, dist, steps):
@@ -102,6 +120,9 @@ def train_step_ms(dev, rank, world, dist, steps):
     with contextlib.redirect_stdout(io.StringIO()):      # the model prints its notices; keep stdout = one JSON line
         torch.manual_seed(1234)
         model = create_model(TrainOptions().parse(argv))
+        from animateportrait_amd import parallel
+        parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
+        parallel.assert_replicas_in_sync(model)
         batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
                  for k, v in make_train_batch(BATCH, seed=1234, rank=rank).items()}
         model.set_input(batch)
@@ -121,8 +142,13 @@ def train_step_ms(dev, rank, world, dist, steps):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    from animateportrait_amd import parallel
+    parallel.assert_replicas_in_sync(model, tol=1e-9)    # identical updates on identical weights on every rank
     losses = model.get_current_losses()
     return {'ms_per_step': round(dt * 1e3, 2), 'samples_per_s': round(world * BATCH / dt, 2), 'steps': steps,
+            'world_size': world, 'global_batch': world * BATCH,
+            'gradient_exchange': 'none (1 rank)' if world == 1 else
+                                 '2 RCCL all-reduces / step (G 63.7 MB in flight under the D backward passes, D 55.3 MB)',
             'batch_per_gpu': BATCH, 'dtype': 'f32', 'loss_G': round(losses.get('G', float('nan')), 4),
             'gflop_per_sample_algorithmic': 1234.0,
             'note': 'geomgm_ifw_fore drawing config; frozen aux nets (MODNet/MobileFaceNet/Sphere20a/FlowUnet) absent '
@@ -139,20 +165,44 @@ def main():
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
     a = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    if a.gpus < 1 or a.gpus > torch.cuda.device_count():
+        raise SystemExit('--gpus %d but this node exposes %d GPU(s)' % (a.gpus, torch.cuda.device_count()))
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
+        import socket
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        os.execv(sys.executable, [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                                  '--nproc-per-node', str(a.gpus), '--master-addr', '127.0.0.1',
+                                  '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: refusing to report a run whose rank count differs from the '
+                         'one asked for' % (a.gpus, world))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dist = None
+    rccl_world = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)                    # the world RCCL really sees: every rank contributes 1
+        rccl_world = int(probe.item())
+        if rccl_world != a.gpus:
+            raise SystemExit('RCCL all-reduce saw %d ranks, --gpus %d' % (rccl_world, a.gpus))
+
+    # ---- CPU baseline first (rank 0, N=1 only): the GPU legs then run last, back to back
+    cpu = None
+    if not a.no_cpu_baseline and world == 1:
+        cpu = cpu_baseline()
 
     from animateportrait_amd import ops
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
@@ -270,7 +320,7 @@ def main():
     if rank == 0:
         fps = world * BATCH * a.steps / dt
         out = {'metric': 'generator frames/sec @256x256 bs=16', 'value': round(fps, 2), 'unit': 'frames/s',
-               'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+               'n_gpus': world, 'rccl_world_size': rccl_world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32 (fp32 tensors; wide convs multiply on the bf16 pipe with operands split 3-way, fp32 accumulate)',
                'data': 'synthetic',
@@ -285,9 +335,9 @@ def main():
             out['exact_fp32'] = exact
         if train is not None:
             out['train_step'] = train
-        if not a.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
-            out['speedup_vs_cpu'] = round(fps / out['cpu_baseline']['value'], 1)
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+            out['speedup_vs_cpu'] = round(fps / world / cpu['value'], 1)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

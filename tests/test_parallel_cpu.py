@@ -80,3 +80,79 @@ def test_shard_batch_rejects_ragged():
     from animateportrait_amd import parallel
     with pytest.raises(ValueError):
         parallel.shard_batch({'x': torch.zeros(5, 1)}, 0, 2)
+
+
+# ------------------------------------------------------------------ replicas start equal; DP grads == big-batch grads
+class _FakeModel:
+    """The attributes parallel.broadcast_model / state_fingerprint read from a BaseModel."""
+
+    def __init__(self, seed):
+        from animateportrait_amd.optim import FlatAdam
+        torch.manual_seed(seed)                                  # every rank builds DIFFERENT weights, as train.py did
+        self.netG_A = torch.nn.Sequential(torch.nn.Conv2d(1, 4, 3), torch.nn.Conv2d(4, 2, 3))
+        self.netS = torch.nn.Conv2d(2, 2, 1)                     # a frozen net outside every optimiser
+        self.model_names = ['G_A', 'S']
+        self.optimizers = [FlatAdam(self.netG_A.parameters(), lr=1e-3)]
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from animateportrait_amd import parallel, ops
+    from oracle import discriminator as od, generator as og, losses as ol
+    parallel.init_distributed('gloo')
+    # ---- (1) initial weights: different per rank before, identical after broadcast_model
+    m = _FakeModel(seed=1000 + rank)
+    before = parallel.state_fingerprint(m)
+    raised = False
+    try:
+        parallel.assert_replicas_in_sync(m)
+    except RuntimeError:
+        raised = True
+    epoch0 = ops.WEIGHTS_EPOCH
+    parallel.broadcast_model(m)
+    after = parallel.state_fingerprint(m)
+    parallel.assert_replicas_in_sync(m)
+    views_ok = all(p.data_ptr() >= m.optimizers[0].flat.data_ptr() for p in m.netG_A.parameters())
+    # ---- (2) SURVEY.md section 4: all-reduced grads of N shards == single-rank grads on the concatenated batch
+    # (InstanceNorm keeps samples independent, mean-reduced losses average).  Net = the oracle's PatchGAN.
+    sd = og.init_params(od.patchgan_param_shapes(2, 4), seed=3)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(4, 2, 64, 64, generator=g)
+    shard = parallel.shard_batch({'x': x}, rank, world)['x']
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    sdp = dict(zip(sd.keys(), params))
+    ol.gan_loss_lsgan(od.patchgan_forward(sdp, shard), True).backward()
+    parallel.allreduce_gradients(params, bucket_bytes=1 << 12)
+    # numpy payloads: tensors would travel as file descriptors that die with this process
+    q.put((rank, before.numpy(), after.numpy(), raised, views_ok, ops.WEIGHTS_EPOCH - epoch0,
+           [p.grad.numpy().copy() for p in params]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_initial_weights_and_dp_gradient_equivalence_world2():
+    from oracle import discriminator as od, generator as og, losses as ol
+    world = 2
+    port = 29950 + random.randint(0, 300)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, b0, a0, r0, v0, e0, g0), (_, b1, a1, r1, v1, e1, g1) = res
+    assert not np.array_equal(b0, b1) and r0 and r1       # different seeds -> replicas differed and that was detected
+    assert np.array_equal(a0, a1) and np.array_equal(a0, b0)   # after the broadcast both hold rank 0's weights
+    assert v0 and v1 and e0 == 1 and e1 == 1              # still views of the flat buffer; packed caches invalidated
+    sd = og.init_params(od.patchgan_param_shapes(2, 4), seed=3)
+    x = torch.randn(4, 2, 64, 64, generator=torch.Generator().manual_seed(9))
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    ol.gan_loss_lsgan(od.patchgan_forward(dict(zip(sd.keys(), params)), x), True).backward()
+    for a, b, ref in zip(g0, g1, params):
+        assert np.array_equal(a, b)
+        r = ref.grad.numpy()            # (biases in front of InstanceNorm have pure rounding-noise gradients: atol)
+        assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max() + 1e-6, float(np.abs(a - r).max())

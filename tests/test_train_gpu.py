@@ -160,3 +160,172 @@ def test_checkpoint_roundtrip(dev, tmp_path):
         model.netG_A.model3['7'].weight.add_(1.0)
     model.load_networks('latest')
     assert torch.equal(model.netG_A.model3['7'].weight, w)
+
+
+# ------------------------------------------------------------------ data-parallel equivalence, entry points, guards
+def _flat_grads(model):
+    return model.optimizer_G.flat_grad.clone(), model.optimizer_D.flat_grad.clone()
+
+
+def _backward_both(model, batch):
+    """The gradient half of optimize_parameters (:782-819) without the optimiser steps."""
+    model.set_input(batch)
+    model.forward()
+    nets_D = [getattr(model, 'net' + n) for n in model.model_names[1:]]
+    model.set_requires_grad(nets_D, False)
+    model.optimizer_G.zero_grad()
+    model.backward_G()
+    model.set_requires_grad(nets_D, True)
+    model.optimizer_D.zero_grad()
+    model.backward_D_A(); model.backward_D_A_l(); model.backward_D_A_le(); model.backward_D_A_ll(); model.backward_D_A_coh()
+    return _flat_grads(model)
+
+
+def test_dp_equivalence_shard_grads_average_to_big_batch_grads(dev):
+    """SURVEY.md section 4 / VERDICT r1 #1b: the data-parallel step is exact.  backward of a B=4 batch == the mean of
+    the backward passes of its two B=2 shards (what the two ranks of a DP run all-reduce), for G and all five D's.
+    The image pool of D_A_coh is empty (< pool_size images seen), so query() returns its input on every call."""
+    from animateportrait_amd import parallel
+    from animateportrait_amd.data.synthetic_dataset import make_train_batch
+    torch.manual_seed(3)
+    model, opt = _make_model(dev)
+    batch = make_train_batch(4, seed=77)
+    gG, gD = _backward_both(model, batch)
+    accG, accD = torch.zeros_like(gG), torch.zeros_like(gD)
+    for r in range(2):
+        a, b = _backward_both(model, parallel.shard_batch(batch, r, 2))
+        accG += a / 2
+        accD += b / 2
+    for name, big, avg, opt_ in (('G', gG, accG, model.optimizer_G), ('D', gD, accD, model.optimizer_D)):
+        assert float(big.abs().max()) > 0
+        off = 0
+        for p in opt_._params:
+            k = p.numel()
+            x, y = big[off:off + k].double(), avg[off:off + k].double()
+            off += k
+            scale = float(x.abs().max())
+            if scale == 0.0:            # biases in front of InstanceNorm: exact zeros on both sides
+                assert float(y.abs().max()) == 0.0
+                continue
+            # same per-sample arithmetic, different summation order over the batch: fp32 rounding only
+            assert float((x - y).abs().max()) <= 2e-4 * scale + 1e-9, (name, tuple(p.shape), float((x - y).abs().max()), scale)
+        rel = float((big.double() - avg.double()).norm() / big.double().norm())
+        assert rel < 5e-5, (name, rel)
+
+
+_ENTRY_FLAGS = ['--netG', 'resnet_9blocks_rcatland32_full_ifw', '--dataset_mode', 'synthetic', '--output_nc', '1',
+                '--ngf', '8', '--ndf', '8', '--netg_resb_div', '3', '--netg_resb_disp', '3', '--gpu_ids', '0']
+
+
+def test_train_and_test_entry_points_end_to_end(dev, tmp_path, capsys):
+    """Module2/train.py:7-64 and test.py:38-66 counterparts, run as the CLI runs them: two epochs of two synthetic
+    batches, checkpoints written with the reference's file names, then inference from the saved generator."""
+    from animateportrait_amd import train, test
+    ck, res = str(tmp_path / 'ck'), str(tmp_path / 'res')
+    train.main(['--model', 'geomgm_ifw_fore', '--name', 'e2e_drawing', '--checkpoints_dir', ck, '--batch_size', '2',
+                '--synthetic_batches', '2', '--niter', '2', '--niter_decay', '0', '--save_epoch_freq', '1',
+                '--print_freq', '2', '--lr', '0.00005', '--lambda_geom_lipline', '50', '--lambda_warp_inter', '10',
+                '--blendbg', '1'] + _ENTRY_FLAGS)
+    out = capsys.readouterr().out
+    assert 'End of epoch 2 / 2' in out and 'G_A:' in out and 'nan' not in out.lower()
+    import os
+    for name in ('G_A', 'D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh'):
+        for ep in ('latest', '1', '2'):
+            assert os.path.exists(os.path.join(ck, 'e2e_drawing', '%s_net_%s.pth' % (ep, name))), (ep, name)
+    # a mistyped checkpoint name is an error (test.py:48 -> load_networks), not a silent random-weights run
+    with pytest.raises(FileNotFoundError):
+        test.main(['--model', 'geomgm_ifw_fore', '--name', 'no_such_run', '--checkpoints_dir', ck, '--results_dir', res,
+                   '--batch_size', '2', '--synthetic_batches', '1'] + _ENTRY_FLAGS)
+    test.main(['--model', 'geomgm_ifw_fore', '--name', 'e2e_drawing', '--checkpoints_dir', ck, '--results_dir', res,
+               '--batch_size', '2', '--synthetic_batches', '2', '--num_test', '3', '--epoch', '2'] + _ENTRY_FLAGS)
+    frames = sorted(os.listdir(os.path.join(res, 'e2e_drawing', 'test_2', 'images')))
+    assert len(frames) >= 3 and all(f.endswith('_fake_B.npy') for f in frames)
+    y = np.load(os.path.join(res, 'e2e_drawing', 'test_2', 'images', frames[0]))
+    assert y.shape == (1, 256, 256) and np.isfinite(y).all() and np.abs(y).max() <= 1.0
+    # the saved generator reproduces the frame: same weights -> same output as the CLI wrote
+    from animateportrait_amd import networks
+    from animateportrait_amd.data.synthetic_dataset import make_train_batch
+    G = networks.define_G(3, 1, 8, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0],
+                          div=3, disp=3)
+    G.load_state_dict(torch.load(os.path.join(ck, 'e2e_drawing', '2_net_G_A.pth')), strict=True)
+    b = make_train_batch(2, seed=1234)
+    mask = (b['mask'] > 0.5).float()
+    fore = ((b['A'] / 2 + 0.5) * mask + 1 - mask) * 2 - 1
+    with torch.no_grad():
+        ref = G(*[t.to(dev).contiguous() for t in (fore, b['A_lm'], b['tB_lm'], b['warp_motion'], b['iw_flow'], b['if_mask'])])
+    assert linf(ref[0], torch.from_numpy(y)) < 1e-6
+
+
+def test_streaming_test_model_entry_point_requires_static_checkpoint(dev, tmp_path):
+    """geomcgt_ifw_test (main_end2end_module2.py:96-97): without checkpoints/static/drawing.pth setup() fails as the
+    reference's __init__ does (:226), unless --allow_random_init asks for the smoke mode."""
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    argv = ['--model', 'geomcgt_ifw_test', '--name', 'x_drawing', '--checkpoints_dir', str(tmp_path),
+            '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--output_nc', '1', '--ngf', '8', '--gpu_ids', '0']
+    model = create_model(TestOptions().parse(argv))
+    with pytest.raises(FileNotFoundError, match='drawing.pth'):
+        model.setup(model.opt)
+
+
+def test_singular_tps_system_is_reported(dev):
+    """ADVICE r1 / sparse_image_warp.py:124-128: duplicate control points make the spline system singular; the
+    reference fails loudly, ap_tps_solve flags it -- the wrapper must surface the flag at the next sync point."""
+    from animateportrait_amd.models import sparse_image_warp as siw
+    siw.check_status()
+    src = torch.tensor([[[10., 10.], [10., 10.], [30., 40.], [50., 20.]]], device=dev)      # two coincident points
+    dst = src + 1.0
+    img = torch.rand(1, 64, 64, 1, device=dev)
+    siw.sparse_image_warp(img, src, dst)
+    with pytest.raises(RuntimeError, match='singular'):
+        siw.check_status()
+    siw.check_status()                      # the flag is consumed
+    tg = torch.Generator().manual_seed(1)
+    good = torch.rand(1, 20, 2, generator=tg).to(dev) * 48 + 8
+    siw.sparse_image_warp(img, good, good + 0.5)
+    siw.check_status()                      # a regular system raises nothing
+
+
+def test_autograd_guards_and_generator_input_gradient(dev):
+    """ADVICE r1 (autograd.py): (a) d(out)/d(input) of the generator is defined and matches the oracle's autograd;
+    (b) an optimiser step between forward and backward raises instead of giving gradients of other weights;
+    (c) a second backward raises a clear error; (d) inputs without a defined gradient are refused."""
+    from animateportrait_amd import networks, ops
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    from oracle import generator as og
+    sd = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=5)
+    G = networks.define_G(3, 1, 8, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0],
+                          div=3, disp=3)
+    G.load_state_dict(sd, strict=True)
+    d = make_generator_inputs(1, seed=21)
+    args = [t.to(dev) for t in generator_args(d)]
+    gout = torch.randn(1, 1, 256, 256, generator=torch.Generator().manual_seed(2))
+    # (a)
+    x = args[0].clone().requires_grad_(True)
+    y = G(x, *args[1:])
+    y.backward(gout.to(dev))
+    xr = d['input'].clone().double().requires_grad_(True)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    yr = og.generator_forward(sd64, xr, *[t.double() for t in generator_args(d)[1:]], div=3, disp=3)
+    yr.backward(gout.double())
+    x32 = d['input'].clone().requires_grad_(True)
+    og.generator_forward(sd, x32, *generator_args(d)[1:], div=3, disp=3).backward(gout)
+    ref_err = linf(x32.grad, xr.grad)
+    scale = float(xr.grad.abs().max())
+    assert x.grad is not None and linf(x.grad, xr.grad) <= max(3.0 * ref_err, 2e-3 * scale), (linf(x.grad, xr.grad), ref_err, scale)
+    # (c)
+    with pytest.raises(RuntimeError, match='second time'):
+        y.backward(gout.to(dev))
+    # (b)
+    y2 = G(*args)
+    with torch.no_grad():
+        G.model_tri_merge.weight.mul_(1.0)          # in-place write bumps the version
+    with pytest.raises(RuntimeError, match='modified'):
+        y2.backward(gout.to(dev))
+    y3 = G(*args)
+    ops.WEIGHTS_EPOCH += 1                          # what FlatAdam.step does
+    with pytest.raises(RuntimeError, match='modified'):
+        y3.backward(gout.to(dev))
+    # (d)
+    with pytest.raises(NotImplementedError, match='flow'):
+        G(args[0], args[1], args[2], args[3], args[4].clone().requires_grad_(True), args[5])
