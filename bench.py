@@ -98,10 +98,11 @@ def cpu_baseline(warmup=3, iters=5):
                 og.generator_forward(sd, *args, div=3, disp=3)
                 ts.append(time.perf_counter() - t0)
             res[b] = b / statistics.median(ts)
-    return {'value': round(res[BATCH], 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
-            'bs1_frames_per_s': round(res[1], 3), 'cpu_model': cpu_model(),
+    # value = the better of the two batch sizes (oneDNN on many cores is often faster per frame at B=1)
+    return {'value': round(max(res.values()), 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'bs1_frames_per_s': round(res[1], 3), 'bs16_frames_per_s': round(res[BATCH], 3), 'cpu_model': cpu_model(),
             'sample': 'oracle.generator_forward ngf=64 fp32, B=1 (3 warm-up) and B=16 (1 warm-up), median of %d timed '
-                      'iterations each (%.1f s in total), torch CPU %d threads; value = B=16 rate'
+                      'iterations each (%.1f s in total), torch CPU %d threads; value = max(B=1, B=16) rate'
                       % (iters, time.time() - t_all, cores)}
 
 
