@@ -73,7 +73,7 @@ SIGNATURES = {
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd_view': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ApOutView), c_f32p, c_f32p, c_f32p,
                                           ctypes.c_void_p]),
-    'ap_instnorm_finalize': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+    'ap_instnorm_finalize': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                             c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
@@ -117,6 +117,27 @@ SIGNATURES = {
                                    ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_adam_step': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                     ctypes.c_float, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
+    'ap_reduce_workspace_floats': (ctypes.c_int64, []),
+    'ap_reduce_mean': (ctypes.c_int, [ctypes.c_int32, c_f32p, c_f32p, ctypes.c_float, ctypes.c_int64, ctypes.c_float,
+                                      c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_reduce_mean_bwd': (ctypes.c_int, [ctypes.c_int32, c_f32p, c_f32p, ctypes.c_float, ctypes.c_int64, ctypes.c_float,
+                                          c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_mask_composite': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_mask_composite_bwd': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
+    'ap_axpy': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p]),
+    'ap_crop_resize_fwd': (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int32] * 9 +
+                           [ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    'ap_crop_resize_bwd': (ctypes.c_int, [c_f32p, ctypes.c_void_p] + [ctypes.c_int32] * 9 +
+                           [ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    'ap_kp_to_map': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
+                                    ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    'ap_flow_post': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_landmark_discs': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
+    'ap_circle_rows': (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
 }
 
 _lib = None

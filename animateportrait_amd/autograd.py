@@ -19,6 +19,42 @@ class Tape:
         self.grads = {}          # id(Feat) -> list of (tensor, pad)
         self.keep = []           # keep Feats alive so ids stay unique
         self.param_grads = {}    # Parameter -> tensor
+        self.block = None        # contiguous gradient block of the network (see grad_block), or None
+        self.block_lo = 0
+
+    def grad_block(self, params):
+        """When every trainable parameter of the network is a view of ONE optimiser's flat buffer (optim.FlatAdam) and
+        the views are adjacent, the backward kernels write the parameter gradients straight into one contiguous block
+        laid out like that range; the whole block is then added to the optimiser's flat gradient buffer with one launch
+        -- instead of one AccumulateGrad add per parameter and call (~200 launches per train step)."""
+        live = [p for p in params if p.requires_grad]
+        if not live or any(getattr(p, '_flat_owner', None) is None for p in live):
+            return False
+        owner = live[0]._flat_owner
+        if any(p._flat_owner is not owner for p in live):
+            return False
+        lo = min(p._flat_off for p in live)
+        hi = max(p._flat_off + p.numel() for p in live)
+        if hi - lo != sum(p.numel() for p in live):
+            return False
+        self.block = torch.zeros(hi - lo, dtype=torch.float32, device=owner.flat_grad.device)
+        self.block_lo, self.block_owner = lo, owner
+        return True
+
+    def slot(self, p):
+        """Where the gradient kernel of parameter ``p`` should write (None: allocate; a second contribution to the
+        same parameter is computed apart and added)."""
+        if self.block is None or p in self.param_grads:
+            return None
+        o = p._flat_off - self.block_lo
+        return self.block[o:o + p.numel()].view(p.shape)
+
+    def flush_block(self):
+        if self.block is not None:
+            from . import losses
+            o = self.block_owner
+            losses.axpy_(o.flat_grad[self.block_lo:self.block_lo + self.block.numel()], self.block)
+            self.block = None
 
     def track(self, f):
         self.grads[id(f)] = []
@@ -37,7 +73,11 @@ class Tape:
 
     def add_param(self, p, g):
         if p in self.param_grads:
-            self.param_grads[p] = self.param_grads[p] + g
+            prev = self.param_grads[p]
+            if self.block is not None:
+                prev.add_(g)                     # prev is the parameter's slot of the block
+            else:
+                self.param_grads[p] = prev + g
         else:
             self.param_grads[p] = g
 
@@ -74,13 +114,18 @@ def conv_backward(tape, layer, srcs, out, norm, act):
     if layer.weight.requires_grad:
         if s.transposed:
             # dW[ci][co*k*k]: M-role = the layer input (virtual allowed), shifted tensor = dy (stride 2)
-            dw = ops.wgrad(s.k, 2, s.pad, PAD_ZERO, srcs[0], [gfeat], layer.weight.shape)
+            dw = ops.wgrad(s.k, 2, s.pad, PAD_ZERO, srcs[0], [gfeat], layer.weight.shape, out=tape.slot(layer.weight))
         else:
-            dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape)
+            dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape,
+                           out=tape.slot(layer.weight))
         tape.add_param(layer.weight, dw)
     if layer.bias.requires_grad:
         # a bias in front of InstanceNorm has an exactly-zero gradient (it is removed by the mean subtraction)
-        tape.add_param(layer.bias, torch.zeros_like(layer.bias) if norm else ops.bias_grad(dy))
+        slot = tape.slot(layer.bias)
+        if norm:
+            tape.add_param(layer.bias, slot if slot is not None else torch.zeros_like(layer.bias))   # block is zero-filled
+        else:
+            tape.add_param(layer.bias, ops.bias_grad(dy, out=slot))
     # ---- data gradients, one launch per input segment that needs one
     c0 = 0
     for i, f in enumerate(srcs):
@@ -200,6 +245,7 @@ class _NetFn(torch.autograd.Function):
                                'between forward and backward; its gradients would belong to different weights'
                                % type(ctx.net).__name__)
         with torch.no_grad():
+            direct = tape.grad_block(ctx.params)
             tape.add(ctx.out_feat, gout.contiguous(), 0)
             tape.backward()
             gin = [None] * ctx.n_inputs
@@ -208,7 +254,11 @@ class _NetFn(torch.autograd.Function):
                 if contribs:
                     g1, pad, g2 = ops._split_contribs(contribs)
                     gin[0] = g1 if (pad == 0 and g2 is None) else ops.fold_add(g1, pad, g2)
-            gp = [tape.param_grads.get(p) for p in ctx.params]
+            if direct:       # already summed into the optimiser's flat gradient buffer (p.grad is a view of it)
+                tape.flush_block()
+                gp = [None] * len(ctx.params)
+            else:
+                gp = [tape.param_grads.get(p) for p in ctx.params]
         ctx.tape = None
         return (None, None, None, *gin, *gp)
 

@@ -13,4 +13,7 @@ inline int check_launch(const char* what) {
     if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return AP_OK;
 }
+// InstanceNorm statistics: planes with mean^2 > ratio * var (as estimated from the conv epilogue's fp32 sums) are
+// recomputed from the data (instnorm.hip: instnorm_refine_kernel, conv_bf16x3.h: norm_split_kernel)
+constexpr float kInstNormRefineRatio = 32.f;
 }  // namespace apamd

@@ -607,6 +607,8 @@ struct NormSplitParams {
 template <int VEC>
 __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p) {
     __shared__ float s_m[8], s_r[8];
+    __shared__ int s_bad[8];
+    __shared__ double s_red[2][4];
     const int cg = blockIdx.y, n = blockIdx.z, C = p.C, HW = p.HW, CG = C >> 3;
     const int tid = threadIdx.x;
     const bool normed = p.partials != nullptr || p.mean != nullptr;
@@ -631,16 +633,47 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
                 const double m = s * p.inv_count;
                 double var = q * p.inv_count - m * m;
                 var = var > 0.0 ? var : 0.0;
-                const float mf = (float)m, rf = (float)(1.0 / sqrt(var + (double)p.eps));
-                s_m[c] = mf;
-                s_r[c] = rf;
-                if (blockIdx.x == 0) {
-                    p.mean_out[n * C + cg * 8 + c] = mf;
-                    p.rstd_out[n * C + cg * 8 + c] = rf;
-                }
+                s_m[c] = (float)m;
+                s_r[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+                s_bad[c] = (m * m > (double)kInstNormRefineRatio * var) ? 1 : 0;
             }
         }
         __syncthreads();
+        // ill-conditioned planes (|mean| >> std: E[x^2] - E[x]^2 of fp32 sums is rounding noise there) are recomputed
+        // from the data with the shifted two-pass formula, as instnorm_refine_kernel does.  Every pixel block of the
+        // plane repeats the same deterministic sum (rare path: read amplification only for such planes).
+        for (int c = 0; c < 8; ++c) {
+            if (!s_bad[c]) continue;                           // block-uniform
+            const float m0 = s_m[c];
+            const float* px = p.x + ((long long)n * C + cg * 8 + c) * HW;
+            double s = 0.0, q = 0.0;
+            for (int k = tid; k < HW; k += 256) {
+                const float d = px[k] - m0;
+                s += (double)d;
+                q += (double)d * (double)d;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                s += __shfl_xor(s, sh, 64);
+                q += __shfl_xor(q, sh, 64);
+            }
+            if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = q; }
+            __syncthreads();
+            if (tid == 0) {
+                const double S = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+                const double Q = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+                const double dm = S * p.inv_count;
+                double var = Q * p.inv_count - dm * dm;
+                var = var > 0.0 ? var : 0.0;
+                s_m[c] = (float)((double)m0 + dm);
+                s_r[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+            }
+            __syncthreads();
+        }
+        if (blockIdx.x == 0 && tid < 8) {
+            p.mean_out[n * C + cg * 8 + tid] = s_m[tid];
+            p.rstd_out[n * C + cg * 8 + tid] = s_r[tid];
+        }
     } else if (p.mean != nullptr) {
         if (tid < 8) {
             s_m[tid] = p.mean[n * C + cg * 8 + tid];

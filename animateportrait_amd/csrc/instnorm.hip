@@ -35,6 +35,43 @@ __global__ void instnorm_finalize_kernel(const float* __restrict__ partials, int
     rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// E[x^2] - E[x]^2 from fp32 tile sums loses log2(mean^2 / var) bits: a plane whose |mean| is many standard deviations
+// (a PatchGAN fed a mostly-white masked crop, base_model.py:245-247) would get a variance that is rounding noise,
+// hidden by the var > 0 clamp.  Planes with mean^2 > kRefineRatio * var are therefore recomputed from the data with
+// the shifted two-pass formula (shift = the first estimate of the mean, itself accurate): one workgroup per plane,
+// which exits at once for a well-conditioned plane.  The same rule is inlined in norm_split_kernel.
+__global__ __launch_bounds__(256) void instnorm_refine_kernel(const float* __restrict__ y, int HW, float eps,
+                                                              float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[2][4];
+    const int i = blockIdx.x;
+    const float m = mean[i], r = rstd[i];
+    const float var0 = 1.f / (r * r) - eps;
+    if (!(m * m > kInstNormRefineRatio * var0)) return;
+    const float* p = y + (long long)i * HW;
+    double s = 0.0, q = 0.0;
+    for (int k = threadIdx.x; k < HW; k += 256) {
+        const float d = p[k] - m;
+        s += (double)d;
+        q += (double)d * (double)d;
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) {
+        s += __shfl_xor(s, sh, 64);
+        q += __shfl_xor(q, sh, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double dm = S / (double)HW;
+        double var = Q / (double)HW - dm * dm;
+        var = var > 0.0 ? var : 0.0;
+        mean[i] = (float)((double)m + dm);
+        rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 __device__ __forceinline__ float act1(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.f;
     if (act == 2) return v > 0.f ? v : 0.2f * v;
@@ -78,12 +115,14 @@ using namespace apamd;
 
 extern "C" {
 
-int ap_instnorm_finalize(const float* stat_partials, int32_t NC, int32_t tiles, int32_t count, float eps,
+int ap_instnorm_finalize(const float* stat_partials, const float* y, int32_t NC, int32_t tiles, int32_t count, float eps,
                          float* mean, float* rstd, ap_stream_t stream) {
     if (!stat_partials || !mean || !rstd) return fail(AP_ERR_INVALID, "instnorm_finalize: null pointer");
     if (NC < 1 || tiles < 1 || count < 1) return fail(AP_ERR_INVALID, "instnorm_finalize: bad sizes");
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((NC * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        stat_partials, NC, tiles, 1.0 / (double)count, eps, mean, rstd);
+    if (y != nullptr)     // ill-conditioned planes (|mean| >> std) are recomputed from the data
+        hipLaunchKernelGGL(instnorm_refine_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, y, count, eps, mean, rstd);
     return check_launch("instnorm_finalize_kernel");
 }
 

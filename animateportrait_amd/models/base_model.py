@@ -114,14 +114,6 @@ class BaseModel(ABC):
                 for p in net.parameters():
                     p.requires_grad = requires_grad
 
-    def masked(self, A, mask):                                        # :238-247
-        t = self.opt.mask_type
-        if t == 0:
-            return (A / 2 + 0.5) * mask * 2 - 1
-        if t == 1:
-            return ((A / 2 + 0.5) * mask + 1 - mask) * 2 - 1
-        if t == 2:
-            return torch.cat((A, mask), 1)
-        if t == 3:
-            return torch.cat((((A / 2 + 0.5) * mask + 1 - mask) * 2 - 1, mask), 1)
-        raise ValueError('mask_type %r' % t)
+    def masked(self, A, mask):                                        # :238-247, one fused launch each way
+        from .. import losses
+        return losses.masked(A, mask, self.opt.mask_type)

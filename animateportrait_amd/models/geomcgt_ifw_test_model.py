@@ -19,7 +19,7 @@ What is different (and why):
 """
 import torch
 
-from .. import networks, ops
+from .. import losses, networks, ops
 from .base_model import BaseModel
 
 
@@ -96,8 +96,8 @@ class GeomCGTIFWTestModel(BaseModel):
                 setattr(self, attr, input[k].to(dev) if torch.is_tensor(input[k]) else input[k])
         self.image_paths = input.get('image_paths')
         if self.aux['netF'] is not None:
-            self.iw_flow, self.real_A_if_mask = self.aux['netF'](self.real_A, self.real_A_lm_68[:, :68],
-                                                                 self.target_B_lm_68[:, :68])
+            self.iw_flow, self.real_A_if_mask = losses.flow_network_warp(                       # :62-76, :270-271
+                self.aux['netF'], self.real_A, self.real_A_lm_68[:, :68], self.target_B_lm_68[:, :68])
         else:
             self.iw_flow, self.real_A_if_mask = input['iw_flow'].to(dev), input['if_mask'].to(dev)
         self._matte_in = None
@@ -125,14 +125,14 @@ class GeomCGTIFWTestModel(BaseModel):
             matte = self._matte_in
         mask = (matte > 0.5).float()
         fakeB_static = self.static_drawing(self.real_A)       # of the unmasked photo, as :282-285
-        self.real_A = ((self.real_A / 2 + 0.5) * mask + 1 - mask) * 2 - 1
+        self.real_A = losses.fore_composite(self.real_A, mask)
         self.fg_mask = (mask * 2 - 1).repeat(1, 3, 1, 1)
         with torch.no_grad():
             self.fake_B = self.netG_A(self.real_A.contiguous(), self.real_A_lm, self.target_B_lm, self.warp_motion,
                                       self.iw_flow, self.real_A_if_mask)
         self.mask1 = ops.grid_sample(mask.contiguous(), self.warp_motion.contiguous(), align_corners=True)
         self.fake_B_fore = self.fake_B.clone()
-        self.fake_B = ((self.fake_B / 2 + 0.5) * self.mask1 + (fakeB_static / 2 + 0.5) * (1 - self.mask1)) * 2 - 1
+        self.fake_B = losses.bg_blend(self.fake_B, fakeB_static, self.mask1)
         self.fg_mask1 = (self.mask1 * 2 - 1).repeat(1, 3, 1, 1)
         if hasattr(self, 'target_B_lm_68') and hasattr(self, 'winB'):
             self.fake_B_vis = self.get_lmvis(self.fake_B, self.target_B_lm_68, self.winB)

@@ -24,9 +24,8 @@ What is different (and why):
 import itertools
 
 import torch
-import torch.nn.functional as F
 
-from .. import networks, parallel
+from .. import losses, networks, parallel
 from ..optim import FlatAdam
 from ..util.image_pool import ImagePool
 from .base_model import BaseModel
@@ -151,23 +150,20 @@ class GeomGMIFWForeModel(BaseModel):
         return (dist2 <= (self.thickness / 2.0 + 0.5) ** 2).any(dim=1, keepdim=True).float()
 
     def get_lm(self, x, win, out_size=112):
-        """:390-415, per sample: window crop into a ones-filled box, x3 channels, bicubic to 112, landmark net."""
+        """:390-415, per sample: window crop into a ones-filled box, BGR / x3 channels, bicubic (align_corners=False)
+        to 112^2, [-1,1] -> [0,1] -- one fused HIP launch each way (ap_crop_resize_*) -- then the frozen landmark
+        regressor and the re-projection of its window-normalised output to image pixels."""
         net = self.aux['landmarks']
-        cs = self.opt.crop_size
-        out = []
-        for i in range(x.shape[0]):
-            x1, x2, y1, y2 = [int(v) for v in win[i]]
-            box = torch.ones((1, x.shape[1], x2 - x1, x2 - x1), device=x.device, dtype=x.dtype)
-            box[:, :, max(0, y1) - y1:min(y2, cs) - y1, max(0, x1) - x1:min(cs, x2) - x1] = \
-                x[i:i + 1, :, max(0, y1):min(y2, cs), max(0, x1):min(cs, x2)]
-            box = box[:, [2, 1, 0]] if box.shape[1] == 3 else box.repeat(1, 3, 1, 1)
-            box = F.interpolate(box, size=(out_size, out_size), mode='bicubic', align_corners=False)
-            lm = net((box + 1) * 0.5)
-            lm = (lm[0] if isinstance(lm, (tuple, list)) else lm).view(1, 68, 2)
-            scale = torch.tensor([x2 - x1, y2 - y1], device=x.device, dtype=x.dtype)
-            off = torch.tensor([x1, y1], device=x.device, dtype=x.dtype)
-            out.append(lm * scale + off)
-        return torch.cat(out, 0)
+        n, c = x.shape[:2]
+        wdev = losses.windows_to_device(win, n, x.device)
+        box = losses.crop_resize(x, wdev, (2, 1, 0) if c == 3 else (0, 0, 0), (out_size, out_size),
+                                 losses.RESIZE_BICUBIC, scale=0.5, shift=0.5)
+        lm = net(box)
+        lm = (lm[0] if isinstance(lm, (tuple, list)) else lm).view(n, 68, 2)
+        wf = wdev.to(x.dtype)
+        scale = torch.stack([wf[:, 1] - wf[:, 0], wf[:, 3] - wf[:, 2]], 1).view(n, 1, 2)
+        off = torch.stack([wf[:, 0], wf[:, 2]], 1).view(n, 1, 2)
+        return lm * scale + off
 
     # ------------------------------------------------------------------ data
     def set_input(self, input):
@@ -195,15 +191,19 @@ class GeomGMIFWForeModel(BaseModel):
             if self.opt.coh_use_more:
                 self.real_B3, self.real_B4 = dev('B3'), dev('B4')
         if self.aux['netF'] is not None:                                         # :503-505
-            self.iw_flow, self.real_A_if_mask = self.aux['netF'](self.real_A, self.real_A_lm_68, self.target_B_lm_68)
-            self.iw_flow2, self.real_A_if_mask2 = self.aux['netF'](self.real_A, self.real_A_lm_68, self.target_B2_lm_68)
+            nf = self.aux['netF']                 # the frozen FlowUnet module itself; pre / post stages run on the device
+            self.iw_flow, self.real_A_if_mask = losses.flow_network_warp(nf, self.real_A, self.real_A_lm_68[:, :68],
+                                                                         self.target_B_lm_68[:, :68])
+            self.iw_flow2, self.real_A_if_mask2 = losses.flow_network_warp(nf, self.real_A, self.real_A_lm_68[:, :68],
+                                                                           self.target_B2_lm_68[:, :68])
         else:
             self._notice('netF', 'no intrinsic-flow network: iw_flow / if_mask are read from the batch')
             self.iw_flow, self.real_A_if_mask = dev('iw_flow'), dev('if_mask')
             self.iw_flow2, self.real_A_if_mask2 = dev('iw_flow2'), dev('if_mask2')
         if self.aux['modnet'] is not None:
             with torch.no_grad():
-                self.mask = (self.aux['modnet'](self.real_A) > 0.5).float()       # :519-521
+                _, _, matte = self.aux['modnet'](self.real_A, True)               # :519-521
+                self.mask = (matte > 0.5).float()
         else:
             self._notice('modnet', 'no matting network: the foreground mask is read from the batch')
             self.mask = (dev('mask') > 0.5).float()
@@ -213,7 +213,7 @@ class GeomGMIFWForeModel(BaseModel):
         """:517-565."""
         o = self.opt
         mask = self.mask
-        fore = lambda x: ((x / 2 + 0.5) * mask + 1 - mask) * 2 - 1                # noqa: E731  (:523-527)
+        fore = lambda x: losses.fore_composite(x, mask)                           # noqa: E731  (:523-527)
         if not o.blendbg:
             self.real_A = fore(self.real_A)
             self.real_A_fore = self.real_A
@@ -233,10 +233,9 @@ class GeomGMIFWForeModel(BaseModel):
             m12 = warp_nchw(cat2(mask, mask), rc(cat2(self.real_A_lm_68, self.real_A_lm_68)),
                             rc(cat2(self.target_B_lm_68, self.target_B2_lm_68)))
             self.mask1, self.mask2 = m12[:b], m12[b:]
-            stat = self.fakeB_static / 2 + 0.5
             self.fake_B_fore, self.fake_B2_fore = self.fake_B, self.fake_B2
-            self.fake_B = ((self.fake_B / 2 + 0.5) * self.mask1 + stat * (1 - self.mask1)) * 2 - 1
-            self.fake_B2 = ((self.fake_B2 / 2 + 0.5) * self.mask2 + stat * (1 - self.mask2)) * 2 - 1
+            self.fake_B = losses.bg_blend(self.fake_B, self.fakeB_static, self.mask1)     # :541
+            self.fake_B2 = losses.bg_blend(self.fake_B2, self.fakeB_static, self.mask2)   # :543
         for flag, suf in ((o.use_mask, ''), (o.use_eye_mask, 'e'), (o.use_lip_mask, 'l')):   # :546-557
             if flag:
                 setattr(self, 'fake_B_l' + suf, self.masked(self.fake_B, getattr(self, 'B_mask' + suf)))
@@ -331,25 +330,27 @@ class GeomGMIFWForeModel(BaseModel):
             self._notice('landmarks', 'no landmark regressor: geometry loss (lambda_geom) is skipped')
         if o.lambda_geom_lipline > 0:                                             # :715-719
             m1, m2 = self.getlipline(self.target_B_lm_68), self.getlipline(self.target_B2_lm_68)
-            self.loss_geom_B_lipline = (torch.mean((self.fake_B + 1) * m1)
-                                        + torch.mean((self.fake_B2 + 1) * m2)) * o.lambda_geom_lipline
+            self.loss_geom_B_lipline = (losses.weighted_mean(self.fake_B, m1, 1.0)
+                                        + losses.weighted_mean(self.fake_B2, m2, 1.0)) * o.lambda_geom_lipline
             loss = loss + self.loss_geom_B_lipline
         if o.warp_loss:                                                           # :734-735
-            self.loss_warp_B = F.l1_loss(self.fake_B, self.fakeB_static_warp) * o.lambda_warp
+            self.loss_warp_B = losses.l1_loss(self.fake_B, self.fakeB_static_warp.detach(), o.lambda_warp)
             loss = loss + self.loss_warp_B
         rc = lambda lm: lm[:, :, [1, 0]]                                          # noqa: E731
         self.fake_B_warp = warp_nchw(self.fake_B.detach(), rc(self.target_B_lm_68), rc(self.target_B2_lm_68))  # :738
-        self.loss_warp_inter1 = F.l1_loss(self.fake_B2, self.fake_B_warp) * o.lambda_warp_inter
+        self.loss_warp_inter1 = losses.l1_loss(self.fake_B2, self.fake_B_warp.detach(), o.lambda_warp_inter)
         loss = loss + self.loss_warp_inter1
         if self.aux['faceloss'] is not None and o.identity_loss in (1, 2):        # :741-752
-            rep = lambda x: x.repeat(1, 3, 1, 1) if x.shape[1] == 1 else x         # noqa: E731
+            fl = self.aux['faceloss']
+            # networks.FaceLoss reads a 1-channel drawing three times itself; other callables get the x3 repeat of :745-750
+            rep = (lambda x: x) if isinstance(fl, networks.FaceLoss) else \
+                (lambda x: x.repeat(1, 3, 1, 1) if x.shape[1] == 1 else x)         # noqa: E731
             if o.identity_loss == 1:
                 gray = 0.299 * self.real_A[:, 0:1] + 0.587 * self.real_A[:, 1:2] + 0.114 * self.real_A[:, 2:3]
                 other = rep(gray)
             else:
                 other = rep(self.fakeB_static)
-            self.loss_iden_B = torch.mean(self.aux['faceloss'](rep(self.fake_B), other, bbox1=self.winB,
-                                                               bbox2=self.winA)) * o.lambda_face
+            self.loss_iden_B = torch.mean(fl(rep(self.fake_B), other, bbox1=self.winB, bbox2=self.winA)) * o.lambda_face
             loss = loss + self.loss_iden_B
         elif o.identity_loss:
             self._notice('faceloss', 'no face-recognition network: identity loss (lambda_face) is skipped')

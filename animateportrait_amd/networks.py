@@ -433,10 +433,48 @@ class GANLoss(nn.Module):
         return t.expand_as(prediction)
 
     def __call__(self, prediction, target_is_real):
-        if self.gan_mode == 'lsgan':
-            t = self._labels[1 if target_is_real else 0]
-            return ((prediction - t) ** 2).mean()
+        if self.gan_mode == 'lsgan':                      # nn.MSELoss vs the expanded label: one fused reduction
+            from . import losses
+            return losses.lsgan_loss(prediction, self._labels[1 if target_is_real else 0])
         if self.gan_mode == 'vanilla':
             return nn.functional.binary_cross_entropy_with_logits(
                 prediction, self.get_target_tensor(prediction, target_is_real))
         return -prediction.mean() if target_is_real else prediction.mean()
+
+
+class FaceLoss(nn.Module):
+    """networks.py:2862-2966 around a frozen feature network: ``forward(imgs1, imgs2, bbox1=, bbox2=)`` crops the
+    ``[x1, x2, y1, y2]`` windows into ones-filled squares, resizes them to ``height x width`` (bilinear,
+    align_corners=True) and sums the L1 distances of the network's feature list (second argument detached).
+    The reference builds Sphere20a from ``checkpoints/sphere20a_20171020.pth`` (absent from its tree); here the
+    network is passed in (stock PyTorch-ROCm module), the crop + resize is one HIP launch each way."""
+
+    def __init__(self, net, height=112, width=96):
+        super().__init__()
+        self.net = net.eval()
+        self.height, self.width = height, width
+
+    def crop_head_bbox(self, imgs, bboxs):                                          # :2946-2966
+        from . import losses
+        n, c = imgs.shape[:2]
+        win = bboxs if (torch.is_tensor(bboxs) and bboxs.is_cuda and bboxs.dtype == torch.int32) else \
+            losses.windows_to_device(bboxs, n, imgs.device)
+        # the reference fills a 3-channel box from the image's channels; a 1-channel drawing was repeated x3 by the
+        # caller (geomgm_ifw_fore_model.py:745-750) -- reading channel 0 three times is the same tensor
+        return losses.crop_resize(imgs, win, (0, 0, 0) if c == 1 else (0, 1, 2), (self.height, self.width),
+                                  losses.RESIZE_BILINEAR_AC)
+
+    def compute_loss(self, img1, img2):                                            # :2926-2940
+        f1 = self.net(img1)
+        with torch.no_grad():
+            f2 = self.net(img2)
+        loss = 0.0
+        for a, b in zip(f1, f2):
+            loss = loss + nn.functional.l1_loss(a, b.detach())
+        return loss
+
+    def forward(self, imgs1, imgs2, kps1=None, kps2=None, bbox1=None, bbox2=None):
+        if kps1 is not None or kps2 is not None or bbox1 is None or bbox2 is None:
+            raise NotImplementedError('FaceLoss on the HIP path takes bbox1 / bbox2 (the only form the model uses, '
+                                      'geomgm_ifw_fore_model.py:745-752)')
+        return self.compute_loss(self.crop_head_bbox(imgs1, bbox1), self.crop_head_bbox(imgs2, bbox2))

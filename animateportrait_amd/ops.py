@@ -84,7 +84,7 @@ class Feat:
             partial, tiles = self.pending
             n, c, h, w = self.data.shape
             self._alloc_stats()
-            C.check(C.lib().ap_instnorm_finalize(_ptr(partial), n * c, tiles, h * w, EPS, _ptr(self._mean),
+            C.check(C.lib().ap_instnorm_finalize(_ptr(partial), _ptr(self.data), n * c, tiles, h * w, EPS, _ptr(self._mean),
                                                  _ptr(self._rstd), _stream()), 'instnorm_finalize')
             self.pending = None
 
@@ -523,9 +523,19 @@ def grid_sample(x, grid, align_corners=False):
 
 
 # =============================================================================== backward ops
-def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
+def _grad_out(out, shape, device):
+    """The tensor a gradient kernel writes: the caller's slot (a contiguous view of a gradient block) or a new one."""
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+        raise ValueError('gradient slot of shape %s for a gradient of shape %s' % (tuple(out.shape), tuple(shape)))
+    return out
+
+
+def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
-    srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW).
+    srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW): ``out`` when given
+    (the layer's slot in the network's contiguous gradient block), else a new tensor.
     precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers)."""
     n, m, gh, gw = g.data.shape
     cin = sum(f.data.shape[1] for f in srcs)
@@ -540,7 +550,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
         s.data, s.C, s.act = f.data.data_ptr(), cin, f.act
         if f.virtual:
             s.mean, s.rstd = f.mean.data_ptr(), f.rstd.data_ptr()
-        dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+        dw = _grad_out(out, out_shape, g.data.device)
         C.check(C.lib().ap_conv_head_wgrad(ctypes.byref(s), _ptr(g.data), n, f.data.shape[2], f.data.shape[3], k, pad,
                                            _ptr(dw), _stream()), 'conv_head_wgrad')
         return dw
@@ -557,12 +567,13 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
         h, w = f.data.shape[2:]
         ws = torch.empty(C.check(C.lib().ap_conv_final_wgrad_workspace_floats(n, cin, h, w), 'conv_final_wgrad_ws'),
                          dtype=torch.float32, device=g.data.device)
-        dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+        dw = _grad_out(out, out_shape, g.data.device)
         C.check(C.lib().ap_conv_final_wgrad(ctypes.byref(s), _ptr(g.data), n, h, w, k, pad, pad_mode, _ptr(ws), _ptr(dw),
                                             _stream()), 'conv_final_wgrad')
         return dw
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
-        return _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
+        dw = _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
+        return dw if out is None else out.copy_(dw)
     d = C.ApWgradDesc()
     d.N, d.M, d.GH, d.GW = n, m, gh, gw
     d.H, d.W = srcs[0].data.shape[2], srcs[0].data.shape[3]
@@ -582,7 +593,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
     lib = C.lib()
     nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
     ws = torch.empty(nws, dtype=torch.float32, device=g.data.device)
-    dw = torch.empty(out_shape, dtype=torch.float32, device=g.data.device)
+    dw = _grad_out(out, out_shape, g.data.device)
     assert dw.numel() == m * cin * k * k
     C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
     return dw
@@ -674,9 +685,9 @@ def act_bwd(contribs, out, act):
     return dy
 
 
-def bias_grad(dy):
+def bias_grad(dy, out=None):
     n, c, h, w = dy.shape
-    db = torch.empty(c, dtype=torch.float32, device=dy.device)
+    db = _grad_out(out, (c,), dy.device)
     lib = C.lib()
     if c >= 128:
         C.check(lib.ap_bias_grad(_ptr(dy), n, c, h * w, _ptr(db), _stream()), 'bias_grad')

@@ -34,6 +34,7 @@ class FlatAdam(torch.optim.Optimizer):
                 self.flat[off:off + k].copy_(p.detach().reshape(-1))
                 p.data = self.flat[off:off + k].view_as(p)          # parameter becomes a view of the flat buffer
                 p.grad = self.flat_grad[off:off + k].view_as(p)     # so does its gradient
+                p._flat_owner, p._flat_off = self, off              # autograd.Tape.grad_block writes there directly
                 off += k
 
     def zero_grad(self, set_to_none=False):

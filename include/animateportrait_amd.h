@@ -151,8 +151,10 @@ int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t t
 int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen);
 
 /* ---- InstanceNorm2d(affine=False, eps) : networks.py:33-34 (F.instance_norm)
- * finalize: partial tiles -> mean[n,c], rstd[n,c] (biased variance); count = Hout*Wout */
-int ap_instnorm_finalize(const float* stat_partials, int32_t NC, int32_t tiles, int32_t count,
+ * finalize: partial tiles -> mean[n,c], rstd[n,c] (biased variance); count = Hout*Wout.  y (nullable): the convolution
+ * output the tiles were summed over ([NC][count]); when given, planes whose |mean| is many standard deviations -- where
+ * E[x^2] - E[x]^2 of fp32 sums is rounding noise -- are recomputed from it with the shifted two-pass formula. */
+int ap_instnorm_finalize(const float* stat_partials, const float* y, int32_t NC, int32_t tiles, int32_t count,
                          float eps, float* mean, float* rstd, ap_stream_t stream);
 /* out = act((x - mean) * rstd) + residual, where residual is
  *   NULL, a plain tensor (res_mean == NULL), or itself normalised: (res - res_mean) * res_rstd.
@@ -277,6 +279,63 @@ int ap_tps_warp(const float* img, const float* dst, const float* coef, int32_t B
  * (Module2/models/geomgm_ifw_fore_model.py:346-360); step counts from 1. */
 int ap_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, ap_stream_t stream);
+
+/* ======================================================================= losses, compositing, aux-net glue, rasterisers
+ * (csrc/losses.hip).  Reductions are deterministic (fixed-order two-stage sums); `workspace` holds
+ * ap_reduce_workspace_floats() floats.
+ *
+ * ap_reduce_mean: out[0] = weight * mean(term_i), i < n, with
+ *   op 0  term = (a_i - c)^2            GANLoss('lsgan'), c = 1.0 / 0.0 (Module2/models/networks.py:429-430, 455-473)
+ *   op 1  term = |a_i - b_i|            nn.L1Loss (warp / coherence losses, geomgm_ifw_fore_model.py:734-739)
+ *   op 2  term = (a_i + c) * b_i        lip-line loss mean((fake + 1) * mask) (:715-719)
+ * ap_reduce_mean_bwd: ga_i = gout[0] * weight / n * d term_i / d a_i (gout: device scalar, no host sync). */
+int64_t ap_reduce_workspace_floats(void);
+int ap_reduce_mean(int32_t op, const float* a, const float* b, float c, int64_t n, float weight, float* workspace,
+                   float* out, ap_stream_t stream);
+int ap_reduce_mean_bwd(int32_t op, const float* a, const float* b, float c, int64_t n, float weight, const float* gout,
+                       float* ga, ap_stream_t stream);
+/* Mask compositing in the reference's operation order (bit-identical to the ATen chain).  a: N x C x HW, m: N x 1 x HW,
+ * s: N x Cs x HW (Cs = 1 or C, mode 2 only); out: N x (C + append_mask) x HW, the appended channel is m.
+ *   mode 0  (a/2+.5)*m*2-1                         BaseModel.masked type 0 (base_model.py:240-241)
+ *   mode 1  ((a/2+.5)*m + 1 - m)*2-1               masked type 1 / 3 (:242-247), foreground on white (geomgm_ifw_fore_model.py:523-527)
+ *   mode 2  ((a/2+.5)*m + (s/2+.5)*(1-m))*2-1      background blend with the static drawing (:541, 543)
+ *   mode 3  a                                      masked type 2 (append_mask = 1)
+ * ap_mask_composite_bwd: ga = g[:, :C] * m (modes 0-2) / g[:, :C] (mode 3); g has GC >= C channels. */
+int ap_mask_composite(const float* a, const float* m, const float* s, int32_t N, int32_t C, int32_t Cs, int32_t HW,
+                      int32_t mode, int32_t append_mask, float* out, ap_stream_t stream);
+int ap_mask_composite_bwd(const float* g, const float* m, int32_t N, int32_t C, int32_t GC, int32_t HW, int32_t mode,
+                          float* ga, ap_stream_t stream);
+/* dst += alpha * src: accumulation of a network's gradient block into the optimiser's flat gradient buffer
+ * (what autograd's AccumulateGrad does per parameter in the reference, loss.backward() at :586, 610, 634, 780). */
+int ap_axpy(float* dst, const float* src, int64_t n, float alpha, ap_stream_t stream);
+/* Window crop into a ones-filled (x2-x1)^2 box + resize, fused: the glue in front of the frozen auxiliary nets.
+ *   get_lm (geomgm_ifw_fore_model.py:390-410): BGR / x3 channel map, bicubic align_corners=False to 112^2, (v+1)*0.5
+ *   FaceLoss.crop_head_bbox (networks.py:2946-2966): bilinear align_corners=True to 112 x 96
+ * x: N x C x H x W; win: N x 4 int32 ON THE DEVICE, [x1, x2, y1, y2] per sample; out: N x OC x OH x OW (OC <= 4),
+ * out[:, k] = scale * resize(box of channel (chmap >> 8k) & 255) + shift.  mode 0 bilinear/align_corners=True,
+ * mode 1 bicubic (A = -0.75)/align_corners=False.  ap_crop_resize_bwd: gx (N x C x H x W, zeroed inside) = d/dx. */
+int ap_crop_resize_fwd(const float* x, const int32_t* win, int32_t N, int32_t C, int32_t H, int32_t W, int32_t OC,
+                       int32_t chmap, int32_t OH, int32_t OW, int32_t mode, float scale, float shift, float* out,
+                       ap_stream_t stream);
+int ap_crop_resize_bwd(const float* gout, const int32_t* win, int32_t N, int32_t C, int32_t H, int32_t W, int32_t OC,
+                       int32_t chmap, int32_t OH, int32_t OW, int32_t mode, float scale, float* gx, ap_stream_t stream);
+/* kp_to_map(mode='binary') (geomgm_ifw_fore_model.py:19-44): lm N x P x 2 (x, y) -> out N x P x S x S in {0, 1},
+ * out = ((x - lm_x*num/den)^2 + (y - lm_y*num/den)^2 <= radius^2); the reference calls it with S=224, num/den = 7/8,
+ * radius 4 on the CPU with numpy (:71-73) -- a GPU -> CPU -> GPU round trip per frame there. */
+int ap_kp_to_map(const float* lm, int32_t N, int32_t P, int32_t S, float num, float den, float radius, float* out,
+                 ap_stream_t stream);
+/* Tail of flow_network_warp (geomgm_ifw_fore_model.py:75-83): mask = (argmax_c vis < 2), flow' = flow * gain * mask / den
+ * * num, both resized S -> OS bilinear align_corners=True.  flow N x 2 x S x S, vis N x VC x S x S ->
+ * flow_out N x 2 x OS x OS, mask_out N x 1 x OS x OS.  Reference values: gain 20, num/den = 8/7, S 224, OS 256. */
+int ap_flow_post(const float* flow, const float* vis, int32_t N, int32_t VC, int32_t S, int32_t OS, float gain, float num,
+                 float den, float* flow_out, float* mask_out, ap_stream_t stream);
+/* draw2(op=0) (Module2/data/umlvdfw_test_dataset.py:34-41): filled cv2.circle(radius) at np.round(lm) for every
+ * landmark; out N x 1 x H x W = hi inside / lo outside (the reference: +1 / -1).  The disc is OpenCV's octant-walk
+ * fill (drawing.cpp Circle(), opencv-python 4.2 pinned by requirements.txt:2), whose row half-widths
+ * ap_circle_rows returns (hw[0..radius]); radius <= 31. */
+int ap_landmark_discs(const float* lm, int32_t N, int32_t P, int32_t H, int32_t W, int32_t radius, float lo, float hi,
+                      float* out, ap_stream_t stream);
+int ap_circle_rows(int32_t radius, int32_t* hw);
 
 #ifdef __cplusplus
 }

@@ -4,8 +4,16 @@ Follows Module2/models/geomgm_ifw_fore_model.py: forward :517-565, backward_G :6
 backward_D_basic3 :613-635, backward_D_basic2 :589-611, with the batched semantics the build defines
 ("reference b=1 applied per sample, mean-reduced losses averaged over the batch").  The frozen auxiliary
 networks (MODNet / MobileFaceNet / Sphere20a / FlowUnet) are not in the reference tree; their outputs are part
-of the batch (``mask``, ``iw_flow``, ``if_mask`` ...) and the geometry / identity terms are left out, exactly as
-the product model does when no aux callable is registered.
+of the batch (``mask``, ``iw_flow``, ``if_mask`` ...).  The geometry (:704-713) and identity (:741-752) terms run
+when ``aux`` supplies a landmark regressor / a face feature network (tests pass the fixed-seed stand-ins of
+``animateportrait_amd/standins.py`` to both sides), through ``oracle.aux_glue`` -- which
+is pinned to the reference's own ``get_lm`` / ``FaceLoss`` (tests/golden/aux.npz); without ``aux`` they are left
+out, exactly as the product model does when no aux callable is registered.
+
+``overrides``: the three TPS-warped constants (``mask1``, ``mask2``, ``fakeB_static_warp``) and ``fake_B_warp`` may be
+supplied by the caller.  The fp32 spline solve is ill-conditioned (0.1-0.2 px between any two fp32 evaluations, see
+tests/test_train_gpu.py::test_tps_vs_reference_golden); the composed-gradient test feeds the product's warps here
+so that every other difference is held to fp32-rounding level.
 
 The reference model class itself cannot be instantiated here (cv2, .cuda(), absent checkpoints -- SURVEY.md
 section 8c); the pieces this composition is made of (G, D, GANLoss, masked, sparse_image_warp) are each pinned to
@@ -14,7 +22,7 @@ goldens captured from the reference.
 import torch
 import torch.nn.functional as F
 
-from . import generator as og, discriminator as od, losses as ol, tps as ot
+from . import generator as og, discriminator as od, losses as ol, tps as ot, aux_glue as oa
 
 
 class Opt:
@@ -31,6 +39,10 @@ class Opt:
     lambda_geom_lipline = 50.0
     lambda_warp = 5.0
     lambda_warp_inter = 10.0
+    lambda_geom = 50.0
+    more_weight_for_lip = 2
+    lambda_face = 3.0
+    identity_loss = 2
     crop_size = 256
     div, disp = 3, 3
     thickness = 2
@@ -60,10 +72,11 @@ def warp_nchw(img, src_xy, dst_xy):
     return w.permute(0, 3, 1, 2)
 
 
-def forward(sdG, batch, opt=Opt):
+def forward(sdG, batch, opt=Opt, overrides=None):
     """:517-565 -> dict of tensors (fake_B, fake_B2, local crops, warped static drawing ...)."""
     o = {}
-    mask = (batch['mask'] > 0.5).float()
+    ov = overrides or {}
+    mask = (batch['mask'] > 0.5).to(batch['mask'].dtype)
     real_A_fore = ol.fore_composite(batch['A'], mask)
     gen = lambda tlm, mo, fl, im: og.generator_forward(sdG, real_A_fore, batch['A_lm'], tlm, mo, fl, im,  # noqa: E731
                                                        div=opt.div, disp=opt.disp)
@@ -71,8 +84,8 @@ def forward(sdG, batch, opt=Opt):
     fake_B2 = gen(batch['tB2_lm'], batch['warp_motion2'], batch['iw_flow2'], batch['if_mask2'])
     o['fake_B_fore'], o['fake_B2_fore'] = fake_B, fake_B2
     if opt.blendbg:
-        mask1 = warp_nchw(mask, batch['A_lm_68'], batch['tB_lm_68'])
-        mask2 = warp_nchw(mask, batch['A_lm_68'], batch['tB2_lm_68'])
+        mask1 = ov['mask1'] if 'mask1' in ov else warp_nchw(mask, batch['A_lm_68'], batch['tB_lm_68'])
+        mask2 = ov['mask2'] if 'mask2' in ov else warp_nchw(mask, batch['A_lm_68'], batch['tB2_lm_68'])
         fake_B = ol.bg_blend(fake_B, batch['fakeB_static'], mask1)
         fake_B2 = ol.bg_blend(fake_B2, batch['fakeB_static'], mask2)
     o['fake_B'], o['fake_B2'] = fake_B, fake_B2
@@ -81,12 +94,13 @@ def forward(sdG, batch, opt=Opt):
         o['fake_B2_l' + suf] = ol.masked(fake_B2, batch['B2_mask' + suf], opt.mask_type)
         o['real_B_l' + suf] = ol.masked(batch['B'], batch['Br_mask' + suf], opt.mask_type)
     # blendbg=1: real_A_lm_681 is the plain 68-point set (no edge points), :534-536 then :558-565
-    o['fakeB_static_warp'] = warp_nchw(batch['fakeB_static'], batch['A_lm_68'], batch['tB_lm_68'])
+    o['fakeB_static_warp'] = ov['fakeB_static_warp'] if 'fakeB_static_warp' in ov else \
+        warp_nchw(batch['fakeB_static'], batch['A_lm_68'], batch['tB_lm_68'])
     return o
 
 
-def g_loss(sdD, o, batch, opt=Opt):
-    """:677-780 without the geometry / identity terms.  sdD: dict name -> discriminator params."""
+def g_loss(sdD, o, batch, opt=Opt, aux=None, overrides=None):
+    """:677-780.  sdD: dict name -> discriminator params; aux: {'landmarks': net, 'faceloss': net} (optional)."""
     gan = ol.gan_loss_lsgan
     D = od.patchgan_forward
     terms = {}
@@ -99,8 +113,27 @@ def g_loss(sdD, o, batch, opt=Opt):
     m2 = lipline(batch['tB2_lm_68'], opt.crop_size, opt.thickness)
     terms['geom_B_lipline'] = (torch.mean((o['fake_B'] + 1) * m1) + torch.mean((o['fake_B2'] + 1) * m2)) * opt.lambda_geom_lipline
     terms['warp_B'] = F.l1_loss(o['fake_B'], o['fakeB_static_warp']) * opt.lambda_warp
-    fake_B_warp = warp_nchw(o['fake_B'].detach(), batch['tB_lm_68'], batch['tB2_lm_68'])
+    ov = overrides or {}
+    fake_B_warp = ov['fake_B_warp'] if 'fake_B_warp' in ov else \
+        warp_nchw(o['fake_B'].detach(), batch['tB_lm_68'], batch['tB2_lm_68'])
     terms['warp_inter1'] = F.l1_loss(o['fake_B2'], fake_B_warp) * opt.lambda_warp_inter
+    aux = aux or {}
+    cs = opt.crop_size
+    if aux.get('landmarks') is not None:                                           # :704-713
+        mse = F.mse_loss
+        lm1 = oa.get_lm(aux['landmarks'], o['fake_B'], batch['winB'])
+        lm2 = oa.get_lm(aux['landmarks'], o['fake_B2'], batch['winB2'])
+        t1, t2 = batch['tB_lm_68'][:, :68].to(lm1.dtype), batch['tB2_lm_68'][:, :68].to(lm1.dtype)
+        if opt.more_weight_for_lip != 2:
+            g = mse(lm1 / cs, t1 / cs) + mse(lm2 / cs, t2 / cs)
+        else:
+            g = (mse(lm1[:, :48] / cs, t1[:, :48] / cs) + 2 * mse(lm1[:, 48:68] / cs, t1[:, 48:68] / cs)
+                 + mse(lm2[:, :48] / cs, t2[:, :48] / cs) + 2 * mse(lm2[:, 48:68] / cs, t2[:, 48:68] / cs))
+        terms['geom_B'] = g * opt.lambda_geom
+    if aux.get('faceloss') is not None and opt.identity_loss == 2:                 # :748-752
+        rep = lambda x: x.repeat(1, 3, 1, 1)                                       # noqa: E731
+        terms['iden_B'] = torch.mean(oa.face_loss(aux['faceloss'], rep(o['fake_B']), rep(batch['fakeB_static']),
+                                                  batch['winB'], batch['winA'])) * opt.lambda_face
     terms['G'] = sum(terms.values())
     return terms
 

@@ -797,3 +797,35 @@ def test_conv_bf16x3_strided_and_transposed(dev, case):
         yn = layer.run(feat, norm_act=ops.ACT_NONE)
         got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
         assert linf(got, F.instance_norm(ref.float())) < (2e-3 if prec == ops.PRECISION_BF16X3 else 1e-4)
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'fp32'])
+def test_instnorm_ill_conditioned_planes(dev, precision, monkeypatch):
+    """ADVICE r1 (instnorm.hip): a plane whose |mean| is hundreds of standard deviations -- what a PatchGAN sees on a
+    mostly-white masked crop (base_model.py:245-247) -- must still be normalised like F.instance_norm: the statistics
+    from the conv epilogue's fp32 (sum, sum of squares) tiles are recomputed from the data for such planes, in both
+    consumers (standalone finalize and the fused norm / split pass)."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_FP32 if precision == 'fp32' else ops.PRECISION_BF16X3)
+    g = torch.Generator().manual_seed(77)
+    n, cin, c, h, w = 2, 32, 64, 64, 64
+    x = torch.ones(n, cin, h, w) + torch.randn(n, cin, h, w, generator=g) * 1e-3      # near-constant input planes
+    x[:, :, 20:28, 30:40] += torch.randn(n, cin, 8, 10, generator=g) * 0.05            # a small textured box
+    layer = ConvLayer([cin], c, 3, 1, 1, ops.PAD_REFLECT).to(dev)
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) * 0.05 + 0.02)
+    src = ops.Feat(x.to(dev))
+    a = layer.run(src, norm_act=ops.ACT_NONE)
+    b = layer.run(src, norm_act=ops.ACT_NONE)
+    raw = a.data.double().cpu()
+    ratio = (raw.mean(dim=(2, 3)) ** 2 / raw.var(dim=(2, 3), unbiased=False)).min()
+    assert float(ratio) > 100.0                                   # the case under test: |mean| > 10 std everywhere
+    ref = F.instance_norm(raw)                                    # fp64 on the kernel's own conv output
+    y_fin = (a.data - a.mean.view(n, c, 1, 1)) * a.rstd.view(n, c, 1, 1)              # standalone finalize (+ refine)
+    assert linf(y_fin, ref) < 5e-4 * float(ref.abs().max())
+    y_ns, _ = ops._norm_apply_split(b, None, want_y=True, want_xs=False)               # fused pass, inline recompute
+    assert linf(y_ns, ref) < 5e-4 * float(ref.abs().max())
+    assert linf(b.rstd, a.rstd) <= 1e-6 * float(a.rstd.abs().max())
+    rstd_ref = 1.0 / torch.sqrt(raw.var(dim=(2, 3), unbiased=False) + 1e-5)
+    assert float(((a.rstd.view(n, c).double().cpu() - rstd_ref) / rstd_ref).abs().max()) < 1e-4

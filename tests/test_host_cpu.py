@@ -150,8 +150,9 @@ def test_ganloss_and_scheduler(golden):
     from animateportrait_amd import networks as N
     gd = golden('losses.npz')
     crit = N.GANLoss('lsgan')
-    assert abs(float(crit(gd['pred'], True)) - float(gd['gan_real'])) < 1e-6
-    assert abs(float(crit(gd['pred'], False)) - float(gd['gan_fake'])) < 1e-6
+    # the lsgan reduction is a HIP kernel (ap_reduce_mean): no CPU path; its golden check is in test_losses_gpu.py
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        crit(gd['pred'], True)
     ad = golden('adam.npz')
 
     class Opt:

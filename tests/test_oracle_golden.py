@@ -197,3 +197,76 @@ def test_tps_batched_equals_per_sample():
     for i in range(3):
         wi, fi = ot.sparse_image_warp(img[i:i + 1], src[i:i + 1], dst[i:i + 1])
         assert linf(w[i:i + 1], wi) < 1e-4 and linf(fl[i:i + 1], fi) < 1e-4
+
+
+# ------------------------------------------------------------------ glue around the frozen aux nets (aux.npz)
+def _aux_inputs(gd, c, i):
+    seed = int(gd['lm_c%d_%d_seed' % (c, i)])
+    x = torch.rand(1, c, 256, 256, generator=torch.Generator().manual_seed(seed)) * 2 - 1
+    return x, gd['lm_c%d_%d_win' % (c, i)]
+
+
+def test_get_lm_crop_bicubic_vs_reference(golden):
+    """oracle.aux_glue.get_lm == GeomGMIFWForeModel.get_lm (geomgm_ifw_fore_model.py:390-415) run by
+    make_aux_golden.py with the stand-in landmark net: the tensor fed to the net and the re-projected landmarks."""
+    from oracle import aux_glue as oa
+    from animateportrait_amd import standins
+    gd = golden('aux.npz')
+    net = standins.StandinLandmarkNet()
+    for c in (1, 3):
+        for i in range(3):
+            x, win = _aux_inputs(gd, c, i)
+            box = oa.get_lm_box(x, win)
+            ref = gd['lm_c%d_%d_box' % (c, i)]
+            assert linf(box[:, :ref.shape[1]], ref) < 1e-6
+            assert np.allclose(box.double().sum(dim=(0, 2, 3)).numpy(), gd['lm_c%d_%d_boxsum' % (c, i)], rtol=1e-9)
+            assert linf(oa.get_lm(net, x, win), gd['lm_c%d_%d_out' % (c, i)]) < 1e-4     # pixels
+
+
+def test_faceloss_crop_and_feature_l1_vs_reference(golden):
+    """oracle.aux_glue.face_loss == networks.FaceLoss.forward (networks.py:2881-2966) with the stand-in feature net."""
+    from oracle import aux_glue as oa
+    from animateportrait_amd import standins
+    gd = golden('aux.npz')
+    net = standins.StandinFaceNet()
+    a = (torch.rand(2, 1, 256, 256, generator=torch.Generator().manual_seed(int(gd['fl_seed_a']))) * 2 - 1)
+    b = (torch.rand(2, 1, 256, 256, generator=torch.Generator().manual_seed(int(gd['fl_seed_b']))) * 2 - 1)
+    a.requires_grad_(True)
+    h1 = oa.crop_head_bbox(a.repeat(1, 3, 1, 1), gd['fl_bb1'])
+    h2 = oa.crop_head_bbox(b.repeat(1, 3, 1, 1), gd['fl_bb2'])
+    assert linf(h1[:, :1], gd['fl_head1']) < 1e-6 and linf(h2[:, :1], gd['fl_head2']) < 1e-6
+    loss = oa.face_loss(net, a.repeat(1, 3, 1, 1), b.repeat(1, 3, 1, 1), gd['fl_bb1'], gd['fl_bb2'])
+    assert abs(float(loss) - float(gd['fl_loss'])) < 1e-6
+    loss.backward()
+    assert linf(a.grad[:, :, ::4, ::4], gd['fl_grad_a_sub']) < 1e-8
+    assert abs(float(a.grad.double().abs().sum()) - float(gd['fl_grad_a_abs'])) < 1e-6 * float(gd['fl_grad_a_abs'])
+
+
+def test_kp_to_map_and_flow_network_warp_vs_reference(golden):
+    """oracle.aux_glue == kp_to_map_some / flow_network_warp (geomgm_ifw_fore_model.py:19-51, 69-84)."""
+    from oracle import aux_glue as oa
+    from animateportrait_amd import standins
+    gd = golden('aux.npz')
+    j1 = oa.kp_to_map_some((224, 224), gd['kp_lm1'].numpy() * 7 / 8)
+    assert np.array_equal(j1.numpy().astype(np.uint8), gd['kp_j1'])
+    wf, rm = oa.flow_network_warp(standins.StandinFlowNet(), torch.zeros(1, 3, 256, 256), gd['kp_lm1'], gd['kp_lm2'])
+    assert linf(wf[:, :, ::2, ::2], gd['fw_flow_sub']) < 1e-5 and linf(rm[:, :, ::2, ::2], gd['fw_mask_sub']) < 1e-6
+    assert abs(float(wf.double().abs().sum()) - float(gd['fw_flow_abs'])) < 1e-6 * float(gd['fw_flow_abs'])
+    assert float(rm.double().sum()) == pytest.approx(float(gd['fw_mask_sum']), rel=1e-7)
+
+
+def test_cv2_filled_circle_rule_table():
+    """draw2(op=0) uses cv2.circle(..., -1).  cv2 is absent here (parity unpinned for this one function): the oracle
+    restates OpenCV's octant walk; this table is what that rule gives for the small radii -- the r=1 plus, the r=2
+    diamond, and the r=3 disc of the reference's landmark maps (row half-widths for |dy| = 0..r) -- and the C
+    library's host-side table (what ap_landmark_discs rasterises) agrees with the oracle for every radius."""
+    from oracle import aux_glue as oa
+    from animateportrait_amd import losses
+    table = {0: [0], 1: [1, 0], 2: [2, 1, 0], 3: [3, 2, 2, 0], 4: [4, 3, 3, 2, 0], 5: [5, 4, 4, 4, 3, 0]}
+    for r, hw in table.items():
+        assert oa.cv2_filled_circle_rows(r) == hw, r
+    for r in range(0, 32):
+        assert losses.circle_rows(r) == oa.cv2_filled_circle_rows(r), r
+    img = oa.draw2(16, 16, [[7.5, 8.0], [0.2, 15.0]], 3)       # np.round: 7.5 -> 8 (half to even); clipping at the border
+    pix = (img[0] > 0).numpy()
+    assert pix.sum() == 29 + 11 and pix[8, 5:12].all() and pix[5, 8] and not pix[5, 7]

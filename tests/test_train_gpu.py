@@ -74,9 +74,30 @@ def _make_model(dev, ngf=8, ndf=8):
     return create_model(opt), opt
 
 
-def test_train_step_losses_and_grads_vs_oracle(dev):
-    """One G step and one D step (ngf=ndf=8, B=2): every loss term and the gradient norms of the product model
-    against the CPU oracle composition."""
+def _relerr(a, b64):
+    b64 = b64.double()
+    return float((a.detach().cpu().double() - b64).abs().max() / b64.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize('precision', ['bf16x3', 'fp32'])
+def test_train_step_losses_and_grads_vs_oracle(dev, precision, monkeypatch):
+    """One G step and one D step of the drawing configuration (ngf=ndf=8, B=2) WITH the geometry and identity
+    branches (stand-in landmark / face nets): every loss term, and every gradient tensor
+    ELEMENTWISE, against the CPU oracle composition evaluated in fp64.  Bar per tensor: as close to the fp64 truth as
+    the oracle's own fp32 evaluation is (x3), which is how the reference itself would fare -- weight gradients behind
+    InstanceNorm are cancellation-dominated.  The TPS-warped constants are handed from the product to the oracle
+    (their own parity: test_tps_*), so every remaining difference is arithmetic of the path under test.
+    Two arithmetic modes: exact fp32 MFMA (APAMD_PRECISION=fp32; bar = 3x the oracle's fp32 noise + 5e-5: the
+    composition -- tape accumulation over 2B batches and five D's, reflection-pad folds, fused losses -- is exact) and
+    the default split-bf16 mode (fp32-class products, ~2^-16 each: + 2e-3 for the generator, the gradient
+    counterpart of the 1e-3 L-inf output budget; + 1e-2 for the discriminators' weight gradients: on a mostly-white
+    masked crop sum_pix g * a cancels to ~1e-3 of sum |g * a| -- the activation plane is almost constant and the
+    InstanceNorm gradient sums to zero -- so the 2^-16 product error is amplified; fp32 mode shows the schedule
+    itself is exact)."""
+    from animateportrait_amd import networks as N, standins, ops
+    monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_FP32 if precision == 'fp32' else ops.PRECISION_BF16X3)
+    floor = 5e-5 if precision == 'fp32' else 2e-3
+    floor_d = 5e-5 if precision == 'fp32' else 1e-2
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
     from oracle import generator as og, discriminator as od, train_step as ts
     torch.manual_seed(0)
@@ -84,53 +105,85 @@ def test_train_step_losses_and_grads_vs_oracle(dev):
     sdG = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=11)
     model.netG_A.load_state_dict(sdG, strict=True)
     sdD = {}
-    for i, name in enumerate(['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']):
-        cin = 1 if name == 'D_A' else 2
-        sdD[name] = og.init_params(od.patchgan_param_shapes(cin, 8), seed=20 + i)
+    dnames = ['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']
+    for i, name in enumerate(dnames):
+        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, 8), seed=20 + i)
         getattr(model, 'net' + name).load_state_dict(sdD[name], strict=True)
+    model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
+    model.aux['faceloss'] = N.FaceLoss(standins.StandinFaceNet().to(dev))
     batch = make_train_batch(2, seed=5)
-    # ---------------- oracle
-    for v in sdG.values():
-        v.requires_grad_(True)
-    o = ts.forward(sdG, batch)
-    terms = ts.g_loss(sdD, o, batch)
-    terms['G'].backward()
-    for sd in sdD.values():
-        for v in sd.values():
-            v.requires_grad_(True)
-    dl = ts.d_losses(sdD, o, batch)
-    sum(dl.values()).backward()
+    batch['winB'] = torch.tensor([[32, 224, 32, 224], [-12, 200, 24, 230]])        # one window leaves the frame
+    batch['winB2'] = torch.tensor([[30, 226, 28, 220], [40, 260, 50, 256]])
+    batch['winA'] = torch.tensor([[36, 220, 30, 210], [20, 230, 20, 228]])
     # ---------------- product
     model.set_input(batch)
     model.forward()
-    assert linf(model.fake_B_fore, o['fake_B_fore']) < 1e-3 and linf(model.fake_B2_fore, o['fake_B2_fore']) < 1e-3
-    # after the background blend the TPS-warped binary mask enters: its fp32 flow is only good to ~0.1 px
-    # (see test_tps_vs_reference_golden), which moves edge pixels of the blend -- compare in the mean
-    assert float((model.fake_B.detach().cpu() - o['fake_B']).abs().mean()) < 1e-3
-    assert float((model.fakeB_static_warp.cpu() - o['fakeB_static_warp']).abs().mean()) < 4e-3
     nets_D = [getattr(model, 'net' + n) for n in model.model_names[1:]]
     model.set_requires_grad(nets_D, False)
     model.optimizer_G.zero_grad()
     model.backward_G()
-    for k in ('G_A', 'G_A_l', 'G_A_le', 'G_A_ll', 'G_A_coh', 'geom_B_lipline', 'warp_B', 'warp_inter1', 'G'):
-        a, b = float(getattr(model, 'loss_' + k)), float(terms[k])
-        assert abs(a - b) <= 1e-2 * abs(b) + 1e-4, (k, a, b)
-    gn = {k: float(p.grad.double().norm()) for k, p in model.netG_A.named_parameters()}
-    rn = {k: float(v.grad.double().norm()) for k, v in sdG.items()}
-    for k in rn:
-        if k.endswith('.weight'):
-            assert abs(gn[k] - rn[k]) <= 5e-2 * rn[k] + 1e-6, (k, gn[k], rn[k])
+    gG = {k: p.grad.detach().clone().cpu() for k, p in model.netG_A.named_parameters()}
     model.set_requires_grad(nets_D, True)
     model.optimizer_D.zero_grad()
     model.backward_D_A(); model.backward_D_A_l(); model.backward_D_A_le(); model.backward_D_A_ll(); model.backward_D_A_coh()
-    for name in ('D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh'):
-        a, b = float(getattr(model, 'loss_' + name)), float(dl[name])
-        assert abs(a - b) <= 1e-2 * abs(b) + 1e-5, (name, a, b)
-        net = getattr(model, 'net' + name)
-        for k, p in net.named_parameters():
-            if k.endswith('.weight'):
-                r = float(sdD[name][k].grad.double().norm())
-                assert abs(float(p.grad.double().norm()) - r) <= 3e-2 * r + 1e-6, (name, k)
+    gD = {n: {k: p.grad.detach().clone().cpu() for k, p in getattr(model, 'net' + n).named_parameters()} for n in dnames}
+    from animateportrait_amd.models.sparse_image_warp import check_status
+    check_status()
+    ov32 = {k: getattr(model, k).detach().cpu() for k in ('mask1', 'mask2', 'fakeB_static_warp', 'fake_B_warp')}
+    # the D step is checked on the product's own generated frames (their parity is asserted above at 1e-3; a 1e-4
+    # input difference would otherwise dominate D gradients whose fp32 noise is 1e-6)
+    fakes32 = {k: getattr(model, k).detach().cpu() for k in ('fake_B', 'fake_B2', 'fake_B_l', 'fake_B2_l', 'fake_B_le',
+                                                              'fake_B2_le', 'fake_B_ll', 'fake_B2_ll')}
+    # ---------------- oracle, fp32 (what the reference's arithmetic gives) and fp64 (the truth)
+    res = {}
+    for tag, dt in (('f32', torch.float32), ('f64', torch.float64)):
+        cast = lambda t: t.to(dt) if torch.is_tensor(t) and t.is_floating_point() else t     # noqa: E731
+        sG = {k: cast(v).clone().requires_grad_(True) for k, v in sdG.items()}
+        sD = {n: {k: cast(v).clone() for k, v in sd.items()} for n, sd in sdD.items()}
+        b = {k: cast(v) for k, v in batch.items()}
+        ov = {k: cast(v) for k, v in ov32.items()}
+        aux = {'landmarks': standins.StandinLandmarkNet().to(dt), 'faceloss': standins.StandinFaceNet().to(dt)}
+        o = ts.forward(sG, b, overrides=ov)
+        terms = ts.g_loss(sD, o, b, aux=aux, overrides=ov)
+        terms['G'].backward()
+        for sd in sD.values():
+            for v in sd.values():
+                v.requires_grad_(True)
+        od_ = dict(o)
+        od_.update({k: cast(v) for k, v in fakes32.items()})
+        dl = ts.d_losses(sD, od_, b)
+        sum(dl.values()).backward()
+        res[tag] = dict(o=o, terms=terms, dl=dl, gG={k: v.grad for k, v in sG.items()},
+                        gD={n: {k: v.grad for k, v in sd.items()} for n, sd in sD.items()})
+    r32, r64 = res['f32'], res['f64']
+    # ---------------- forward tensors and loss terms
+    assert linf(model.fake_B_fore, r64['o']['fake_B_fore']) < 1e-3 and linf(model.fake_B2_fore, r64['o']['fake_B2_fore']) < 1e-3
+    assert linf(model.fake_B, r64['o']['fake_B']) < 1e-3 and linf(model.fake_B2, r64['o']['fake_B2']) < 1e-3
+    assert linf(model.fake_B_l, r64['o']['fake_B_l']) < 1e-3 and linf(model.real_B_ll, r64['o']['real_B_ll']) < 1e-6
+    for k in ('G_A', 'G_A_l', 'G_A_le', 'G_A_ll', 'G_A_coh', 'geom_B', 'geom_B_lipline', 'warp_B', 'warp_inter1',
+              'iden_B', 'G'):
+        a, t = float(getattr(model, 'loss_' + k)), float(r64['terms'][k])
+        assert abs(a - t) <= 1e-3 * abs(t) + 1e-5, (k, a, t)
+    for name in dnames:
+        a, t = float(getattr(model, 'loss_' + name)), float(r64['dl'][name])
+        assert abs(a - t) <= 1e-3 * abs(t) + 1e-6, (name, a, t)
+    # ---------------- gradients, elementwise, every tensor
+    bad = []
+
+    def check(tag, k, mine, g32, g64):
+        if float(g64.abs().max()) < 1e-12 or (k.endswith('.bias') and float(mine.abs().max()) == 0.0):
+            # bias in front of InstanceNorm: exact zero here, pure rounding noise in the reference
+            assert float(g64.abs().max()) < 1e-6 * max(1.0, float(r64['gG']['model_tri_merge.weight'].abs().max())), (tag, k)
+            return
+        e, noise = _relerr(mine, g64), _relerr(g32, g64)
+        if e > 3.0 * noise + (floor if tag == 'G' else floor_d):
+            bad.append((tag, k, e, noise))
+    for k in sdG:
+        check('G', k, gG[k], r32['gG'][k], r64['gG'][k])
+    for n in dnames:
+        for k in sdD[n]:
+            check(n, k, gD[n][k], r32['gD'][n][k], r64['gD'][n][k])
+    assert not bad, bad
 
 
 def test_optimize_parameters_runs_and_updates(dev):
