@@ -89,7 +89,14 @@ class Tape:
 
 # ------------------------------------------------------------------------------ conv layer
 def _dgrad_spec(layer, seg_c):
-    """ConvSpec of the operator that computes the data gradient for one input segment."""
+    """ConvSpec of the operator that computes the data gradient for one input segment (same arithmetic as the
+    layer's forward pass)."""
+    spec, fold = _dgrad_spec_geometry(layer, seg_c)
+    spec.precision = layer.spec.precision
+    return spec, fold
+
+
+def _dgrad_spec_geometry(layer, seg_c):
     s = layer.spec
     k = s.k
     if s.transposed:      # ConvTranspose2d(k, s=2, p): gradient is a stride-2 convolution, weight read as OIHW
@@ -114,9 +121,10 @@ def conv_backward(tape, layer, srcs, out, norm, act):
     if layer.weight.requires_grad:
         if s.transposed:
             # dW[ci][co*k*k]: M-role = the layer input (virtual allowed), shifted tensor = dy (stride 2)
-            dw = ops.wgrad(s.k, 2, s.pad, PAD_ZERO, srcs[0], [gfeat], layer.weight.shape, out=tape.slot(layer.weight))
+            dw = ops.wgrad(s.k, 2, s.pad, PAD_ZERO, srcs[0], [gfeat], layer.weight.shape, precision=s.precision,
+                           out=tape.slot(layer.weight))
         else:
-            dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape,
+            dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape, precision=s.precision,
                            out=tape.slot(layer.weight))
         tape.add_param(layer.weight, dw)
     if layer.bias.requires_grad:

@@ -5,6 +5,15 @@
 #include <cstdio>
 #include "../../include/animateportrait_amd.h"
 
+// Ablation switches (skip the DMA refill / the barriers / the epilogue of the matrix kernels, APAMD_ABLATE=<bits>)
+// exist only in the experiment build (`make ablate` -> libapamd_ablate.so, -DAPAMD_ABLATION); in the product library
+// the tests compile to nothing and the environment variable is not read.
+#ifdef APAMD_ABLATION
+#define AP_ABLATE(p, bits) ((p).ablate & (bits))
+#else
+#define AP_ABLATE(p, bits) 0
+#endif
+
 namespace apamd {
 char* last_error_buf();   // thread-local, 512 bytes
 int fail(int code, const char* fmt, ...);

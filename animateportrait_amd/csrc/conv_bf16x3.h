@@ -38,9 +38,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ROW_ = 1: a 1 x K kernel (K horizontal taps).  The 7x7 stems (3 input channels) run this way: their input is
 // expanded to "row channels" (ky, c) -- 21 of 32 channels of a split tensor -- so that the 49 x 3 products of a
 // pixel become 2 channel chunks x 7 taps (ap_split_prepass_rows).
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0>
+// PARTS_ = 2: split-bf16 arithmetic (head + tail of both operands staged, three MFMAs per product).
+// PARTS_ = 1: plain bf16 arithmetic (AP_PRECISION_BF16, the training configurations): only the head parts are
+// staged -- half the LDS image and half the LDS-DMA traffic -- and a product is ONE MFMA (fp32 accumulation).  The
+// global operand layouts (XS tensors, packed weights) are the same; the kernel just skips the tail planes.
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2>
 struct Bf3Cfg {
-    static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_;
+    static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_, PARTS = PARTS_;
+    static_assert(PARTS == 1 || PARTS == 2, "head only, or head + tail");
     static constexpr int TMAX = K > 0 ? (ROW ? K : K * K) : NTAP_;
     static_assert(TMAX >= 1, "K == 0 needs a tap count");
     static constexpr int EXT = K > 0 ? K - 1 : 1;
@@ -51,23 +56,25 @@ struct Bf3Cfg {
     static constexpr int IW = 31 * S + EXT + 1;
     static constexpr int PLANE = IH * IW;                          // pixels of the staged tile
     static constexpr int XP = (2 * PLANE + 63) / 64 * 64;          // slots per part: [kgroup][pixel], padded to whole DMA pieces
-    static constexpr int X_SLOTS = 2 * XP;                         // [part][kgroup][pixel]
-    static int w_slots(int ntaps) { return 2 * ntaps * 2 * CO_TILE; }   // [part][tap][kgroup][cout], multiple of 64
+    static constexpr int X_SLOTS = PARTS * XP;                     // [part][kgroup][pixel]
+    static int w_slots(int ntaps) { return PARTS * ntaps * 2 * CO_TILE; }   // LDS image [part][tap][kgroup][cout], multiple of 64
     static constexpr int NIT = XP / 256 + (XP % 256 ? 1 : 0);      // DMA pieces per thread and part
     // epilogue: 32 x 36-float transposition patches (NPATCH per wave, so that two accumulator tiles are in flight
     // between the LDS write and read phases) + statistics; they live in the free stage buffer of the tile's last chunk
-    static constexpr int W_BYTES_MAX = 2 * TMAX * 2 * CO_TILE * 16;
-    static constexpr int NPATCH = (NT % 2 == 0 && (8 * 32 * 36 + WPX * CO_TILE * 2) * 4 <= (2 * XP * 16 > W_BYTES_MAX ? 2 * XP * 16 : W_BYTES_MAX)) ? 2 : 1;
+    static constexpr int W_BYTES_MAX = PARTS * TMAX * 2 * CO_TILE * 16;
+    static constexpr int NPATCH = (NT % 2 == 0 && (8 * 32 * 36 + WPX * CO_TILE * 2) * 4 <= PARTS * XP * 16 + W_BYTES_MAX) ? 2 : 1;
     static constexpr int EPI_FLOATS = 4 * NPATCH * 32 * 36 + WPX * CO_TILE * 2;
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(CO_TILE % 16 == 0, "weight image must be whole wave-wide LDS-DMA pieces");
-    // the epilogue patches live in the (free) stage buffer of the tile's last chunk: its activation image, or --
-    // small pixel tiles -- its weight image
-    static constexpr bool EPI_IN_W = EPI_FLOATS * 4 > X_SLOTS * 16;
-    static_assert(!EPI_IN_W || EPI_FLOATS * 4 <= 2 * TMAX * 2 * CO_TILE * 16, "epilogue patches do not fit a stage buffer");
+    // the epilogue patches live in the (free) stage buffer of the tile's last chunk -- the LAST stage in memory, each
+    // stage being one contiguous [weight image | activation image] block -- and, where a head-only stage is smaller
+    // than the patches, in EPI_EXTRA bytes behind it
     static_assert(IH < 128 && IW < 256, "piece geometry is packed into 15 bits");
-    static int wfloats(int ntaps) { return w_slots(ntaps) * 4; }   // floats per (cout tile, chunk) weight block
-    static size_t lds_bytes(int ntaps) { return (size_t)2 * (X_SLOTS + w_slots(ntaps)) * 16; }   // two stages
+    static int wfloats(int ntaps) { return 2 * ntaps * 2 * CO_TILE * 4; }   // floats per packed (cout tile, chunk) weight block: always both parts
+    static size_t lds_bytes(int ntaps) {                                                          // two stages (+ patches)
+        const size_t stage = (size_t)(X_SLOTS + w_slots(ntaps)) * 16, epi = (size_t)EPI_FLOATS * 4;
+        return 2 * stage + (epi > stage ? (epi - stage + 15) / 16 * 16 : 0);
+    }
 };
 
 __device__ __forceinline__ void split_bf16(float v, __bf16& hi, __bf16& lo) {
@@ -94,8 +101,9 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 
 // seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels.
 // Launch with min(#tiles, #CUs) workgroups of 256 threads; needs nchunks >= 2.
+// (head-only arithmetic halves the LDS image: two workgroups per CU, i.e. two waves per SIMD and <= 256 registers each)
 template <class C>
-__global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
+__global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const ConvKParams p) {
     constexpr int S = C::S, K = C::K, TMAX = C::TMAX, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
     constexpr bool XPF = true;             // fragments of the next stage's tap 0 are fetched during this stage's last tap
@@ -111,9 +119,11 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     const int nreal = p.cin_pad >> 4;      // chunks that exist in the sources
 
     constexpr int T = TMAX;
-    constexpr int W_SLOTS = 2 * T * 2 * CO_TILE;
-    uint4* const wbuf = smem;                                  // [2][W_SLOTS]
-    uint4* const xbuf = smem + 2 * W_SLOTS;                    // [2][X_SLOTS]
+    constexpr int PARTS = C::PARTS;
+    constexpr int W_SLOTS = PARTS * T * 2 * CO_TILE;
+    constexpr int STAGE = W_SLOTS + C::X_SLOTS;                // stage b = smem + b * STAGE: [W_SLOTS weights | X_SLOTS activations]
+    uint4* const wbuf = smem;                                  // + b * STAGE
+    uint4* const xbuf = smem + W_SLOTS;                        // + b * STAGE
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
 
     // ---- this workgroup's tiles.  Workgroup b runs on XCD b % 8; each XCD owns a contiguous range of the tile
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         bool real;                 // false: the padding chunk of an odd count -- its weights are zero, the activation
                                    // image keeps whatever finite data the buffer held two stages ago
     };
-    constexpr int NWP = (W_SLOTS / 64 + 3) / 4, NPIECE = 2 * NIT + NWP;
+    constexpr int NWP = (W_SLOTS / 64 + 3) / 4, NPIECE = PARTS * NIT + NWP;
     unsigned woff[NWP];            // byte offset of this lane's slot in weight piece j
 #pragma unroll
     for (int j = 0; j < NWP; ++j) woff[j] = ((j * 4 + wave) * 64 + lane) * 16;
@@ -206,19 +216,19 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
         d.xh = xs + ((long long)(n * 2 + 0) * CG + cg0) * (HW + 1) * 16;
         d.xl = xs + ((long long)(n * 2 + 1) * CG + cg0) * (HW + 1) * 16;
-        d.xdst = lds0 + (2 * W_SLOTS + buf * C::X_SLOTS + wave * 64) * 16;
+        d.xdst = lds0 + (buf * STAGE + W_SLOTS + wave * 64) * 16;
         d.wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
-        d.wdst = lds0 + (buf * W_SLOTS + wave * 64) * 16;
+        d.wdst = lds0 + (buf * STAGE + wave * 64) * 16;
         return d;
     };
     auto dma_piece = [&](const DmaCtx& d, const int (&goff)[NIT], int j) __attribute__((always_inline)) {
-        if (j < 2 * NIT) {
+        if (j < PARTS * NIT) {
             const int part = j / NIT, k = j % NIT;
             // wave-uniform conditions: a real chunk, and the whole piece inside the part
             if (d.real && (k * 256 + 3 * 64 < XP || k * 256 + wave * 64 < XP))
                 glds16_sv(part ? d.xl : d.xh, (unsigned)goff[k], d.xdst + (part * XP + k * 256) * 16);
         } else {
-            const int jj = j - 2 * NIT;
+            const int jj = j - PARTS * NIT;
             if (jj * 4 + 3 < W_SLOTS / 64 || jj * 4 + wave < W_SLOTS / 64) glds16_sv(d.wsrc, woff[jj], d.wdst + jj * 4096);
         }
     };
@@ -244,64 +254,64 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
     constexpr int WR = WIN ? NT + K - 1 : 1;
     bf16x8 wh[2][WR], wl[2][WR];                                   // [kx parity][window row]
     auto fetch_a = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
-        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
+        const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
-            al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+            if constexpr (PARTS == 2) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
         }
     };
     auto fetch_brow = [&](int stage_buf, int kx, int j, int wb) __attribute__((always_inline)) {
-        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot + j * IW + kx;
+        const uint4* Xc = xbuf + stage_buf * STAGE + b_slot + j * IW + kx;
         wh[wb][j] = *reinterpret_cast<const bf16x8*>(Xc);
-        wl[wb][j] = *reinterpret_cast<const bf16x8*>(Xc + XP);
+        if constexpr (PARTS == 2) wl[wb][j] = *reinterpret_cast<const bf16x8*>(Xc + XP);
     };
     auto fetch = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
-        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
-        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
+        const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
+        const uint4* Xc = xbuf + stage_buf * STAGE + b_slot;
         int toff;
         if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
             ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
-            al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+            if constexpr (PARTS == 2) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
         }
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
-            bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
+            if constexpr (PARTS == 2) bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
         }
     };
 
     // fragment r of tap t (r < 2 MT: weights head / tail alternating; then activations)
     auto fetch_one = [&](int stage_buf, int t, int buf, int r) __attribute__((always_inline)) {
-        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
-        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
+        const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
+        const uint4* Xc = xbuf + stage_buf * STAGE + b_slot;
         int toff;
         if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
-        if (r < 2 * MT) {
-            const int m = r >> 1;
-            if (r & 1) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
+        if (r < PARTS * MT) {
+            const int m = r / PARTS;
+            if (PARTS == 2 && (r & 1)) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + t) * 2) * CO_TILE + m * 32);
             else ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + t) * 2) * CO_TILE + m * 32);
         } else {
-            const int q = (r - 2 * MT) >> 1;
-            if (r & 1) bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
+            const int q = (r - PARTS * MT) / PARTS;
+            if (PARTS == 2 && (r & 1)) bl[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * S * IW);
             else bh[buf][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * S * IW);
         }
     };
     // the same for the windowed form: fragment r of tap (0, 0) -- weights into buffer `buf`, window rows into `wb`
     auto fetch_one_win = [&](int stage_buf, int buf, int wb, int r) __attribute__((always_inline)) {
-        const uint4* Wc = wbuf + stage_buf * W_SLOTS + a_slot;
-        const uint4* Xc = xbuf + stage_buf * C::X_SLOTS + b_slot;
-        if (r < 2 * MT) {
-            const int m = r >> 1;
-            if (r & 1) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + 0) * 2) * CO_TILE + m * 32);
+        const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
+        const uint4* Xc = xbuf + stage_buf * STAGE + b_slot;
+        if (r < PARTS * MT) {
+            const int m = r / PARTS;
+            if (PARTS == 2 && (r & 1)) al[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((1 * T + 0) * 2) * CO_TILE + m * 32);
             else ah[buf][m] = *reinterpret_cast<const bf16x8*>(Wc + ((0 * T + 0) * 2) * CO_TILE + m * 32);
         } else {
-            const int q = (r - 2 * MT) >> 1;
-            if (r & 1) wl[wb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + q * IW);
+            const int q = (r - PARTS * MT) / PARTS;
+            if (PARTS == 2 && (r & 1)) wl[wb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + q * IW);
             else wh[wb][q] = *reinterpret_cast<const bf16x8*>(Xc + q * IW);
         }
     };
@@ -348,14 +358,14 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                 auto mfma_one = [&](int i) __attribute__((always_inline)) {
                     // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
                     // never wait on each other's result (small terms first)
-                    const int g = i / (MT * NT), m = (i % (MT * NT)) / NT, q = i % NT;
+                    const int g = PARTS == 2 ? i / (MT * NT) : 2, m = (i % (MT * NT)) / NT, q = i % NT;
                     const bf16x8 xh = WIN ? wh[wb][WIN ? ky + q : 0] : bh[cb][q];
                     const bf16x8 xl = WIN ? wl[wb][WIN ? ky + q : 0] : bl[cb][q];
                     if (g == 0) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cb][m], xh, acc[m][q], 0, 0, 0);
                     else if (g == 1) acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], xl, acc[m][q], 0, 0, 0);
                     else acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cb][m], xh, acc[m][q], 0, 0, 0);
                 };
-                constexpr int NM = 3 * MT * NT, NRD = 2 * MT + 2 * NT;
+                constexpr int NM = (PARTS == 2 ? 3 : 1) * MT * NT, NRD = PARTS * (MT + NT);
                 if (!last) {
                     int nrd = NRD;                                  // LDS reads issued for the next tap
                     if constexpr (WIN) {
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                         fetch_a(P, ky2 * K + kx2, cb ^ 1);
                         if (kx2 == kx) {
                             fetch_brow(P, kx, ky2 + NT - 1, wb);
-                            nrd = 2 * MT + 2;
+                            nrd = PARTS * (MT + 1);
                         } else {
 #pragma unroll
                             for (int q = 0; q < NT; ++q) fetch_brow(P, kx2, q, wb ^ 1);
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                     for (int i = 0; i < NM; ++i) mfma_one(i);
                     // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
                     // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
-                    constexpr int PER = (NM + NRD - 1) / NRD, NRD1 = 2 * MT + 2, PER1 = (NM + NRD1 - 1) / NRD1;
+                    constexpr int PER = (NM + NRD - 1) / NRD, NRD1 = PARTS * (MT + 1), PER1 = (NM + NRD1 - 1) / NRD1;
                     if (nrd == NRD) {
 #pragma unroll
                         for (int i = 0; i < NRD; ++i) {
@@ -396,13 +406,13 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                     // the next stage's tap 0 are issued one per MFMA slot, so the matrix pipe keeps running.
                     const bool do_fetch = c + 1 < nchunks;
                     const bool tail = c + 2 >= nchunks;
-                    const bool do_dma = do_fetch && !(p.ablate & 1) && (!tail || has_next);
+                    const bool do_dma = do_fetch && !AP_ABLATE(p, 1) && (!tail || has_next);
                     int ig[NIT];
 #pragma unroll
                     for (int k = 0; k < NIT; ++k) ig[k] = tail ? ngoff[k] : cgoff[k];
                     const DmaCtx d = dma_setup(tail ? nxt.n : cur.n, tail ? nxt.cot : cur.cot, tail ? 0 : c + 2, P);
                     dma_wait_all();
-                    if (!(p.ablate & 2)) __syncthreads();
+                    if (!AP_ABLATE(p, 2)) __syncthreads();
                     constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
                     constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
                     constexpr int R0 = NM - (NRD + RPS - 1) / RPS;              // first slot that carries reads
@@ -445,8 +455,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
             // pixels of one cout row: 16-byte global stores (the dword-per-lane form is store-issue bound) and a
             // 3-step row reduction for the InstanceNorm statistics instead of a 5-step one per accumulator register.
             constexpr int TS = 36;                                            // patch row stride (floats, 16-B aligned)
-            float* const epi = C::EPI_IN_W ? reinterpret_cast<float*>(wbuf + pl * W_SLOTS)
-                                           : reinterpret_cast<float*>(xbuf + pl * C::X_SLOTS);
+            float* const epi = reinterpret_cast<float*>(smem + pl * STAGE);
             constexpr int NP = C::NPATCH;
             float* const patch0 = epi + wave * (NP * 32 * TS);
             float* const sred = epi + 4 * NP * 32 * TS;                        // [WPX][CO_TILE][2]
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
                 }
             }
         };
-        if (p.ablate & 8) {
+        if (AP_ABLATE(p, 8)) {
             if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
         } else if (p.act == 0) {
             epilogue(std::integral_constant<int, 0>{});
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(256, 1) void conv_bf16x3(const ConvKParams p) {
         }
         if (!has_next) break;
         __syncthreads();                                           // patches and statistics consumed: refill that stage
-        if (!(p.ablate & 1)) issue(nxt, ngoff, 1, pl);
+        if (!AP_ABLATE(p, 1)) issue(nxt, ngoff, 1, pl);
         cur = nxt;
 #pragma unroll
         for (int k = 0; k < NIT; ++k) cgoff[k] = ngoff[k];

@@ -51,33 +51,39 @@ static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
 // split-bf16 kernels (conv_bf16x3.h)
 struct Bf3Kernel {
     int S, K, CO_TILE, TH, TMAX, ROW;
-    const void* fn;
+    const void* fn;              // split-bf16 arithmetic (AP_PRECISION_BF16X3): head + tail staged, 3 MFMAs per product
     int (*wfloats)(int);
     size_t (*lds_bytes)(int);
     const char* name;
+    const void* fn1;             // plain bf16 arithmetic (AP_PRECISION_BF16): the same tile with head parts only
+    size_t (*lds_bytes1)(int);
+    const void* kernel(int precision) const { return precision == AP_PRECISION_BF16 ? fn1 : fn; }
+    size_t lds(int precision, int ntaps) const { return precision == AP_PRECISION_BF16 ? lds_bytes1(ntaps) : lds_bytes(ntaps); }
 };
-template <class C>
-static Bf3Kernel bk(const char* name) {
+template <int S, int K, int WCO, int MT, int WPX, int NT, int NTAP = 0, int ROW = 0>
+static Bf3Kernel bk2(const char* name) {
+    using C = Bf3Cfg<S, K, WCO, MT, WPX, NT, NTAP, ROW, 2>;
+    using C1 = Bf3Cfg<S, K, WCO, MT, WPX, NT, NTAP, ROW, 1>;
     return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, C::ROW, reinterpret_cast<const void*>(&conv_bf16x3<C>),
-                     &C::wfloats, &C::lds_bytes, name};
+                     &C::wfloats, &C::lds_bytes, name, reinterpret_cast<const void*>(&conv_bf16x3<C1>), &C1::lds_bytes};
 }
 static const std::vector<Bf3Kernel>& bf3_registry() {
     static std::vector<Bf3Kernel> v = {
-        bk<Bf3Cfg<1, 3, 1, 2, 4, 1>>("Bf3Cfg<1, 3, 1, 2, 4, 1>"),      // 3x3 s1, small batches: 64 couts x 4 rows
-        bk<Bf3Cfg<1, 3, 1, 2, 4, 4>>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
-        bk<Bf3Cfg<2, 3, 2, 1, 2, 2>>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
-        bk<Bf3Cfg<1, 4, 1, 1, 4, 4>>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
-        bk<Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>>("Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>"),   // 1x7 over row channels (7x7 stems)
+        bk2<1, 3, 1, 2, 4, 1>("Bf3Cfg<1, 3, 1, 2, 4, 1>"),      // 3x3 s1, small batches: 64 couts x 4 rows
+        bk2<1, 3, 1, 2, 4, 4>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
+        bk2<2, 3, 2, 1, 2, 2>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
+        bk2<1, 4, 1, 1, 4, 4>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
+        bk2<1, 7, 1, 2, 4, 4, 0, 1>("Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>"),   // 1x7 over row channels (7x7 stems)
         // ... and its half-size tile (32 couts x 8 rows, 70 KB of LDS): two workgroups per CU, so that the output
         // burst of one tile's epilogue runs under the other workgroup's MFMAs (the stems are write-bound: 2 chunks of K)
-        bk<Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>>("Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>"),
+        bk2<1, 7, 1, 1, 4, 2, 0, 1>("Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>"),
         // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
-        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 1>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
-        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 2>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
-        bk<Bf3Cfg<1, 0, 1, 2, 4, 4, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 4, 4>"),
+        bk2<1, 0, 1, 2, 4, 4, 1>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
+        bk2<1, 0, 1, 2, 4, 4, 2>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
+        bk2<1, 0, 1, 2, 4, 4, 4>("Bf3Cfg<1, 0, 1, 2, 4, 4, 4>"),
         // the 4-tap form with a half-height tile (64 couts x 8 rows, 74 KB of LDS): two workgroups per CU for the
         // launches whose tiles are short in K and heavy in output (fused phases, space-to-depth layers)
-        bk<Bf3Cfg<1, 0, 1, 2, 4, 2, 4>>("Bf3Cfg<1, 0, 1, 2, 4, 2, 4>"),
+        bk2<1, 0, 1, 2, 4, 2, 4>("Bf3Cfg<1, 0, 1, 2, 4, 2, 4>"),
     };
     return v;
 }
@@ -133,7 +139,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     const bool rowk = d->KH == 1 && d->KW == 7;
     if (rowk) {
         if (d->transposed || d->stride != 1 || d->pad != 3 || d->nsrc != 1 || d->src[0].C != 32 ||
-            d->precision != AP_PRECISION_BF16X3 || d->w_layout != AP_W_OIHW || d->w_flip)
+            d->precision == AP_PRECISION_FP32 || d->w_layout != AP_W_OIHW || d->w_flip)
             return fail(AP_ERR_UNSUPPORTED, "1x7 kernels exist only as the row form of a 7x7 stem (one 32-channel "
                                             "split source, stride 1, pad 3, split-bf16 precision)");
         if (d->pad_mode == AP_PAD_REFLECT && d->pad >= d->W) return fail(AP_ERR_INVALID, "reflection pad %d >= width", d->pad);
@@ -153,7 +159,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         KT = K;
         if (K == 2) {
             // the space-to-depth form of a 4x4 stride-2 layer (ap_split_prepass_s2d): 4 run-time taps, split-bf16 only
-            if (d->stride != 1 || d->pad != 0 || d->precision != AP_PRECISION_BF16X3 || d->w_layout != AP_W_OIHW || d->w_flip)
+            if (d->stride != 1 || d->pad != 0 || d->precision == AP_PRECISION_FP32 || d->w_layout != AP_W_OIHW || d->w_flip)
                 return fail(AP_ERR_UNSUPPORTED, "2x2 kernels exist only as the space-to-depth form of a 4x4 stride-2 layer "
                                                 "(stride 1, pad 0, split-bf16 precision)");
             KT = 0;
@@ -226,7 +232,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     // split-bf16 matrix path (conv_bf16x3.h): wide 3x3 / transposed layers when the caller allows ~1e-4 relative error
     // (>= 48 outputs fill most of a 64-cout tile; with >= 128 inputs even a 16-output layer -- the data gradient of a
     // ResnetBlock2 convolution w.r.t. its 16-channel landmark segments -- is 3x faster here than on the fp32 pipe)
-    if (!rowk && d->precision == AP_PRECISION_BF16X3 && (d->Cout >= 48 || (d->Cout >= 16 && pl.Cin >= 128)) && pl.Cin >= 32 &&
+    if (!rowk && d->precision != AP_PRECISION_FP32 && (d->Cout >= 48 || (d->Cout >= 16 && pl.Cin >= 128)) && pl.Cin >= 32 &&
         !env_int("APAMD_NO_BF16X3", 0)) {
         bool seg_ok = true;
         for (int s = 0; s < d->nsrc; ++s) seg_ok = seg_ok && d->src[s].C % 16 == 0;
@@ -647,7 +653,7 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen) {
         return AP_OK;
     }
     if (pl.bf3) {
-        snprintf(buf, buflen, "%s", pl.bk->name);
+        snprintf(buf, buflen, "%s%s", pl.bk->name, d->precision == AP_PRECISION_BF16 ? " bf16" : "");
         return AP_OK;
     }
     snprintf(buf, buflen, "ConvCfg<%d, %d, %d, %d, %d, %d, %d>", pl.k->CI, pl.k->S, pl.k->K, pl.k->WCO, pl.k->MT,
@@ -803,7 +809,8 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         for (const auto& L : pl.launches) {
             const Bf3Kernel* kern = bf3_for_taps(pl.bk, (int)L.taps.size());
             if (!kern) return fail(AP_ERR_UNSUPPORTED, "no split-bf16 kernel for a phase with %d taps", (int)L.taps.size());
-            rc = ensure_lds_attr(kern->fn);
+            const void* kfn = kern->kernel(d->precision);
+            rc = ensure_lds_attr(kfn);
             if (rc) return rc;
             ConvKParams p;
             memset(&p, 0, sizeof(p));
@@ -825,7 +832,11 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             p.tiles_x = L.tiles_x; p.tiles_y = L.tiles_y; p.co_tiles = pl.co_tiles;
             p.cin_pad = pl.cin_pad;
             p.wfloats = pl.bk->wfloats(p.ntaps);
-            p.ablate = env_int("APAMD_ABLATE", 0);
+#ifdef APAMD_ABLATION
+    #ifdef APAMD_ABLATION
+        p.ablate = env_int("APAMD_ABLATE", 0);
+#endif
+#endif
             if (view) {
                 // output window: a sub-grid of the output, stored with the caller's strides (ap_out_view)
                 p.OH = view->OH; p.OW = view->OW;
@@ -853,7 +864,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 for (int t = 0; t < p.ntaps; ++t)
                     p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
             }
-            const size_t lds = pl.bk->lds_bytes(p.ntaps);
+            const size_t lds = kern->lds(d->precision, p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
             if (p.nchunks < 2) return fail(AP_ERR_UNSUPPORTED, "bf16x3 pipeline needs >= 32 input channels");
             if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes
@@ -861,10 +872,16 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
             long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * p.co_tiles;
             // (two per CU when two stage sets fit its 160 KB of LDS)
-            const int cus = env_int("APAMD_BF3_BLOCKS", num_cus() * (2 * lds <= 160 * 1024 ? 2 : 1));
+            int cus = num_cus() * (2 * lds <= 160 * 1024 ? 2 : 1);
+            if (const int forced = env_int("APAMD_BF3_BLOCKS", 0)) {      // tuning / test knob: never silent
+                static bool told = false;
+                if (!told) fprintf(stderr, "libapamd: APAMD_BF3_BLOCKS=%d overrides the persistent workgroup count\n", forced);
+                told = true;
+                cus = forced;
+            }
             if (nblk > cus) nblk = cus;
             void* args[] = {&p};
-            hipError_t e = hipLaunchKernel(kern->fn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
+            hipError_t e = hipLaunchKernel(kfn, dim3((unsigned)nblk), dim3(256), args, lds, (hipStream_t)stream);
             if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "conv_bf16x3 launch: %s", hipGetErrorString(e));
             if (pl.fused_phases) break;
         }
@@ -924,7 +941,9 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         p.tiles_x = L.tiles_x; p.tiles_y = L.tiles_y; p.co_tiles = pl.co_tiles;
         p.cin_pad = pl.cin_pad;
         p.wfloats = pl.k->wfloats(p.ntaps);
+#ifdef APAMD_ABLATION
         p.ablate = env_int("APAMD_ABLATE", 0);
+#endif
         p.tap_bits = 0;
         if (pl.k->K == 0) {
             if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);

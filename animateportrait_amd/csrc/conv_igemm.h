@@ -22,6 +22,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "common.h"
 
 namespace apamd {
 
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(256, C::MINW) void conv_igemm_f32(const ConvKParams
         // Refill of the other pipeline buffer.  On the dense path both halves are placed INSIDE the MFMA
         // stream (loads right after the first step, normalise + ds_write three quarters through), so
         // their VALU/VMEM/DS issue slots hide under the 64-cycle MFMAs instead of serialising with them.
-        const bool refill = more && !(p.ablate & 1);
+        const bool refill = more && !AP_ABLATE(p, 1);
         if (C::K == 0 && refill) {
             issue_x(chunk + 1);
             issue_w(chunk + 1, wbuf + (cur ^ 1) * wfloats);
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, C::MINW) void conv_igemm_f32(const ConvKParams
         const float* Wc = wbuf + cur * wfloats + a_lane;
         const float* Xc = xbuf + cur * XE + b_lane;
 
-        if (p.ablate & 4) {
+        if (AP_ABLATE(p, 4)) {
             float a0 = Wc[0], b0 = Xc[0];
             for (int s = 0; s < p.ntaps * (CI / 2); ++s) {
 #pragma unroll
@@ -347,10 +348,10 @@ __global__ __launch_bounds__(256, C::MINW) void conv_igemm_f32(const ConvKParams
             }
         }
         if (C::K == 0 && refill) commit_x(chunk + 1, xbuf + (cur ^ 1) * XE);
-        if (!(p.ablate & 2)) __syncthreads();
+        if (!AP_ABLATE(p, 2)) __syncthreads();
     }
 
-    if (p.ablate & 8) {
+    if (AP_ABLATE(p, 8)) {
         if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;   // keep the accumulators live
         return;
     }

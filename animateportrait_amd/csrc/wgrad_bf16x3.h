@@ -64,8 +64,12 @@ __device__ __forceinline__ bf16x8 funnel8(const u32x4 lo, const u32x4 hi) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-template <class C>
+// PROD = 3: split-bf16 arithmetic (tail x head, head x tail, head x head per tap).  PROD = 1: plain bf16 arithmetic
+// (AP_PRECISION_BF16): the head x head product only -- the staging is unchanged (the tail planes still travel; their
+// fragment reads are dead code), the matrix work is a third.
+template <class C, int PROD = 3>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
+    static_assert(PROD == 1 || PROD == 3, "one or three products");
     constexpr int K = C::K, T = C::T, ROWS = C::ROWS, NXG = C::NXG;
     constexpr int G_SLOTS = C::G_SLOTS, A_SLOTS = C::A_SLOTS, STAGE = G_SLOTS + A_SLOTS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
     };
     auto mfma_one = [&](int gidx, int i) __attribute__((always_inline)) {
         const int ks = gidx / K, ky = gidx % K, rb = gidx % RB, pb = gidx & 1;
-        const int pr = i / K, kx = i % K;                               // product-major: round the K accumulators
+        const int pr = PROD == 1 ? 2 : i / K, kx = i % K;               // product-major: round the K accumulators
         bf16x8 bh, bl;
         if (kx == 0) { bh = funnel8<0>(rh[rb][0], rh[rb][1]); bl = funnel8<0>(rl[rb][0], rl[rb][1]); }
         else if (kx == 2) { bh = funnel8<2>(rh[rb][0], rh[rb][1]); bl = funnel8<2>(rl[rb][0], rl[rb][1]); }
@@ -197,8 +201,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
 
     auto stage = [&](auto ptag, int st) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;                       // stage buffer
-        constexpr int NM = 3 * K, PPS = (NPW + 2 * NM - 1) / (2 * NM);  // DMA pieces per MFMA slot (last two groups)
-        const bool more = st + 1 < st1, dma = st + 2 < st1 && !(p.ablate & 1);
+        constexpr int NM = PROD * K, PPS = (NPW + 2 * NM - 1) / (2 * NM);  // DMA pieces per MFMA slot (last two groups)
+        const bool more = st + 1 < st1, dma = st + 2 < st1 && !AP_ABLATE(p, 1);
         if (st == st0) {
             fetch_group(P, 0);
             fetch_group(P, 1);
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
                 // the reads of this stage's last group were issued one group ago: once everybody is past the
                 // barrier the buffer can be refilled (stage st+2), and stage st+1 has landed for the reads below
                 if (dma) locate();
-                if (!(p.ablate & 2)) {
+                if (!AP_ABLATE(p, 2)) {
                     dma_wait_all();
                     __syncthreads();
                 }
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
     // partial[split][m][q], q = ci*T + tap.  C/D layout: column j = lane & 31 (ci), row i = (r&3) + 8*(r>>2) + 4*half (m)
     float* out = p.partial + (long long)split * p.M * p.Q;
     const int ci = ct * 64 + wq * 32 + l32;
-    if (p.ablate & 16) {
+    if (AP_ABLATE(p, 16)) {
         if (acc[0][0] == 123.456f) out[0] = 1.f;
         return;
     }

@@ -57,13 +57,16 @@ struct WgradPlan {
 // split-bf16 instantiations by kernel size (stride 1)
 struct WgradBf3Kernel {
     int K;
-    const void* fn;
+    const void* fn;        // three products per tap (AP_PRECISION_BF16X3)
     size_t lds_bytes;
+    const void* fn1;       // head x head only (AP_PRECISION_BF16)
 };
 static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
     static std::vector<WgradBf3Kernel> v = {
-        {3, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>>), WgradBf3Cfg<3>::lds_bytes()},
-        {4, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>>), WgradBf3Cfg<4>::lds_bytes()},
+        {3, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>, 3>), WgradBf3Cfg<3>::lds_bytes(),
+         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>, 1>)},
+        {4, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 3>), WgradBf3Cfg<4>::lds_bytes(),
+         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 1>)},
     };
     return v;
 }
@@ -136,7 +139,7 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         }
     }
     const char* nob = getenv("APAMD_NO_BF16X3");
-    if (d->precision == AP_PRECISION_BF16X3 && S == 1 && (K == 3 || K == 4) && d->M >= 48 && pl.Cin >= 32 &&
+    if (d->precision != AP_PRECISION_FP32 && S == 1 && (K == 3 || K == 4) && d->M >= 48 && pl.Cin >= 32 &&
         !(nob && atoi(nob))) {
         // wide stride-1 layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
         pl.bf3 = true;
@@ -146,6 +149,11 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.m_tiles = (d->M + 63) / 64;
         pl.c_tiles = (pl.Cin + 63) / 64;
         const char* e = getenv("APAMD_WGRAD_BLOCKS");
+        if (e) {                                                  // tuning / test knob: never silent
+            static bool told = false;
+            if (!told) fprintf(stderr, "libapamd: APAMD_WGRAD_BLOCKS=%s overrides the workgroup count\n", e);
+            told = true;
+        }
         const int target = e ? atoi(e) : num_cus_w();            // one workgroup per CU (its LDS stages fill a CU)
         int P = target / (pl.m_tiles * pl.c_tiles);
         if (P > pl.nstages / 2) P = pl.nstages / 2;
@@ -361,7 +369,8 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         for (const auto& k : wgrad_bf3_registry())
             if (k.K == d->K) bk = &k;
         if (!bk) return fail(AP_ERR_UNSUPPORTED, "wgrad: no split-bf16 kernel for k=%d", d->K);
-        rc = ensure_wattr(bk->fn);
+        const void* wfn = d->precision == AP_PRECISION_BF16 ? bk->fn1 : bk->fn;
+        rc = ensure_wattr(wfn);
         if (rc) return rc;
         uint4* at = reinterpret_cast<uint4*>(workspace);
         uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
@@ -382,12 +391,14 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
         p.partial = partial;
         {
+#ifdef APAMD_ABLATION
             const char* ab = getenv("APAMD_ABLATE");
             p.ablate = ab ? atoi(ab) : 0;
+#endif
         }
         void* args[] = {&p};
         const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
-        hipError_t e = hipLaunchKernel(bk->fn, dim3(nblk), dim3(256), args, bk->lds_bytes, stream);
+        hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args, bk->lds_bytes, stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
         const long long n = (long long)d->M * pl.Q;
         int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
@@ -417,8 +428,10 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
     p.m_tiles = pl.m_tiles; p.q_tiles = pl.q_tiles;
     p.partial = partial;
     {
+#ifdef APAMD_ABLATION
         const char* ab = getenv("APAMD_ABLATE");
         p.ablate = ab ? atoi(ab) : 0;
+#endif
     }
     void* args[] = {&p};
     const unsigned nblk = (unsigned)(pl.m_tiles * pl.q_tiles * pl.P);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, C::NA <= 20 ? 2 : 1) void wgrad_igemm_f32(cons
     __syncthreads();
     for (int st = st0; st < st1; ++st) {
         const int cur = (st - st0) & 1;
-        const bool more = st + 1 < st1 && !(p.ablate & 1);
+        const bool more = st + 1 < st1 && !AP_ABLATE(p, 1);
         if (more) issue(st + 1);
         const float* G = gbuf + cur * C::M_TILE * GS + aoff;
         const float* A = abuf + cur * NCI * PLANE;

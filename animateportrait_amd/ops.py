@@ -25,8 +25,11 @@ WEIGHTS_EPOCH = 0
 #   'bf16x3' operands split into bf16 head + tail, three bf16 MFMAs per tile, fp32 accumulation: fp32-class
 #            results (generator L-inf ~1e-4 vs the fp32 reference, inside the 1e-3 budget) at ~5x the MFMA rate.
 # Picked up by every ConvSpec created afterwards (APAMD_PRECISION=fp32 forces exact arithmetic).
-PRECISION_FP32, PRECISION_BF16X3 = 0, 1
-DEFAULT_PRECISION = PRECISION_FP32 if os.environ.get('APAMD_PRECISION', 'bf16x3') == 'fp32' else PRECISION_BF16X3
+#   'bf16'   plain bf16 operands (the head parts only), ONE MFMA per tile, fp32 accumulation, fp32 master weights: the
+#            training configurations (BASELINE configs[2-3]); ~3x less matrix work than bf16x3, bf16-autocast accuracy.
+PRECISION_FP32, PRECISION_BF16X3, PRECISION_BF16 = 0, 1, 2
+PRECISION_BY_NAME = {'fp32': PRECISION_FP32, 'bf16x3': PRECISION_BF16X3, 'bf16': PRECISION_BF16}
+DEFAULT_PRECISION = PRECISION_BY_NAME.get(os.environ.get('APAMD_PRECISION', 'bf16x3'), PRECISION_BF16X3)
 
 
 def _stream():
@@ -197,7 +200,7 @@ ROW_CHANNELS = 32   # channels of the row expansion (k * C <= 32)
 def stem_rows_eligible(spec):
     """7x7 'same' stems with <= 4 input channels (networks.py:1218, 1231, 1244) run as a 1x7 split-bf16 convolution
     over the row expansion of their input."""
-    return (spec.precision == PRECISION_BF16X3 and spec.k == 7 and spec.stride == 1 and spec.pad == 3 and
+    return (spec.precision != PRECISION_FP32 and spec.k == 7 and spec.stride == 1 and spec.pad == 3 and
             not spec.transposed and len(spec.cin_segments) == 1 and spec.cin_segments[0] <= 4 and spec.cout >= 32 and
             spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_STEM_ROWS'))
 
@@ -205,7 +208,7 @@ def stem_rows_eligible(spec):
 def stem_rows_spec(spec):
     s = ConvSpec([ROW_CHANNELS], spec.cout, spec.k, 1, spec.pad, spec.pad_mode)
     s.kh = 1
-    s.precision = PRECISION_BF16X3
+    s.precision = spec.precision
     s.alg_macs = spec.cin_segments[0] * spec.k * spec.k     # algorithmic MACs per output value (profiler accounting)
     return s
 
@@ -246,7 +249,7 @@ def presplit_rows(f, k, pad, pad_mode):
 def s2d_eligible(spec, h, w):
     """4x4 stride-2 pad-1 layers with >= 32 input channels (PatchGAN body, networks.py:2620-2636) run as a 2x2
     stride-1 split-bf16 convolution over the space-to-depth copy of their input."""
-    return (spec.precision == PRECISION_BF16X3 and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and
+    return (spec.precision != PRECISION_FP32 and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and
             spec.pad_mode == PAD_ZERO and not spec.transposed and len(spec.cin_segments) == 1 and
             spec.cin_segments[0] >= 32 and spec.cin_segments[0] % 8 == 0 and spec.cout >= 48 and h % 2 == 0 and
             w % 2 == 0 and spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_S2D'))
@@ -254,7 +257,7 @@ def s2d_eligible(spec, h, w):
 
 def s2d_spec(spec):
     s = ConvSpec([4 * spec.cin_segments[0]], spec.cout, 2, 1, 0, PAD_ZERO)
-    s.precision = PRECISION_BF16X3
+    s.precision = spec.precision
     return s
 
 
@@ -327,7 +330,7 @@ def wants_split(c):
     """Whether a materialised residual-trunk feature of ``c`` channels is going to be staged by a split-bf16
     convolution: its consumers are c -> c 3x3 layers, so this is the C library's eligibility rule (>= 48 outputs,
     >= 32 inputs in 16-channel segments).  A wrong guess only costs the unused copy."""
-    return DEFAULT_PRECISION == PRECISION_BF16X3 and c >= 48 and c % 16 == 0
+    return DEFAULT_PRECISION != PRECISION_FP32 and c >= 48 and c % 16 == 0
 
 
 def takes_split(spec, n, h, w):
@@ -408,7 +411,7 @@ def dgrad_strip_eligible(spec, g):
     """spec: data-gradient operator of a reflection-padded 3x3 stride-1 layer (full correlation, pad 2), g: the plain
     gradient Feat.  True when the padded-coordinate output is 32 m + 2 columns wide (the 64 x 64 maps of the ResNet
     blocks: 66) and the operator runs on the split-bf16 path: see conv2d_dgrad_strip."""
-    if (spec.precision != PRECISION_BF16X3 or spec.k != 3 or spec.stride != 1 or spec.pad != 2 or spec.transposed or
+    if (spec.precision == PRECISION_FP32 or spec.k != 3 or spec.stride != 1 or spec.pad != 2 or spec.transposed or
             len(spec.cin_segments) != 1 or g.virtual or os.environ.get('APAMD_NO_DGRAD_STRIP')):
         return False
     n, c, h, w = g.data.shape

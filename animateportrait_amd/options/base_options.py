@@ -45,6 +45,10 @@ class BaseOptions:
         p.add_argument('--load_iter', type=int, default=0)
         p.add_argument('--verbose', action='store_true')
         p.add_argument('--suffix', default='', type=str)
+        p.add_argument('--precision', type=str, default=None, choices=['fp32', 'bf16x3', 'bf16'],
+                       help='(not in the reference) arithmetic of the wide convolutions: fp32 = exact fp32 MFMA; '
+                            'bf16x3 = fp32-class split-bf16 (default, or $APAMD_PRECISION); bf16 = plain bf16 products with '
+                            'fp32 accumulation and fp32 master weights (training configurations)')
         self.initialized = True
         return p
 
@@ -65,6 +69,9 @@ class BaseOptions:
         opt.isTrain = self.isTrain
         if opt.suffix:
             opt.name = opt.name + ('_' + opt.suffix.format(**vars(opt)))
+        if opt.precision is not None:            # picked up by every layer created afterwards
+            from .. import ops
+            ops.DEFAULT_PRECISION = ops.PRECISION_BY_NAME[opt.precision]
         opt.gpu_ids = [int(i) for i in str(opt.gpu_ids).split(',') if int(i) >= 0]      # :127-137
         opt.gpu_ids_p = [int(i) for i in str(opt.gpu_ids_p).split(',') if int(i) >= 0]  # :138-143
         self.opt = opt

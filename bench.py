@@ -106,8 +106,10 @@ def cpu_baseline(warmup=3, iters=5):
                       % (iters, time.time() - t_all, cores)}
 
 
-def train_step_ms(dev, rank, world, dist, steps):
-    """Time `steps` full train steps (after 1 warm-up) of the drawing config (readme.md:65 flags), B=16/GPU."""
+def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
+    """Time `steps` full train steps (after 1 warm-up) of the drawing config (readme.md:65 flags), B=16/GPU.
+    precision: 'bf16x3' (fp32-class arithmetic, fp32 tensors) or 'bf16' (plain bf16 products, fp32 accumulation and
+    fp32 master weights -- BASELINE configs[2-3])."""
     from animateportrait_amd.options.base_options import TrainOptions
     from animateportrait_amd.models import create_model
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
@@ -115,7 +117,7 @@ def train_step_ms(dev, rank, world, dist, steps):
             '--output_nc', '1', '--netg_resb_div', '3', '--netg_resb_disp', '3', '--lr', '0.00005', '--lambda_geom', '50',
             '--lambda_geom_lipline', '50', '--more_weight_for_lip', '2', '--lambda_face', '3.0',
             '--lambda_warp_inter', '10', '--blendbg', '1', '--select_target12_thre', '0.0', '--niter', '70',
-            '--niter_decay', '0', '--batch_size', str(BATCH), '--gpu_ids', str(dev.index)]
+            '--niter_decay', '0', '--batch_size', str(BATCH), '--gpu_ids', str(dev.index), '--precision', precision]
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):      # the model prints its notices; keep stdout = one JSON line
@@ -150,7 +152,10 @@ def train_step_ms(dev, rank, world, dist, steps):
             'world_size': world, 'global_batch': world * BATCH,
             'gradient_exchange': 'none (1 rank)' if world == 1 else
                                  '2 RCCL all-reduces / step (G 63.7 MB in flight under the D backward passes, D 55.3 MB)',
-            'batch_per_gpu': BATCH, 'dtype': 'f32', 'loss_G': round(losses.get('G', float('nan')), 4),
+            'batch_per_gpu': BATCH,
+            'dtype': 'f32 (split-bf16 products, fp32 accumulate)' if precision == 'bf16x3' else
+                     'bf16 (bf16 products, fp32 accumulate, fp32 master weights)',
+            'loss_G': round(losses.get('G', float('nan')), 4),
             'gflop_per_sample_algorithmic': 1234.0,
             'note': 'geomgm_ifw_fore drawing config; frozen aux nets (MODNet/MobileFaceNet/Sphere20a/FlowUnet) absent '
                     'from the reference tree: their outputs are synthetic inputs, geometry/identity terms skipped'}
@@ -312,11 +317,17 @@ def main():
 
     # ---- second half of the BASELINE metric: "train step ms" -- the geomgm_ifw_fore drawing-config step
     # (G + 5 PatchGAN D's, warp / coherence losses, Adam), B=16 per GPU, fp32, gradients all-reduced over RCCL
-    train = None
+    train = train_bf16 = None
     if a.train_steps > 0:
         del G, args, y
         torch.cuda.empty_cache()
-        train = train_step_ms(dev, rank, world, dist, a.train_steps)
+        old = ops.DEFAULT_PRECISION
+        try:
+            train = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16x3')
+            torch.cuda.empty_cache()
+            train_bf16 = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16')
+        finally:
+            ops.DEFAULT_PRECISION = old
 
     if rank == 0:
         fps = world * BATCH * a.steps / dt
@@ -336,6 +347,8 @@ def main():
             out['exact_fp32'] = exact
         if train is not None:
             out['train_step'] = train
+        if train_bf16 is not None:
+            out['train_step_bf16'] = train_bf16
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu'] = round(fps / world / cpu['value'], 1)

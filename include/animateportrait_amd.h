@@ -35,7 +35,7 @@ enum { AP_OK = 0, AP_ERR_INVALID = -1, AP_ERR_UNSUPPORTED = -2, AP_ERR_LAUNCH = 
 enum { AP_ACT_NONE = 0, AP_ACT_RELU = 1, AP_ACT_LRELU = 2 /* slope 0.2 */, AP_ACT_TANH = 3 };
 enum { AP_PAD_ZERO = 0, AP_PAD_REFLECT = 1 };
 enum { AP_W_OIHW = 0 /* nn.Conv2d weight */, AP_W_IOHW = 1 /* nn.ConvTranspose2d weight */ };
-enum { AP_PRECISION_FP32 = 0, AP_PRECISION_BF16X3 = 1 };
+enum { AP_PRECISION_FP32 = 0, AP_PRECISION_BF16X3 = 1, AP_PRECISION_BF16 = 2 };
 
 /* One channel segment of a (virtually concatenated) convolution input.  The
  * loader applies, per element, x := act((x - mean[n,c]) * rstd[n,c]) when
@@ -73,7 +73,12 @@ typedef struct ap_conv_desc {
     int32_t precision;    /* AP_PRECISION_FP32: exact fp32 MFMA.  AP_PRECISION_BF16X3: the caller accepts fp32-class
                            * (~1e-4 relative) results; wide 3x3 layers then run on the bf16 matrix pipe with operands
                            * split into bf16 head + tail (three MFMAs per tile, fp32 accumulation); other layers are
-                           * unaffected.  The same value must be used for pack_weights and fwd. */
+                           * unaffected.  AP_PRECISION_BF16: plain bf16 arithmetic on the same layers (head parts only:
+                           * ONE MFMA per tile, fp32 accumulation, half the LDS image -- two workgroups per CU); the
+                           * training configurations (BASELINE configs[2-3], "bf16"): ~4e-3 relative per product, as
+                           * torch autocast(bf16) of the reference would give; weights, activations and gradients in
+                           * HBM stay fp32 / split tensors (fp32 master weights).  The same value must be used for
+                           * pack_weights and fwd. */
     int32_t presplit;     /* 1: src[s].data are split tensors written by ap_split_prepass (mean/rstd/act already applied
                            * there and ignored here).  Required iff ap_conv2d_wants_presplit(d) == 1. */
     int32_t reserved;
@@ -220,7 +225,8 @@ typedef struct ap_wgrad_desc {
     int32_t K, stride, pad, pad_mode;
     int32_t nsrc;
     int32_t precision;    /* AP_PRECISION_*: BF16X3 lets wide stride-1 3x3 / 4x4 layers run on the bf16 matrix pipe
-                             with split operands (fp32-class results, ~4x the exact-fp32 MFMA rate) */
+                             with split operands (fp32-class results, ~4x the exact-fp32 MFMA rate); BF16: the head x head
+                             product only (plain bf16 operands, fp32 accumulation) */
     ap_src g;             /* g.C is ignored (M is used) */
     ap_src src[3];
 } ap_wgrad_desc;

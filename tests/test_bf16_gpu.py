@@ -1,0 +1,192 @@
+"""GPU (-m gpu): the plain-bf16 arithmetic mode (AP_PRECISION_BF16, BASELINE configs[2-3] "bf16"): every wide
+convolution / data gradient / weight gradient multiplies bf16-rounded operands with ONE MFMA per product and
+accumulates in fp32.  The kernels are checked against exactly that definition (fp64 sums of bf16-rounded
+operands), the composed train step against the fp64 oracle at bf16-autocast tolerances."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import linf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def r16(t):
+    """round to bf16 (nearest even), back in fp64: what the head part of a split tensor / packed weight holds"""
+    return t.float().bfloat16().double()
+
+
+CASES = [
+    # name, segs, cout, k, stride, pad, mode, transposed, H, W
+    ('res3x3 reflect', [64], 64, 3, 1, 1, 'reflect', False, 40, 36),
+    ('block2 3 segments zero', [64, 16, 16], 80, 3, 1, 1, 'zero', False, 33, 64),
+    ('down 3x3 s2', [64], 128, 3, 2, 1, 'zero', False, 64, 64),
+    ('patchgan 4x4 s1', [64], 96, 4, 1, 1, 'zero', False, 32, 32),
+    ('patchgan 4x4 s2 (space-to-depth)', [64], 128, 4, 2, 1, 'zero', False, 64, 48),
+    ('stem 7x7 (row form)', [3], 64, 7, 1, 3, 'reflect', False, 40, 70),
+    ('up 3x3 s2 transposed (fused phases)', [64], 64, 3, 2, 1, 'zero', True, 32, 32),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_bf16_is_fp32_sum_of_bf16_products(dev, case):
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    name, segs, cout, k, stride, pad, mode, tr, H, W = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    n = 2
+    xs = [torch.randn(n, c, H, W, generator=g) * 1.5 + 0.3 for c in segs]
+    layer = ConvLayer(segs, cout, k, stride, pad, ops.PAD_REFLECT if mode == 'reflect' else ops.PAD_ZERO, tr,
+                      1 if tr else 0).to(dev)
+    layer.spec.precision = ops.PRECISION_BF16
+    w = torch.randn(layer.weight.shape, generator=g) * 0.05
+    b = torch.randn(cout, generator=g)
+    with torch.no_grad():
+        layer.weight.copy_(w); layer.bias.copy_(b)
+    x16, w16 = r16(torch.cat(xs, 1)), r16(w)
+    if tr:
+        ref = F.conv_transpose2d(x16, w16, b.double(), stride=2, padding=1, output_padding=1)
+    elif mode == 'reflect':
+        ref = F.conv2d(F.pad(x16, (pad,) * 4, mode='reflect'), w16, b.double(), stride=stride)
+    else:
+        ref = F.conv2d(x16, w16, b.double(), stride=stride, padding=pad)
+    y = layer.run([ops.Feat(x.to(dev)) for x in xs], act=ops.ACT_NONE)
+    buf = __import__('ctypes').create_string_buffer(96)
+    d = layer.spec.desc(n, H, W) if not ops.stem_rows_eligible(layer.spec) else None
+    assert y.data.shape == ref.shape
+    scale = float(ref.abs().max())
+    assert linf(y.data, ref) < 2e-5 * scale, (name, linf(y.data, ref) / scale)
+    # ... and it is NOT the fp32-class result: the plain-bf16 mode really is what ran
+    full = (F.conv_transpose2d(torch.cat(xs, 1).double(), w.double(), b.double(), stride=2, padding=1, output_padding=1) if tr else
+            F.conv2d(F.pad(torch.cat(xs, 1).double(), (pad,) * 4, mode='reflect') if mode == 'reflect' else
+                     F.pad(torch.cat(xs, 1).double(), (pad,) * 4), w.double(), b.double(), stride=stride))
+    assert linf(y.data, full) > 1e-4 * scale
+    # statistics epilogue feeds InstanceNorm as in the other modes
+    yn = layer.run([ops.Feat(x.to(dev)) for x in xs], norm_act=ops.ACT_NONE)
+    got = (yn.data - yn.mean.view(n, cout, 1, 1)) * yn.rstd.view(n, cout, 1, 1)
+    assert linf(got, F.instance_norm(ref - b.double().view(1, -1, 1, 1))) < 1e-3
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] in (3, 4)], ids=[c[0] for c in CASES if c[3] in (3, 4)])
+def test_conv_bf16_backward_is_fp32_sum_of_bf16_products(dev, case):
+    """Data and weight gradients of a plain (bias + no norm) layer in bf16 mode.  Operators on the bf16 matrix path
+    (stride-1 3x3 / 4x4 weight gradients, every wide data gradient) must equal the fp64 sum of bf16-rounded operands
+    -- dgrad: bf16(dy) x bf16(w), wgrad: bf16(dy) x bf16(x); the ones that stay on the exact-fp32 kernels (strided /
+    transposed weight gradients, 16-channel segments) must equal the exact result.  Nothing in between."""
+    from animateportrait_amd import ops, autograd
+    from animateportrait_amd.networks import ConvLayer
+    name, segs, cout, k, stride, pad, mode, tr, H, W = case
+    g = torch.Generator().manual_seed(7 + sum(map(ord, name)))
+    n = 2
+    xs = [torch.randn(n, c, H, W, generator=g) for c in segs]
+    layer = ConvLayer(segs, cout, k, stride, pad, ops.PAD_REFLECT if mode == 'reflect' else ops.PAD_ZERO, tr,
+                      1 if tr else 0).to(dev)
+    layer.spec.precision = ops.PRECISION_BF16
+    w = torch.randn(layer.weight.shape, generator=g) * 0.05
+    with torch.no_grad():
+        layer.weight.copy_(w); layer.bias.zero_()
+    tape = autograd.Tape()
+    feats = [tape.track(ops.Feat(x.to(dev))) for x in xs]
+    out = autograd.conv_forward(tape, layer, feats, act=ops.ACT_NONE)
+    gy = torch.randn(out.data.shape, generator=g)
+    tape.add(out, gy.to(dev), 0)
+    tape.backward()
+    # references
+    gy16, w16 = r16(gy), r16(w)
+    xcat = torch.cat(xs, 1).double().requires_grad_(True)
+    wr = w16.clone().requires_grad_(True)
+
+    def fwd(x, ww):
+        if tr:
+            return F.conv_transpose2d(x, ww, None, stride=2, padding=1, output_padding=1)
+        xp = F.pad(x, (pad,) * 4, mode='reflect') if mode == 'reflect' else F.pad(x, (pad,) * 4)
+        return F.conv2d(xp, ww, None, stride=stride)
+    (fwd(xcat, w16) * gy16).sum().backward()                 # dgrad: bf16(dy) x bf16(w)
+    dx_ref = xcat.grad
+    (fwd(r16(torch.cat(xs, 1)), wr) * gy16).sum().backward()  # wgrad: bf16(dy) x bf16(x)
+    dw_ref = wr.grad
+    xe = torch.cat(xs, 1).double().requires_grad_(True)       # exact-fp32 operators: unrounded operands
+    we = w.double().requires_grad_(True)
+    (fwd(xe, we) * gy.double()).sum().backward()
+    c0 = 0
+    for f, c in zip(feats, segs):
+        contribs = tape.take(f)
+        g1, p, g2 = ops._split_contribs(contribs)
+        dx = g1 if (p == 0 and g2 is None) else ops.fold_add(g1, p, g2)
+        sc = float(dx_ref.abs().max())
+        e16, eex = linf(dx, dx_ref[:, c0:c0 + c]) / sc, linf(dx, xe.grad[:, c0:c0 + c]) / sc
+        assert min(e16, eex) < 3e-5, (name, 'dgrad', c, e16, eex)
+        if c >= 32 and cout >= 48:
+            assert e16 < 3e-5, (name, 'dgrad of a wide segment must run on the bf16 path', c, e16, eex)
+        c0 += c
+    dw = tape.param_grads[layer.weight]
+    sc = float(dw_ref.abs().max())
+    e16, eex = linf(dw, dw_ref) / sc, linf(dw, we.grad) / sc
+    assert min(e16, eex) < 3e-5, (name, 'wgrad', e16, eex)
+    if stride == 1 and not tr and sum(segs) >= 32 and cout >= 48:
+        assert e16 < 3e-5, (name, 'stride-1 wgrad must run on the bf16 path', e16, eex)
+
+
+def test_train_step_bf16_mode_vs_fp64_oracle(dev, monkeypatch):
+    """The drawing-config train step (ngf=ndf=8, B=2) with every wide layer in plain-bf16 arithmetic against the fp64
+    oracle, at bf16-autocast tolerances: outputs within 3e-2 L-inf (the reference's own autocast(bf16) generator is
+    7.8e-2 from fp32), loss terms within 5 %, gradient direction (cosine) >= 0.98 on every large tensor;
+    fp32 master weights: one optimiser step moves the fp32 parameters by ~lr."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.data.synthetic_dataset import make_train_batch
+    from oracle import generator as og, discriminator as od, train_step as ts
+    import test_train_gpu as T
+    monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_BF16)
+    torch.manual_seed(0)
+    model, opt = T._make_model(dev)
+    assert model.netG_A.model_tri_merge.spec.precision == ops.PRECISION_BF16
+    sdG = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=11)
+    model.netG_A.load_state_dict(sdG, strict=True)
+    sdD, dnames = {}, ['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']
+    for i, name in enumerate(dnames):
+        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, 8), seed=20 + i)
+        getattr(model, 'net' + name).load_state_dict(sdD[name], strict=True)
+    batch = make_train_batch(2, seed=5)
+    model.set_input(batch)
+    model.forward()
+    nets_D = [getattr(model, 'net' + n) for n in model.model_names[1:]]
+    model.set_requires_grad(nets_D, False)
+    model.optimizer_G.zero_grad()
+    model.backward_G()
+    gG = {k: p.grad.detach().clone().cpu().double() for k, p in model.netG_A.named_parameters()}
+    ov = {k: getattr(model, k).detach().cpu().double() for k in ('mask1', 'mask2', 'fakeB_static_warp', 'fake_B_warp')}
+    cast = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t     # noqa: E731
+    sG = {k: v.double().clone().requires_grad_(True) for k, v in sdG.items()}
+    sD = {n: {k: v.double() for k, v in sd.items()} for n, sd in sdD.items()}
+    b = {k: cast(v) for k, v in batch.items()}
+    o = ts.forward(sG, b, overrides=ov)
+    terms = ts.g_loss(sD, o, b, overrides=ov)
+    terms['G'].backward()
+    assert linf(model.fake_B_fore, o['fake_B_fore']) < 3e-2
+    assert float((model.fake_B_fore.detach().cpu().double() - o['fake_B_fore']).abs().mean()) < 3e-3
+    for k in ('G_A', 'G_A_l', 'G_A_le', 'G_A_ll', 'G_A_coh', 'geom_B_lipline', 'warp_B', 'warp_inter1', 'G'):
+        a, t = float(getattr(model, 'loss_' + k)), float(terms[k])
+        assert abs(a - t) <= 5e-2 * abs(t) + 1e-3, (k, a, t)
+    worst = 1.0
+    for k, v in sG.items():
+        if k.endswith('.weight') and v.numel() >= 512:
+            cos = float((gG[k] * v.grad).sum() / (gG[k].norm() * v.grad.norm()).clamp_min(1e-30))
+            worst = min(worst, cos)
+            assert cos > 0.98, (k, cos)
+    # fp32 master weights, finite step
+    w0 = model.netG_A.model_tri_merge.weight.detach().clone()
+    assert w0.dtype == torch.float32
+    model.set_input(batch)
+    model.optimize_parameters()
+    losses = model.get_current_losses()
+    assert all(np.isfinite(v) for v in losses.values()), losses
+    step = float((model.netG_A.model_tri_merge.weight - w0).abs().max())
+    assert 0 < step < 3 * 5e-5

@@ -45,10 +45,13 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
         for (int t = 0; t < 8; ++t) {
             const int cb = t & 1;
             if (LDSREADS) {
+                // LDSREADS == 1: the conv's mix (12 reads per 24 MFMAs); otherwise LDSREADS reads per 24 MFMAs
+                constexpr int NA = LDSREADS == 1 ? 4 : (LDSREADS >= 4 ? LDSREADS / 3 : LDSREADS);
+                constexpr int NB = (LDSREADS == 1 ? 12 : LDSREADS) - NA;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[cb ^ 1][i] = src[((t * 12 + i) & 63) * 64];
+                for (int i = 0; i < NA; ++i) a[cb ^ 1][i % 4] = src[((t * 12 + i) & 63) * 64];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) b[cb ^ 1][i] = src[((t * 12 + 4 + i) & 63) * 64];
+                for (int i = 0; i < NB; ++i) b[cb ^ 1][i % 8] = src[((t * 12 + 4 + i) & 63) * 64];
             }
             if (TRIPLES) {
                 // three dependent MFMAs back to back on every accumulator (the naive bf16x3 order)
@@ -70,11 +73,12 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
                         acc[m * 4 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb][m + 2 * (k & 1)], b[cb][q + 4 * (k >> 1)],
                                                                                  acc[m * 4 + q], 0, 0, 0);
             }
-            if (LDSREADS) {
+            if constexpr (LDSREADS != 0) {
+                constexpr int NR = LDSREADS == 1 ? 12 : LDSREADS;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) {
+                for (int i = 0; i < NR; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 24 / NR, 0);
                 }
             }
         }
@@ -118,6 +122,12 @@ int main() {
     run<0, 1>("1 wave/SIMD, registers only, random data", cus, 256, 150 * 1024);
     run<1, 1>("1 wave/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
     run<1, 1>("2 waves/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 512, 150 * 1024);
+    run<8, 1>("1 wave/SIMD, 8 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
+    run<6, 1>("1 wave/SIMD, 6 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
+    run<4, 1>("1 wave/SIMD, 4 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
+    run<1, 1>("1 wave/SIMD, 12 reads / 24 MFMA, random, 128 CUs", cus / 2, 256, 150 * 1024);
+    run<1, 1>("1 wave/SIMD, 12 reads / 24 MFMA, random, 64 CUs", cus / 4, 256, 150 * 1024);
+    run<0, 1>("1 wave/SIMD, registers only, random, 64 CUs", cus / 4, 256, 150 * 1024);
     run<0, 1, 1>("1 wave/SIMD, registers, random, dependent triples", cus, 256, 150 * 1024);
     run<0, 0, 1>("1 wave/SIMD, registers, ones, dependent triples", cus, 256, 150 * 1024);
     return 0;
