@@ -278,9 +278,14 @@ struct SplitTParams {
     SrcSeg seg[kMaxSeg];      // chunk_begin = first concat channel
     int nseg;
     int N, C, H, W, pad, pad_mode, Hp, X8, Cp;
+    int s2d_c;                // > 0: space-to-depth view of a pad-1 source with s2d_c channels (see below)
     uint4* out;
 };
 
+// Space-to-depth view (s2d_c = C0 > 0): channel c' = (ry * 2 + rx) * C0 + c of the (H, W) = (H0/2 + 1, W0/2 + 1) map is
+// pad1(act(IN(concat(src))))[c][2 y + ry][2 x + rx] -- the operand of a stride-2 K x K (K = 3, 4) layer rewritten as
+// the 2 x 2 stride-1 layer over 4 C0 channels (as ap_split_prepass_s2d does for the forward pass), so that strided
+// weight gradients run on the same bf16 GEMM kernel.  p.H / p.W are then the source's own size and pad must be 0.
 // grid: (ceil(Hp * X8 / 8), Cp / 64, N): a workgroup transposes 8 consecutive octets (64 padded pixels, possibly
 // across a row boundary) of 64 channels.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams p) {
@@ -294,7 +299,9 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
         const int y = oct / p.X8, x = (oct - y * p.X8) * 8 + (px & 7);
         int sy = y - p.pad, sx = x - p.pad;
         bool ok = oct < noct && y < He && x < We;
-        if (p.pad_mode == 1) {
+        if (p.s2d_c > 0) {
+            ok = oct < noct && y <= p.H / 2 && x <= p.W / 2;       // the view is (H/2 + 1) x (W/2 + 1)
+        } else if (p.pad_mode == 1) {
             sy = reflect_clamp(sy, p.H);
             sx = reflect_clamp(sx, p.W);
         } else {
@@ -305,18 +312,27 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int c = cg * 64 + cq + i;
+            int c = cg * 64 + cq + i;
             v[i] = 0.f;
             if (c < p.C) {
+                bool okc = ok;
+                int so = soff;
+                if (p.s2d_c > 0) {                                 // (wave-uniform: 16 consecutive channels share r
+                    const int r = c / p.s2d_c;                     //  unless they straddle a multiple of C0)
+                    c -= r * p.s2d_c;
+                    const int yy = 2 * y + (r >> 1) - 1, xx = 2 * x + (r & 1) - 1;
+                    okc = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    so = okc ? yy * p.W + xx : 0;
+                }
                 int s = 0;
                 if (p.nseg > 1 && c >= p.seg[1].chunk_begin) s = 1;
                 if (p.nseg > 2 && c >= p.seg[2].chunk_begin) s = 2;
                 const SrcSeg sg = s == 0 ? p.seg[0] : (s == 1 ? p.seg[1] : p.seg[2]);   // wave-uniform
                 const int cs = c - sg.chunk_begin;
-                float t = sg.data[((long long)n * sg.C + cs) * HW + soff];
+                float t = sg.data[((long long)n * sg.C + cs) * HW + so];
                 if (sg.mean != nullptr) t = (t - sg.mean[n * sg.C + cs]) * sg.rstd[n * sg.C + cs];
                 t = sg.act == 1 ? fmaxf(t, 0.f) : (sg.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-                v[i] = ok ? t : 0.f;
+                v[i] = okc ? t : 0.f;
             }
         }
 #pragma unroll

@@ -50,6 +50,9 @@ struct WgradPlan {
     // split-bf16 kernel (wgrad_bf16x3.h): operands as [n][part][row][x/8][channel] pixel-octet slots
     bool bf3 = false;
     int c_tiles = 0, Mp = 0, Cp = 0, GX8 = 0, AX8 = 0;
+    // ... of the space-to-depth form of a stride-2 layer: a 2 x 2 stride-1 layer over 4 Cin channels
+    bool s2d = false;
+    int Kb = 0, Cb = 0, Hb = 0, Wb = 0;     // kernel size, channels and operand size the bf16 GEMM kernel sees
     // streaming kernel for 1..2 input channels (wgrad_narrow.h): > 0 = output channels per workgroup
     int narrow_cob = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
 };
@@ -67,6 +70,8 @@ static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
          reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>, 1>)},
         {4, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 3>), WgradBf3Cfg<4>::lds_bytes(),
          reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 1>)},
+        {2, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<2>, 3>), WgradBf3Cfg<2>::lds_bytes(),   // space-to-depth forms
+         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<2>, 1>)},
     };
     return v;
 }
@@ -139,15 +144,23 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         }
     }
     const char* nob = getenv("APAMD_NO_BF16X3");
-    if (d->precision != AP_PRECISION_FP32 && S == 1 && (K == 3 || K == 4) && d->M >= 48 && pl.Cin >= 32 &&
-        !(nob && atoi(nob))) {
-        // wide stride-1 layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
+    const bool bf_ok = d->precision != AP_PRECISION_FP32 && d->M >= 48 && !(nob && atoi(nob));
+    // stride-2 3x3 / 4x4 pad-1 layers (the generator's encoder, the PatchGAN body): the space-to-depth form -- a 2 x 2
+    // stride-1 layer over 4 Cin channels -- runs on the same bf16 GEMM kernel (16x the fp32 MFMA rate per product; a
+    // 3x3 layer carries 7 of 16 all-zero taps along)
+    const char* nos = getenv("APAMD_NO_S2D_WGRAD");
+    const bool s2d = bf_ok && S == 2 && (K == 3 || K == 4) && d->pad == 1 && d->pad_mode == AP_PAD_ZERO && pl.Cin >= 8 &&
+                     d->H % 2 == 0 && d->W % 2 == 0 && !(nos && atoi(nos));
+    pl.Kb = K; pl.Cb = pl.Cin; pl.Hb = d->H; pl.Wb = d->W;
+    if (s2d) { pl.s2d = true; pl.Kb = 2; pl.Cb = 4 * pl.Cin; pl.Hb = d->H / 2 + 1; pl.Wb = d->W / 2 + 1; }
+    if (s2d || (bf_ok && S == 1 && (K == 3 || K == 4) && pl.Cin >= 32)) {
+        // wide layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
         pl.bf3 = true;
         pl.tiles_x = (d->GW + 31) / 32;
         pl.tiles_y = (d->GH + 1) / 2;
         pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
         pl.m_tiles = (d->M + 63) / 64;
-        pl.c_tiles = (pl.Cin + 63) / 64;
+        pl.c_tiles = (pl.Cb + 63) / 64;
         const char* e = getenv("APAMD_WGRAD_BLOCKS");
         if (e) {                                                  // tuning / test knob: never silent
             static bool told = false;
@@ -163,11 +176,11 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.Cp = pl.c_tiles * 64;
         pl.GHp = pl.tiles_y * 2;
         pl.GX8 = pl.tiles_x * 4;
-        pl.Hp = pl.GHp + K - 1;
+        pl.Hp = pl.GHp + pl.Kb - 1;
         pl.AX8 = pl.tiles_x * 4 + 1;
         pl.a_floats = (long long)d->N * 2 * pl.Hp * pl.AX8 * pl.Cp * 4;      // 16-byte slots -> floats
         pl.g_floats = (long long)d->N * 2 * pl.GHp * pl.GX8 * pl.Mp * 4;
-        pl.part_floats = (long long)pl.P * d->M * pl.Q;
+        pl.part_floats = (long long)pl.P * d->M * pl.Cb * pl.Kb * pl.Kb;
         return AP_OK;
     }
     const int PR = pl.k->PR;
@@ -216,7 +229,7 @@ static int launch_pad(const ap_src* segs, int nseg, int N, int C, int H, int W, 
 }
 
 static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode,
-                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream) {
+                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c) {
     SplitTParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = nseg;
@@ -227,6 +240,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         cbeg += segs[s].C;
     }
     p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
+    p.s2d_c = s2d_c;
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
     hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
     return check_launch("split_transpose_kernel");
@@ -367,25 +381,25 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
     if (pl.bf3) {
         const WgradBf3Kernel* bk = nullptr;
         for (const auto& k : wgrad_bf3_registry())
-            if (k.K == d->K) bk = &k;
-        if (!bk) return fail(AP_ERR_UNSUPPORTED, "wgrad: no split-bf16 kernel for k=%d", d->K);
+            if (k.K == pl.Kb) bk = &k;
+        if (!bk) return fail(AP_ERR_UNSUPPORTED, "wgrad: no split-bf16 kernel for k=%d", pl.Kb);
         const void* wfn = d->precision == AP_PRECISION_BF16 ? bk->fn1 : bk->fn;
         rc = ensure_wattr(wfn);
         if (rc) return rc;
         uint4* at = reinterpret_cast<uint4*>(workspace);
         uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
         float* partial = workspace + pl.a_floats + pl.g_floats;
-        rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cin, d->H, d->W, d->pad, d->pad_mode, pl.Hp, pl.AX8, pl.Cp,
-                                    at, stream);
+        rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
+                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0);
         if (rc) return rc;
         ap_src g = d->g;
         g.C = d->M;
-        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream);
+        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream, 0);
         if (rc) return rc;
         WgradBf3Params p;
         memset(&p, 0, sizeof(p));
         p.gt = gt; p.at = at;
-        p.N = d->N; p.M = d->M; p.Cin = pl.Cin; p.Q = pl.Q;
+        p.N = d->N; p.M = d->M; p.Cin = pl.Cb; p.Q = pl.Cb * pl.Kb * pl.Kb;
         p.GHp = pl.GHp; p.GX8 = pl.GX8; p.Mp = pl.Mp; p.Hp = pl.Hp; p.AX8 = pl.AX8; p.Cp = pl.Cp;
         p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P;
         p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
@@ -402,6 +416,10 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
         const long long n = (long long)d->M * pl.Q;
         int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+        if (pl.s2d) {
+            hipLaunchKernelGGL(wgrad_reduce_s2d_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, d->M, pl.Cin, d->K, dw);
+            return check_launch("wgrad_reduce_s2d_kernel");
+        }
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, n, dw);
         return check_launch("wgrad_reduce_kernel");
     }

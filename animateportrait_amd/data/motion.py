@@ -32,8 +32,10 @@ def cal_motion256(lm2d0, lm2d, device=None, size=256):
     device = torch.device(device if device is not None else 'cuda:0')
     if device.type != 'cuda':
         raise RuntimeError('animateportrait_amd: cal_motion256 rasterises on the MI355X; there is no CPU path')
-    a0 = np.asarray(lm2d0.cpu() if torch.is_tensor(lm2d0) else lm2d0, dtype=np.float64)
-    a1 = np.asarray(lm2d.cpu() if torch.is_tensor(lm2d) else lm2d, dtype=np.float64)
+    # (C-contiguous copies: an expanded / broadcast view would carry its zero strides through every step below and
+    # reach the kernel as a non-contiguous device tensor)
+    a0 = np.array(lm2d0.cpu() if torch.is_tensor(lm2d0) else lm2d0, dtype=np.float64, order='C')
+    a1 = np.array(lm2d.cpu() if torch.is_tensor(lm2d) else lm2d, dtype=np.float64, order='C')
     if a0.ndim == 2:
         a0, a1 = a0[None], a1[None]
     n = a0.shape[0]
@@ -45,9 +47,9 @@ def cal_motion256(lm2d0, lm2d, device=None, size=256):
     tri = np.full((n, tmax, 3), -1, dtype=np.int32)
     for i, t in enumerate(tris):
         tri[i, :t.shape[0]] = t
-    pts = torch.from_numpy(dst.astype(np.float32)).to(device)
-    val = torch.from_numpy(src.astype(np.float32)).to(device)
-    trid = torch.from_numpy(tri).to(device)
+    pts = torch.from_numpy(np.ascontiguousarray(dst, dtype=np.float32)).to(device).contiguous()
+    val = torch.from_numpy(np.ascontiguousarray(src, dtype=np.float32)).to(device).contiguous()
+    trid = torch.from_numpy(np.ascontiguousarray(tri)).to(device).contiguous()
     out = torch.empty((n, size, size, 2), dtype=torch.float32, device=device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     C.check(C.lib().ap_motion_grid(ctypes.c_void_p(pts.data_ptr()), ctypes.c_void_p(val.data_ptr()),

@@ -161,6 +161,84 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
                     'from the reference tree: their outputs are synthetic inputs, geometry/identity terms skipped'}
 
 
+def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
+    """BASELINE configs[4]: a 10 s clip (625 frames at the reference's 62.5 fps, main_end2end_module2.py:123-124)
+    through the in-process pipeline (Module1 content LSTM -> landmarks -> motion grids -> landmark maps -> netF pre/post
+    -> static drawing (once) -> generator -> blend), wall-clock, next to the reference-style CPU data path (per frame:
+    txt round trip, scipy.griddata motion, static drawing at 512^2, generator at batch 1) timed on `cpu_frames` frames of
+    the same clip and extrapolated.  Random-init weights; stand-in netF / matte (no checkpoints in the reference tree)."""
+    import contextlib
+    import io
+    import tempfile
+    from animateportrait_amd import standins, stream, module1
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.synthetic import make_landmarks
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw',
+                               '--dataset_mode', 'synthetic', '--name', 'drawing_stream', '--output_nc', '1', '--ngf', '64',
+                               '--netg_resb_div', '3', '--netg_resb_disp', '3', '--gpu_ids', str(dev.index)])
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(1234)
+        model = create_model(opt)
+    model.aux['netF'] = standins.StandinFlowNet().to(dev)
+    content = module1.Audio2LandmarkContent().to(dev).eval()
+    g = torch.Generator().manual_seed(1234)
+    photo = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
+    matte = (((yy / 0.8) ** 2 + (xx / 0.6) ** 2) < 1).float().view(1, 1, 256, 256)
+    lm0 = make_landmarks(1, g)[0]
+    t = torch.arange(frames).view(frames, 1, 1).float()
+    seq = lm0.unsqueeze(0) + 3.0 * torch.sin(0.1 * t + lm0.unsqueeze(0) / 40.0)
+    au = torch.randn(frames, 18, 80, generator=g)
+    fid = torch.randn(204, generator=g) * 0.1
+    streamer = stream.ClipStreamer(model, batch=batch)
+
+    def clip(profile=False):
+        module1.predict_landmarks(content, au, fid)          # Module1 content branch over the whole clip (timed, see above)
+        return streamer.run(photo, lm0, seq, matte=matte, profile=profile)
+    clip()                                                   # warm-up (first-use compilation of torch LSTM kernels etc.)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = clip()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    clip(profile=True)
+    stages = {k: round(v, 4) for k, v in streamer.timing.items()}
+    # ---- reference-style CPU path on a bounded sample
+    from oracle import generator as og, static_generator as osg, motion as om, aux_glue as oa
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sd_g = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
+    sd_s = og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321)
+    netF = standins.StandinFlowNet()
+    a_lm = oa.draw2(256, 256, lm0.numpy(), 3).unsqueeze(0)
+
+    def frame(ori, lm):
+        with torch.no_grad():
+            motion = torch.from_numpy(om.cal_motion256(ori, lm)).unsqueeze(0)
+            tb = oa.draw2(256, 256, lm, 3).unsqueeze(0)
+            flow, ifm = oa.flow_network_warp(netF, photo, torch.from_numpy(ori).unsqueeze(0), torch.from_numpy(lm).unsqueeze(0))
+            static = osg.static_drawing(sd_s, photo)         # the reference recomputes it per frame (geomcgt_ifw_test_model.py:282-285)
+            return osg.streaming_forward(lambda *a: og.generator_forward(sd_g, *a, div=3, disp=3), photo, matte, static,
+                                         a_lm, tb, motion, flow, ifm)[0]
+    with tempfile.TemporaryDirectory() as td:
+        stream.reference_style_cpu_clip(frame, lm0.numpy(), seq[:1].numpy(), td)      # warm-up
+        t0 = time.perf_counter()
+        stream.reference_style_cpu_clip(frame, lm0.numpy(), seq[:cpu_frames].numpy(), td)
+        cpu_s = (time.perf_counter() - t0) / cpu_frames
+    return {'metric': 'end-to-end clip wall-clock (10 s clip = %d frames @62.5 fps)' % frames,
+            'value': round(wall, 3), 'unit': 's', 'frames_per_s': round(frames / wall, 1), 'batch': batch,
+            'realtime_factor': round(10.0 / wall, 2), 'stage_seconds_profiled': stages,
+            'cpu_baseline': {'value': round(cpu_s * frames, 1), 'unit': 's (extrapolated from %d frames)' % cpu_frames,
+                             's_per_frame': round(cpu_s, 3), 'cores': cores, 'kind': 'port',
+                             'sample': 'oracle per-frame path: landmark txt round trip, scipy.griddata motion, cv2-rule landmark '
+                                       'maps, netF pre/post, static drawing @512^2, generator, blend; batch 1'},
+            'speedup_vs_cpu': round(cpu_s * frames / wall, 1),
+            'note': 'random-init weights; stand-in netF and matte; Module1 = content LSTM only (random init) on synthetic '
+                    'mel windows: AutoVC front end / pose branch / checkpoints absent from the reference tree'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -169,7 +247,16 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32 comparison leg')
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
+    ap.add_argument('--stream', action='store_true',
+                    help='BASELINE configs[4] instead of the default legs: wall-clock of a 10 s (625-frame) clip through the '
+                         'in-process pipeline, next to the reference-style CPU path (prints its own JSON line)')
     a = ap.parse_args()
+    if a.stream:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
+        torch.cuda.set_device(0)
+        print(json.dumps(stream_leg(torch.device('cuda', 0))))
+        return
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')

@@ -265,6 +265,9 @@ def test_motion_grid_rasteriser(dev, golden):
         assert linf(got[i], gd['motion_%d' % i]) < 2e-5          # 2.5e-3 px
     one = cal_motion256(lm0[1], lm[1], device=dev)
     assert torch.equal(one[0], got[1])
+    # a clip: ONE source landmark set broadcast over the frames (zero-stride view), as the clip streamer passes it
+    clip = cal_motion256(torch.from_numpy(lm0[1]).unsqueeze(0).expand(2, -1, -1).numpy(), np.stack([lm[1], lm[1]]), device=dev)
+    assert torch.equal(clip[0], got[1]) and torch.equal(clip[1], got[1])
     ident = cal_motion256(lm[0], lm[0], device=dev)              # identical landmarks: the identity grid
     ax = torch.arange(256., device=dev) / 127.5 - 1
     assert linf(ident[0, :, :, 0], ax.view(1, 256).expand(256, 256)) < 1e-5

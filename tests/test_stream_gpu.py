@@ -1,0 +1,59 @@
+"""GPU (-m gpu): the in-process clip pipeline (ClipStreamer: landmarks -> motion grids -> landmark maps -> netF pre/post
+-> GeomCGTIFWTestModel) against the oracle's per-frame composition of the reference's data path
+(scipy.griddata motion, cv2-rule discs, flow_network_warp, static drawing, generator, blend)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import linf
+
+pytestmark = pytest.mark.gpu
+
+
+def test_clip_streamer_vs_oracle_frames():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import contextlib
+    import io
+    from animateportrait_amd import standins, stream
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.synthetic import make_landmarks
+    from oracle import generator as og, static_generator as osg, motion as om, aux_glue as oa
+    dev = torch.device('cuda:0')
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw',
+                               '--dataset_mode', 'synthetic', '--name', 'drawing_stream', '--output_nc', '1', '--ngf', '8',
+                               '--netg_resb_div', '3', '--netg_resb_disp', '3', '--gpu_ids', '0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    sd_g = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=1234)
+    sd_s = og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321)
+    model.netG_A.load_state_dict(sd_g, strict=True)
+    model.net_staticG.load_state_dict(sd_s, strict=True)
+    netF = standins.StandinFlowNet()
+    model.aux['netF'] = standins.StandinFlowNet().to(dev)
+    # a smooth photo (sampling a noise image at positions that differ by 1e-3 px would dominate the comparison)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
+    photo = torch.stack([torch.sin(3 * xx + yy), torch.cos(2 * yy - xx), xx * yy], 0).unsqueeze(0).contiguous()
+    matte = (((yy / 0.8) ** 2 + (xx / 0.6) ** 2) < 1).float().view(1, 1, 256, 256) * 0.9
+    g = torch.Generator().manual_seed(9)
+    lm0 = make_landmarks(1, g)[0]
+    t = torch.arange(5).view(5, 1, 1).float()
+    seq = (lm0.unsqueeze(0) + 3.0 * torch.sin(0.7 * t + lm0.unsqueeze(0) / 40.0)).round() + 0.25   # (5, 68, 2)
+    streamer = stream.ClipStreamer(model, batch=2)
+    out = streamer.run(photo, lm0, seq, matte=matte, profile=True).cpu()
+    assert out.shape == (5, 1, 256, 256) and set(streamer.timing) == {'motion_grid', 'landmark_maps', 'set_input_netF', 'generator'}
+    with torch.no_grad():
+        static = osg.static_drawing(sd_s, photo)
+        a_lm = oa.draw2(256, 256, lm0.numpy(), 3).unsqueeze(0)
+        for k in range(5):
+            motion = torch.from_numpy(om.cal_motion256(lm0.numpy(), seq[k].numpy())).unsqueeze(0)
+            tb_lm = oa.draw2(256, 256, seq[k].numpy(), 3).unsqueeze(0)
+            flow, ifm = oa.flow_network_warp(netF, photo, lm0.unsqueeze(0), seq[k:k + 1])
+            fake, _, _, _ = osg.streaming_forward(lambda *a: og.generator_forward(sd_g, *a, div=3, disp=3), photo, matte,
+                                                  static, a_lm, tb_lm, motion, flow, ifm)
+            err = (out[k:k + 1] - fake).abs()
+            assert float(err.max()) < 2e-2 and float(err.mean()) < 3e-4, (k, float(err.max()), float(err.mean()))
+    # same clip in one batch and without stage synchronisation: identical frames
+    out2 = stream.ClipStreamer(model, batch=8).run(photo, lm0, seq, matte=matte).cpu()
+    assert linf(out2, out) < 1e-4          # another batch size picks another tile shape: fp32 summation order
