@@ -106,6 +106,7 @@ template <class C>
 __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const ConvKParams p) {
     constexpr int S = C::S, K = C::K, TMAX = C::TMAX, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
+    constexpr int IWE = (IW + 1) / 2;      // even columns of a row of the LDS image (stride-2 layout, see pgeo)
     constexpr bool XPF = true;             // fragments of the next stage's tap 0 are fetched during this stage's last tap
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4* const smem = reinterpret_cast<uint4*>(smem_raw);
@@ -158,7 +159,12 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         const int it = tid + k * 256;
         const int kg = it >= PLANE ? 1 : 0;
         const int pix = it - kg * PLANE;
-        const int ly = pix / IW, lx = pix - ly * IW;
+        const int ly = pix / IW;
+        int lx = pix - ly * IW;
+        // stride 2: a row of the LDS image holds the even image columns first, then the odd ones, so that the 32
+        // pixels of a fragment (image columns 2 l + kx) are CONSECUTIVE slots -- stride-2 slots are a 2-way bank
+        // conflict on every ds_read_b128 (8.2 M conflict cycles per launch, profiles/r01y_pmc_mfma.md)
+        if constexpr (S == 2) lx = lx < IWE ? 2 * lx : 2 * (lx - IWE) + 1;
         pgeo[k] = it < 2 * PLANE ? ((kg << 15) | (ly << 8) | lx) : -1;
     }
     auto locate = [&](int logical, Bf3Tile& t, int (&goff)[NIT]) __attribute__((always_inline)) {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
 
     // fragment addresses (16-byte slots)
     const int a_slot = half * CO_TILE + wco * MT * 32 + l32;                       // + ((part*T + t)*2) * CO_TILE + m*32
-    const int b_slot = half * PLANE + (wpx * NT) * S * IW + l32 * S;               // + part*XP + toff + q*S*IW
+    const int b_slot = half * PLANE + (wpx * NT) * S * IW + (S == 2 ? l32 : l32 * S);   // + part*XP + toff + q*S*IW
 
     f32x16 acc[MT][NT];
     bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
         const uint4* Xc = xbuf + stage_buf * STAGE + b_slot;
         int toff;
-        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
+        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (S == 2 ? ((t % K) & 1) * IWE + ((t % K) >> 1) : (t % K));
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         const uint4* Wc = wbuf + stage_buf * STAGE + a_slot;
         const uint4* Xc = xbuf + stage_buf * STAGE + b_slot;
         int toff;
-        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (t % K);
+        if constexpr (K > 0) toff = C::ROW ? t : (t / K) * IW + (S == 2 ? ((t % K) & 1) * IWE + ((t % K) >> 1) : (t % K));
         else toff = (int)((p.tap_bits >> (2 * t)) & 1u) * IW + (int)((p.tap_bits >> (2 * t + 1)) & 1u);
         if (r < PARTS * MT) {
             const int m = r / PARTS;
