@@ -37,15 +37,21 @@ struct WgradBf3Params {
     int ablate;               // debugging only (APAMD_ABLATE): 1 = no refill of the stage buffers, 2 = no barrier
 };
 
-template <int K_>
+// PARTS_ = 2: head + tail staged, three products per tap.  PARTS_ = 1 (AP_PRECISION_BF16): head planes only -- half the
+// LDS stage and LDS-DMA traffic, one product per tap, two workgroups per CU.
+template <int K_, int PARTS_ = 2>
 struct WgradBf3Cfg {
-    static constexpr int K = K_, T = K * K, PR = 2;
+    static constexpr int K = K_, T = K * K, PR = 2, PARTS = PARTS_;
+    static_assert(PARTS == 1 || PARTS == 2, "head only, or head + tail");
     static constexpr int ROWS = PR + K - 1;                 // staged rows of the shifted operand
     static constexpr int NXG = 5;                           // staged octets per row: 4 + 1 for the column shift
-    static constexpr int G_SLOTS = 2 * PR * 4 * 64;         // [part][row][octet][m]
-    static constexpr int A_SLOTS = 2 * ROWS * NXG * 64;     // [part][row][octet][ci]
+    static constexpr int G_SLOTS = PARTS * PR * 4 * 64;     // [part][row][octet][m]
+    static constexpr int A_SLOTS = PARTS * ROWS * NXG * 64; // [part][row][octet][ci]
     static constexpr int NPIECE = (G_SLOTS + A_SLOTS) / 64; // 1 KiB DMA pieces per stage
     static constexpr size_t lds_bytes() { return (size_t)2 * (G_SLOTS + A_SLOTS) * 16; }
+    // one accumulator tile per tap: 16 K^2 registers -- with head-only staging two workgroups share a CU when that
+    // leaves room for the operand registers (K <= 3; a 4x4 layer's 256 accumulators need a SIMD's whole file)
+    static constexpr int WG_PER_CU = (PARTS == 1 && T * 16 <= 160) ? 2 : 1;
     static_assert(K - 1 < 8, "the column shift must stay inside one extra octet");
 };
 
@@ -64,12 +70,11 @@ __device__ __forceinline__ bf16x8 funnel8(const u32x4 lo, const u32x4 hi) {
     return __builtin_bit_cast(bf16x8, r);
 }
 
-// PROD = 3: split-bf16 arithmetic (tail x head, head x tail, head x head per tap).  PROD = 1: plain bf16 arithmetic
-// (AP_PRECISION_BF16): the head x head product only -- the staging is unchanged (the tail planes still travel; their
-// fragment reads are dead code), the matrix work is a third.
-template <class C, int PROD = 3>
-__global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
-    static_assert(PROD == 1 || PROD == 3, "one or three products");
+// PARTS = 2: split-bf16 arithmetic (tail x head, head x tail, head x head per tap).  PARTS = 1: plain bf16 arithmetic
+// (AP_PRECISION_BF16): the head x head product only, head planes only.
+template <class C>
+__global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3Params p) {
+    constexpr int PARTS = C::PARTS, PROD = PARTS == 1 ? 1 : 3;
     constexpr int K = C::K, T = C::T, ROWS = C::ROWS, NXG = C::NXG;
     constexpr int G_SLOTS = C::G_SLOTS, A_SLOTS = C::A_SLOTS, STAGE = G_SLOTS + A_SLOTS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -92,9 +97,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
     // shifted operand -- so a piece's kind is static and only scalar offsets depend on the wave.  The position of
     // the NEXT stage to issue advances incrementally (no divisions in the loop).
     const unsigned lane16 = lane * 16;
-    const int dpart = wave & 1, dhw = wave >> 1;
-    constexpr int NAE = ROWS * NXG, NAP = (NAE + 1) / 2;               // (row, octet) pairs; per wave
-    constexpr int NPW = 4 + NAP;                                       // pieces per wave and stage
+    // (head-only staging: every wave moves head pieces -- G row (w >> 1), octets 2 (w & 1) and + 1; every fourth
+    // (row, octet) pair of the shifted operand)
+    const int dpart = PARTS == 2 ? (wave & 1) : 0, dhw = wave >> 1;
+    constexpr int NGP = PARTS == 2 ? 4 : 2;                            // G pieces per wave and stage
+    constexpr int NAE = ROWS * NXG, NAP = PARTS == 2 ? (NAE + 1) / 2 : (NAE + 3) / 4;   // (row, octet) pairs; per wave
+    constexpr int NPW = NGP + NAP;                                     // pieces per wave and stage
     const long long g_row = (long long)p.GX8 * p.Mp, g_part = g_row * p.GHp;
     const long long a_row = (long long)p.AX8 * p.Cp, a_part = a_row * p.Hp;
     int in_ = 0, ity = 0, itx = 0;                                      // (image, tile row, tile column) to issue next
@@ -116,12 +124,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
         }
     };
     auto issue_piece = [&](int buf, int j) __attribute__((always_inline)) {   // uses gbase / abase of the located stage
-        if (j < 4) {
-            glds16_sv(p.gt + gbase + (long long)j * p.Mp, lane16,
-                      lds0 + (buf * STAGE + ((dpart * C::PR + dhw) * 4 + j) * 64) * 16);
+        if (j < NGP) {
+            const int o = PARTS == 2 ? j : 2 * (wave & 1) + j;          // octet of the G row
+            glds16_sv(p.gt + gbase + (long long)o * p.Mp, lane16,
+                      lds0 + (buf * STAGE + ((dpart * C::PR + dhw) * 4 + o) * 64) * 16);
         } else {
-            const int e = (j - 4) * 2 + dhw;                            // (row, octet) pair of this wave
-            if ((j - 4) * 2 + 1 < NAE || e < NAE) {
+            const int e = PARTS == 2 ? (j - NGP) * 2 + dhw : (j - NGP) * 4 + wave;   // (row, octet) pair of this wave
+            if ((PARTS == 2 && (j - NGP) * 2 + 1 < NAE) || e < NAE) {
                 const int r = e / NXG, o = e - r * NXG;
                 glds16_sv(p.at + abase + r * a_row + (long long)o * p.Cp, lane16,
                           lds0 + (buf * STAGE + G_SLOTS + ((dpart * ROWS + r) * NXG + o) * 64) * 16);
@@ -170,31 +179,31 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3(const WgradBf3Params p) {
         const uint4* S0 = smem + buf * STAGE;
         if (ky == 0) {
             ah[ks & 1] = *reinterpret_cast<const bf16x8*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * 64);
-            al[ks & 1] = *reinterpret_cast<const bf16x8*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
+            if constexpr (PARTS == 2) al[ks & 1] = *reinterpret_cast<const bf16x8*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
         }
         const int row = py + ky;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             rh[rb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((0 * ROWS + row) * NXG + xh * 2 + j) * 64);
-            rl[rb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((1 * ROWS + row) * NXG + xh * 2 + j) * 64);
+            if constexpr (PARTS == 2) rl[rb][j] = *reinterpret_cast<const u32x4*>(S0 + ab + ((1 * ROWS + row) * NXG + xh * 2 + j) * 64);
         }
     };
     auto shift_group = [&](int gidx) __attribute__((always_inline)) {  // odd shifts only: even ones are register picks
         const int rb = gidx % RB, pb = gidx & 1;
         sh[pb][1] = funnel8<1>(rh[rb][0], rh[rb][1]);
-        sl[pb][1] = funnel8<1>(rl[rb][0], rl[rb][1]);
+        if constexpr (PARTS == 2) sl[pb][1] = funnel8<1>(rl[rb][0], rl[rb][1]);
         if constexpr (K > 3) {
             sh[pb][3] = funnel8<3>(rh[rb][0], rh[rb][1]);
-            sl[pb][3] = funnel8<3>(rl[rb][0], rl[rb][1]);
+            if constexpr (PARTS == 2) sl[pb][3] = funnel8<3>(rl[rb][0], rl[rb][1]);
         }
     };
     auto mfma_one = [&](int gidx, int i) __attribute__((always_inline)) {
         const int ks = gidx / K, ky = gidx % K, rb = gidx % RB, pb = gidx & 1;
         const int pr = PROD == 1 ? 2 : i / K, kx = i % K;               // product-major: round the K accumulators
         bf16x8 bh, bl;
-        if (kx == 0) { bh = funnel8<0>(rh[rb][0], rh[rb][1]); bl = funnel8<0>(rl[rb][0], rl[rb][1]); }
-        else if (kx == 2) { bh = funnel8<2>(rh[rb][0], rh[rb][1]); bl = funnel8<2>(rl[rb][0], rl[rb][1]); }
-        else { bh = sh[pb][kx]; bl = sl[pb][kx]; }
+        if (kx == 0) { bh = funnel8<0>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<0>(rl[rb][0], rl[rb][1]); }
+        else if (kx == 2) { bh = funnel8<2>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<2>(rl[rb][0], rl[rb][1]); }
+        else { bh = sh[pb][kx]; if constexpr (PARTS == 2) bl = sl[pb][kx]; }
         f32x16& a = acc[ky * K + kx];
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al[ks & 1] : ah[ks & 1], pr == 1 ? bl : bh, a, 0, 0, 0);
     };

@@ -60,18 +60,18 @@ struct WgradPlan {
 // split-bf16 instantiations by kernel size (stride 1)
 struct WgradBf3Kernel {
     int K;
-    const void* fn;        // three products per tap (AP_PRECISION_BF16X3)
+    const void* fn;        // head + tail staged, three products per tap (AP_PRECISION_BF16X3)
     size_t lds_bytes;
-    const void* fn1;       // head x head only (AP_PRECISION_BF16)
+    const void* fn1;       // head planes only, one product per tap (AP_PRECISION_BF16): two workgroups per CU
+    size_t lds_bytes1;
 };
 static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
     static std::vector<WgradBf3Kernel> v = {
-        {3, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>, 3>), WgradBf3Cfg<3>::lds_bytes(),
-         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<3>, 1>)},
-        {4, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 3>), WgradBf3Cfg<4>::lds_bytes(),
-         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<4>, 1>)},
-        {2, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<2>, 3>), WgradBf3Cfg<2>::lds_bytes(),   // space-to-depth forms
-         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<2>, 1>)},
+#define APAMD_WBF3(K)                                                                                         \
+    {K, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 2>>), WgradBf3Cfg<K, 2>::lds_bytes(),     \
+     reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 1>>), WgradBf3Cfg<K, 1>::lds_bytes()}
+        APAMD_WBF3(3), APAMD_WBF3(4), APAMD_WBF3(2),   // (K = 2: the space-to-depth forms of stride-2 layers)
+#undef APAMD_WBF3
     };
     return v;
 }
@@ -167,7 +167,8 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             if (!told) fprintf(stderr, "libapamd: APAMD_WGRAD_BLOCKS=%s overrides the workgroup count\n", e);
             told = true;
         }
-        const int target = e ? atoi(e) : num_cus_w();            // one workgroup per CU (its LDS stages fill a CU)
+        // one workgroup per CU (its LDS stages fill a CU); two with head-only staging
+        const int target = e ? atoi(e) : num_cus_w() * (d->precision == AP_PRECISION_BF16 && pl.Kb <= 3 ? 2 : 1);
         int P = target / (pl.m_tiles * pl.c_tiles);
         if (P > pl.nstages / 2) P = pl.nstages / 2;
         if (P < 1) P = 1;
@@ -412,7 +413,8 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         }
         void* args[] = {&p};
         const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
-        hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args, bk->lds_bytes, stream);
+        hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args,
+                                       d->precision == AP_PRECISION_BF16 ? bk->lds_bytes1 : bk->lds_bytes, stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
         const long long n = (long long)d->M * pl.Q;
         int blocks = (int)std::min<long long>((n + 255) / 256, 4096);

@@ -19,6 +19,27 @@ __global__ __launch_bounds__(512) void mfma_stream(float* out, int iters) {
         // lets the matrix pipe run cooler, and faster, than real activations do)
         unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
         unsigned w[4];
+        if (RANDOM_DATA == 2) {
+            // what the conv really multiplies: bf16 heads and tails of fp32 values -- slots alternate between "weights"
+            // (N(0, 0.02), head / tail) and "activations" (ReLU(N(0, 1)): half of them exact zeros, head / tail)
+            const bool tail = (i >> 6) & 1, act = (i >> 7) & 1;
+            for (int j = 0; j < 4; ++j) {
+                unsigned pr[2];
+                for (int e = 0; e < 2; ++e) {
+                    float u = 0.f;                                   // ~N(0,1): sum of 4 uniforms, centred
+                    for (int q = 0; q < 4; ++q) { h = h * 1664525u + 1013904223u; u += (float)(h >> 8) * (1.f / 16777216.f); }
+                    float v = (u - 2.f) * 1.7320508f;
+                    if (act) v = v > 0.f ? v : 0.f; else v *= 0.02f;
+                    const __bf16 hi = (__bf16)v;
+                    const __bf16 lo = (__bf16)(v - (float)hi);
+                    const __bf16 pick = tail ? lo : hi;
+                    pr[e] = (unsigned)__builtin_bit_cast(unsigned short, pick);
+                }
+                w[j] = pr[0] | (pr[1] << 16);
+            }
+            lds[i] = make_uint4(w[0], w[1], w[2], w[3]);
+            continue;
+        }
         for (int j = 0; j < 4; ++j) {
             h = h * 1664525u + 1013904223u;
             const unsigned lo = RANDOM_DATA ? (0x3c00u | ((h >> 9) & 0x807fu)) : 0x3f80u;
@@ -122,6 +143,9 @@ int main() {
     run<0, 1>("1 wave/SIMD, registers only, random data", cus, 256, 150 * 1024);
     run<1, 1>("1 wave/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
     run<1, 1>("2 waves/SIMD, 12 ds_read_b128 / 24 MFMA, random", cus, 512, 150 * 1024);
+    run<1, 2>("1 wave/SIMD, 12 reads / 24 MFMA, REAL split data", cus, 256, 150 * 1024);
+    run<0, 2>("1 wave/SIMD, registers only, REAL split data", cus, 256, 150 * 1024);
+    run<1, 2>("1 wave/SIMD, 12 reads / 24 MFMA, REAL split, 64 CUs", cus / 4, 256, 150 * 1024);
     run<8, 1>("1 wave/SIMD, 8 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
     run<6, 1>("1 wave/SIMD, 6 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
     run<4, 1>("1 wave/SIMD, 4 ds_read_b128 / 24 MFMA, random", cus, 256, 150 * 1024);
