@@ -68,6 +68,9 @@ SIGNATURES = {
     'ap_norm_apply_split': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p,
                                            ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            c_f32p, ctypes.c_void_p, ctypes.c_void_p]),
+    'ap_norm_apply_split_ex': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_float, c_f32p, c_f32p,
+                                              ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                              c_f32p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
     'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),

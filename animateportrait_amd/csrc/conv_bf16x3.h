@@ -615,6 +615,7 @@ struct NormSplitParams {
     const float* res_rstd;
     float* y;                 // fp32 output or null
     uint4* xs;                // split output or null
+    int heads_only;           // 1: only the head planes of xs are written (consumers in AP_PRECISION_BF16 never read tails)
     int N, C, HW;
 };
 
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
             lv[c] = l;
         }
         *reinterpret_cast<bf16x8*>(ph + pix) = hv;
-        *reinterpret_cast<bf16x8*>(pl + pix) = lv;
+        if (!p.heads_only) *reinterpret_cast<bf16x8*>(pl + pix) = lv;
     } else {
         // A thread owns VEC consecutive pixels (16-byte loads), but a 16-byte store per lane at a 64-byte lane
         // stride writes every cache line in four partial pieces.  Transpose the block's slots through LDS so
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
             const int i = g / VEC, j = g % VEC;                // owner thread and its pixel
             if (base + g < HW) {
                 ph[base + g] = stage[0][j * LP + i];
-                pl[base + g] = stage[1][j * LP + i];
+                if (!p.heads_only) pl[base + g] = stage[1][j * LP + i];
             }
         }
     }

@@ -550,6 +550,12 @@ int64_t ap_split_prepass_bytes(int32_t N, int32_t C, int32_t H, int32_t W) {
 int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
                         float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
                         ap_stream_t stream) {
+    return ap_norm_apply_split_ex(src, stat_partials, tiles, eps, mean_out, rstd_out, residual, N, H, W, y, xs, 0, stream);
+}
+
+int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
+                           float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
+                           int32_t flags, ap_stream_t stream) {
     if (!src || !src->data) return fail(AP_ERR_INVALID, "norm_apply_split: null source");
     if (!y && !xs && !stat_partials) return fail(AP_ERR_INVALID, "norm_apply_split: nothing to produce");
     if (N < 1 || src->C < 8 || (src->C & 7) || H < 1 || W < 1)
@@ -574,6 +580,7 @@ int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t t
     p.act = src->act;
     if (residual) { p.res = residual->data; p.res_mean = residual->mean; p.res_rstd = residual->rstd; }
     p.y = y; p.xs = reinterpret_cast<uint4*>(xs);
+    p.heads_only = (flags & 1) ? 1 : 0;
     p.N = N; p.C = src->C; p.HW = H * W;
     if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
         dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);

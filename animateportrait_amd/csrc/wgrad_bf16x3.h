@@ -288,6 +288,7 @@ struct SplitTParams {
     int nseg;
     int N, C, H, W, pad, pad_mode, Hp, X8, Cp;
     int s2d_c;                // > 0: space-to-depth view of a pad-1 source with s2d_c channels (see below)
+    int heads_only;           // 1: the consumer multiplies head parts only (AP_PRECISION_BF16): the tail planes are not written
     uint4* out;
 };
 
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
                 lv[j] = l;
             }
             *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * noct + oct) * p.Cp + cg * 64 + c) = hv;
-            *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cg * 64 + c) = lv;
+            if (!p.heads_only) *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cg * 64 + c) = lv;
         }
     }
 }

@@ -230,7 +230,7 @@ static int launch_pad(const ap_src* segs, int nseg, int N, int C, int H, int W, 
 }
 
 static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode,
-                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c) {
+                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c, int heads_only) {
     SplitTParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = nseg;
@@ -242,6 +242,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     }
     p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
     p.s2d_c = s2d_c;
+    p.heads_only = heads_only;
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
     hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
     return check_launch("split_transpose_kernel");
@@ -391,11 +392,11 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
         float* partial = workspace + pl.a_floats + pl.g_floats;
         rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
-                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0);
+                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16);
         if (rc) return rc;
         ap_src g = d->g;
         g.C = d->M;
-        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream, 0);
+        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream, 0, d->precision == AP_PRECISION_BF16);
         if (rc) return rc;
         WgradBf3Params p;
         memset(&p, 0, sizeof(p));

