@@ -261,7 +261,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
-    if a.gpus < 1 or a.gpus > torch.cuda.device_count():
+    # test plumbing for boxes with fewer GPUs than ranks: APAMD_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # APAMD_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one device); the JSON line says so
+    share_gpu = bool(os.environ.get('APAMD_BENCH_SHARE_GPU'))
+    backend = os.environ.get('APAMD_DIST_BACKEND', 'nccl')
+    if a.gpus < 1 or (a.gpus > torch.cuda.device_count() and not share_gpu):
         raise SystemExit('--gpus %d but this node exposes %d GPU(s)' % (a.gpus, torch.cuda.device_count()))
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: become N ranks (one per GPU) under torch.distributed.run
@@ -275,7 +279,7 @@ def main():
                                   '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: refusing to report a run whose rank count differs from the '
                          'one asked for' % (a.gpus, world))
@@ -286,7 +290,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         probe = torch.ones(1, device=dev)
         dist.all_reduce(probe)                    # the world RCCL really sees: every rank contributes 1
         rccl_world = int(probe.item())
@@ -420,7 +427,8 @@ def main():
     if rank == 0:
         fps = world * BATCH * a.steps / dt
         out = {'metric': 'generator frames/sec @256x256 bs=16', 'value': round(fps, 2), 'unit': 'frames/s',
-               'n_gpus': world, 'rccl_world_size': rccl_world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
+               'n_gpus': world, 'rccl_world_size': rccl_world, 'collective_backend': backend if world > 1 else None,
+               'ranks_share_one_gpu': share_gpu, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
                'dtype': 'f32 (fp32 tensors; wide convs multiply on the bf16 pipe with operands split 3-way, fp32 accumulate)',
                'data': 'synthetic',
