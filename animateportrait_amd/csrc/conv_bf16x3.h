@@ -330,6 +330,12 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
     dma_wait_all();
     __syncthreads();
 
+    // taps of the 2 x 2 window that exist for the current tile (fused sub-pixel phases; wave-uniform)
+    auto tapmask_of = [&](const Bf3Tile& t) -> unsigned {
+        if (K != 0 || p.nphase <= 1) return 0xFu;
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)p.ph_tapmask[t.cot / p.co_tiles_phase]);
+    };
+    unsigned tmask = tapmask_of(cur);
     for (;;) {
         const bool has_next = tile + tile_step < tile_end;
         locate(has_next ? tile + tile_step : tile, nxt, ngoff);
@@ -387,8 +393,10 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                     } else {
                         fetch(P, t + 1, cb ^ 1);
                     }
+                    if (K != 0 || ((tmask >> tp) & 1u)) {       // (an absent tap of a fused phase: zero weights, nothing to add)
 #pragma unroll
                     for (int i = 0; i < NM; ++i) mfma_one(i);
+                    }
                     // pin the schedule: the next tap's fragment reads are spread evenly between this tap's MFMAs
                     // (left alone, the scheduler sinks every read to just before its first use and stalls on it)
                     constexpr int PER = (NM + NRD - 1) / NRD, NRD1 = PARTS * (MT + 1), PER1 = (NM + NRD1 - 1) / NRD1;
@@ -422,9 +430,10 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                     constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
                     constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
                     constexpr int R0 = NM - (NRD + RPS - 1) / RPS;              // first slot that carries reads
+                    const bool real_tap = K != 0 || ((tmask >> tp) & 1u);
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
-                        mfma_one(i);
+                        if (real_tap) mfma_one(i);
                         if (do_dma) {
 #pragma unroll
                             for (int pp = 0; pp < PPS; ++pp)
@@ -581,6 +590,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         __syncthreads();                                           // patches and statistics consumed: refill that stage
         if (!AP_ABLATE(p, 1)) issue(nxt, ngoff, 1, pl);
         cur = nxt;
+        tmask = tapmask_of(cur);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) cgoff[k] = ngoff[k];
         tile += tile_step;

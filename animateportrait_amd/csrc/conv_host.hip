@@ -863,6 +863,10 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                     const Launch& Lp = pl.launches[ph];
                     p.ph_dy0[ph] = Lp.dy0; p.ph_dx0[ph] = Lp.dx0; p.ph_oy[ph] = Lp.oy_off; p.ph_ox[ph] = Lp.ox_off;
                     p.ph_stat[ph] = Lp.stat_tile_off;
+                    p.ph_tapmask[ph] = 0;
+                    for (size_t t = 0; t < Lp.taps.size() && t < 4; ++t)
+                        if (Lp.taps[t].ky >= 0) p.ph_tapmask[ph] |= 1u << t;
+                    if (env_int("APAMD_NO_TAP_SKIP", 0)) p.ph_tapmask[ph] = 0xFu;
                 }
             }
             p.tap_bits = 0;

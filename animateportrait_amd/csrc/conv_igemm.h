@@ -72,6 +72,8 @@ struct ConvKParams {
     // ox_off / stat_tile_off with its table entry.  nphase <= 1: plain launch, the scalar fields above apply.
     int nphase, co_tiles_phase;
     int ph_dy0[4], ph_dx0[4], ph_oy[4], ph_ox[4], ph_stat[4];
+    unsigned ph_tapmask[4];   // bit t: tap t of the 2 x 2 window exists in that phase (split-bf16 run-time-tap kernels skip
+                              // the MFMAs of the others -- their weights are zero: 7 of the 16 taps of a fused 3x3 up-convolution)
 };
 
 // K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a
