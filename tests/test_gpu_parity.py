@@ -832,3 +832,53 @@ def test_instnorm_ill_conditioned_planes(dev, precision, monkeypatch):
     assert linf(b.rstd, a.rstd) <= 1e-6 * float(a.rstd.abs().max())
     rstd_ref = 1.0 / torch.sqrt(raw.var(dim=(2, 3), unbiased=False) + 1e-5)
     assert float(((a.rstd.view(n, c).double().cpu() - rstd_ref) / rstd_ref).abs().max()) < 1e-4
+
+
+def test_grid_sample_and_warp_acc_flow_reference_goldens(dev, golden):
+    """SURVEY App. D G4 / G5 on the device: F.grid_sample(x, motion) with out-of-range grid points and
+    warp_acc_flow(x, flow, mask) with flows of +-40 px (modules.py:596-625) are the two halves of the fused
+    ap_warp_concat kernel at level 0 -- against outputs of the reference's own functions (ops_small.npz), through the
+    fp32 and the split-bf16 outputs; the backward kernel scatters through the same taps."""
+    from animateportrait_amd import ops
+    gd = golden('ops_small.npz')
+    x, grid, flow, mask = (gd[k].to(dev).contiguous() for k in ('gs_x', 'gs_grid', 'wf_flow', 'wf_mask'))
+    assert float(flow.abs().max()) > 30.0
+    out = ops.warp_concat(ops.Feat(x), grid, flow, mask, 0).data
+    assert linf(out[:, :8], gd['gs_y']) < 2e-5 and linf(out[:, 8:], gd['wf_y']) < 2e-5
+    ones = torch.ones_like(mask)
+    assert linf(ops.warp_concat(ops.Feat(x), grid, flow, ones, 0).data[:, 8:], gd['wf_y_nomask']) < 2e-5
+    both = ops.warp_concat(ops.Feat(x), grid, flow, mask, 0, emit_xs=True)
+    val, _ = _decode_split(both.xs, 2, 16, 32, 32)
+    assert float(((val - both.data).abs() - both.data.abs() * 2.0 ** -16).max()) <= 1e-30
+    # backward through the same (out-of-frame) taps == autograd of the reference formulas
+    gout = torch.randn(2, 16, 32, 32, generator=torch.Generator().manual_seed(4))
+    dx = ops.warp_concat_bwd(gout.to(dev), grid, flow, mask, 0)
+    xr = gd['gs_x'].clone().requires_grad_(True)
+    from oracle import warp as ow
+    ref = torch.cat([F.grid_sample(xr, gd['gs_grid'], mode='bilinear', padding_mode='zeros', align_corners=False),
+                     ow.warp_acc_flow(xr, gd['wf_flow'], gd['wf_mask'])], 1)
+    ref.backward(gout)
+    assert linf(dx, xr.grad) < 1e-5
+
+
+def test_degenerate_shapes_are_errors_not_crashes(dev):
+    """Empty / ragged inputs are refused at the boundary (negative status + message), never launched."""
+    from animateportrait_amd import networks as N, ops, losses
+    G = N.define_G(3, 1, 8, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
+    z = lambda *s: torch.zeros(*s, device=dev)                                      # noqa: E731
+    with torch.no_grad():
+        with pytest.raises((RuntimeError, ValueError)):
+            G(z(0, 3, 256, 256), z(0, 1, 256, 256), z(0, 1, 256, 256), z(0, 256, 256, 2), z(0, 2, 256, 256), z(0, 1, 256, 256))
+        with pytest.raises((RuntimeError, ValueError)):                             # ragged: land maps of another batch size
+            G(z(2, 3, 256, 256), z(1, 1, 256, 256), z(2, 1, 256, 256), z(2, 256, 256, 2), z(2, 2, 256, 256), z(2, 1, 256, 256))
+        with pytest.raises((RuntimeError, ValueError)):                             # motion grid of the wrong size
+            G(z(1, 3, 256, 256), z(1, 1, 256, 256), z(1, 1, 256, 256), z(1, 128, 128, 2), z(1, 2, 256, 256), z(1, 1, 256, 256))
+    with pytest.raises(ValueError):
+        ops.conv2d(ops.ConvSpec([8], 8, 3, 1, 1), [ops.Feat(z(1, 4, 16, 16))], None)   # channel mismatch
+    with pytest.raises((RuntimeError, ValueError)):
+        losses.l1_loss(z(2, 1, 8, 8), z(2, 1, 8, 4))
+    with pytest.raises(RuntimeError):
+        losses.kp_to_map(z(0, 68, 2))
+    y = G(torch.rand(1, 3, 256, 256, device=dev), -torch.ones(1, 1, 256, 256, device=dev), -torch.ones(1, 1, 256, 256, device=dev),
+          z(1, 256, 256, 2), z(1, 2, 256, 256), z(1, 1, 256, 256)).detach()        # the device still works afterwards
+    assert bool(torch.isfinite(y).all())
