@@ -264,20 +264,50 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
     }
 
-    // partial[split][m][q], q = ci*T + tap.  C/D layout: column j = lane & 31 (ci), row i = (r&3) + 8*(r>>2) + 4*half (m)
-    float* out = p.partial + (long long)split * p.M * p.Q;
-    const int ci = ct * 64 + wq * 32 + l32;
+    // Partial sums leave in the accumulators' own order, partial[split][tile = mt * c_tiles + ct][wave][tap][r][lane]:
+    // every store is 256 contiguous bytes per wave.  (The OIHW order -- element (m, ci, tap) at m * Q + ci * T + tap --
+    // put a lane's 4 bytes 36..64 bytes from its neighbour's: 144 fully scattered store instructions per wave, 115 of
+    // the kernel's 250 us.)  wgrad_bf3_reduce_kernel sums the splits in this order and scatters once.
     if (AP_ABLATE(p, 16)) {
-        if (acc[0][0] == 123.456f) out[0] = 1.f;
+        if (acc[0][0] == 123.456f) p.partial[0] = 1.f;
         return;
     }
+    const long long tile_floats = 4LL * T * 1024;
+    float* out = p.partial + ((long long)split * p.m_tiles * p.c_tiles + (long long)mt * p.c_tiles + ct) * tile_floats +
+                 (long long)wave * T * 1024 + lane;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = mt * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (mm < p.M && ci < p.Cin) out[(long long)mm * p.Q + ci * T + t] = acc[t][r];
+        for (int r = 0; r < 16; ++r) out[(t * 16 + r) * 64] = acc[t][r];
+}
+
+// dW = sum over the P splits of the partial tiles written by wgrad_bf16x3 (fixed order), scattered to the caller's
+// layout: s2d_c == 0: dW[m][ci][ky][kx] (OIHW / IOHW rows as the plan defines M and Cin); s2d_c = C > 0: the kernel saw
+// the space-to-depth form (4C channels, 2 x 2 taps) of a stride-2 K x K layer: ci' = (ry*2+rx)*C + c, tap = ty*2+tx ->
+// dW[m][c][2 ty + ry][2 tx + rx], taps >= K (a 3x3 layer's seven all-zero ones) dropped.
+__global__ __launch_bounds__(256) void wgrad_bf3_reduce_kernel(const float* __restrict__ partial, int P, int M, int Cin,
+                                                               int T, int c_tiles, long long total, int s2d_c, int K,
+                                                               float* __restrict__ dw) {
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < P; ++k) s += partial[(long long)k * total + j];
+        const int lane = (int)(j & 63), r = (int)((j >> 6) & 15);
+        const long long jt = j >> 10;
+        const int t = (int)(jt % T);
+        const int wave = (int)((jt / T) & 3);
+        const int tile = (int)(jt / T / 4);
+        const int mt = tile / c_tiles, ct = tile - mt * c_tiles;
+        const int mm = mt * 64 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ci = ct * 64 + (wave >> 1) * 32 + (lane & 31);
+        if (mm >= M || ci >= Cin) continue;
+        if (s2d_c == 0) {
+            dw[((long long)mm * Cin + ci) * T + t] = s;
+        } else {
+            const int r2 = ci / s2d_c, c = ci - r2 * s2d_c;
+            const int ky = 2 * (t >> 1) + (r2 >> 1), kx = 2 * (t & 1) + (r2 & 1);
+            if (ky < K && kx < K) dw[(((long long)mm * s2d_c + c) * K + ky) * K + kx] = s;
         }
+    }
 }
 
 // ---- operand preparation: T[n][part][y][x/8][c][8 px] (bf16 head / tail) = padded view of act(IN(concat(src))),

@@ -181,7 +181,7 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.AX8 = pl.tiles_x * 4 + 1;
         pl.a_floats = (long long)d->N * 2 * pl.Hp * pl.AX8 * pl.Cp * 4;      // 16-byte slots -> floats
         pl.g_floats = (long long)d->N * 2 * pl.GHp * pl.GX8 * pl.Mp * 4;
-        pl.part_floats = (long long)pl.P * d->M * pl.Cb * pl.Kb * pl.Kb;
+        pl.part_floats = (long long)pl.P * pl.m_tiles * pl.c_tiles * 4 * pl.Kb * pl.Kb * 1024;   // accumulator-order tiles
         return AP_OK;
     }
     const int PR = pl.k->PR;
@@ -417,14 +417,12 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args,
                                        d->precision == AP_PRECISION_BF16 ? bk->lds_bytes1 : bk->lds_bytes, stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
-        const long long n = (long long)d->M * pl.Q;
-        int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-        if (pl.s2d) {
-            hipLaunchKernelGGL(wgrad_reduce_s2d_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, d->M, pl.Cin, d->K, dw);
-            return check_launch("wgrad_reduce_s2d_kernel");
-        }
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, n, dw);
-        return check_launch("wgrad_reduce_kernel");
+        const int T = pl.Kb * pl.Kb;
+        const long long total = (long long)pl.m_tiles * pl.c_tiles * 4 * T * 1024;
+        const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, d->M, pl.Cb, T,
+                           pl.c_tiles, total, pl.s2d ? pl.Cin : 0, d->K, dw);
+        return check_launch("wgrad_bf3_reduce_kernel");
     }
     rc = ensure_wattr(pl.k->fn);
     if (rc) return rc;

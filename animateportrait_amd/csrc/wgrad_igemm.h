@@ -193,23 +193,6 @@ __global__ __launch_bounds__(256, C::NA <= 20 ? 2 : 1) void wgrad_igemm_f32(cons
         }
 }
 
-// Reduction of the space-to-depth form of a stride-2 K x K layer: partial[s][m][((ry*2+rx)*C + c)*4 + ty*2 + tx] ->
-// dW[m][c][ky][kx] with ky = 2 ty + ry, kx = 2 tx + rx (taps >= K of a 3x3 layer do not exist: those sums are dropped)
-__global__ void wgrad_reduce_s2d_kernel(const float* __restrict__ partial, int P, int M, int C, int K,
-                                        float* __restrict__ dw) {
-    const long long n = (long long)M * C * K * K, nq = (long long)M * C * 16;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int kx = (int)(i % K), ky = (int)((i / K) % K);
-        const long long mc = i / (K * K);
-        const int c = (int)(mc % C);
-        const long long m = mc / C;
-        const long long q = (m * 4 * C + (long long)((ky & 1) * 2 + (kx & 1)) * C + c) * 4 + (ky >> 1) * 2 + (kx >> 1);
-        float s = 0.f;
-        for (int k = 0; k < P; ++k) s += partial[(long long)k * nq + q];
-        dw[i] = s;
-    }
-}
-
 // dW[i] = sum_s partial[s][i]   (fixed order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, long long n, float* __restrict__ dw) {
     if ((n & 3) == 0) {
