@@ -23,6 +23,6 @@ inline int check_launch(const char* what) {
     return AP_OK;
 }
 // InstanceNorm statistics: planes with mean^2 > ratio * var (as estimated from the conv epilogue's fp32 sums) are
-// recomputed from the data (instnorm.hip: instnorm_refine_kernel, conv_bf16x3.h: norm_split_kernel)
+// recomputed from the data (instnorm.hip: instnorm_finalize_kernel, conv_bf16x3.h: norm_split_kernel)
 constexpr float kInstNormRefineRatio = 32.f;
 }  // namespace apamd

@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
         }
         __syncthreads();
         // ill-conditioned planes (|mean| >> std: E[x^2] - E[x]^2 of fp32 sums is rounding noise there) are recomputed
-        // from the data with the shifted two-pass formula, as instnorm_refine_kernel does.  Every pixel block of the
+        // from the data with the shifted two-pass formula, as instnorm_finalize_kernel does.  Every pixel block of the
         // plane repeats the same deterministic sum (rare path: read amplification only for such planes).
         for (int c = 0; c < 8; ++c) {
             if (!s_bad[c]) continue;                           // block-uniform

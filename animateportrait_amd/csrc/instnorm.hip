@@ -6,68 +6,57 @@
 
 namespace apamd {
 
-// eight lanes per (n, c): combine the conv epilogue's per-tile (sum, sumsq) in fp64 (sums of fp32 values in fp64 are
-// exact here, so the 8-way grouping does not change the result; one thread per plane walked up to 128 tiles serially
-// and made this launch latency-bound: 12.8 -> ~3 us)
-__global__ void instnorm_finalize_kernel(const float* __restrict__ partials, int NC, int tiles, double inv_count,
-                                         float eps, float* __restrict__ mean, float* __restrict__ rstd) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    const int i = g >> 3, sub = g & 7;
-    double s = 0.0, q = 0.0;
-    if (i < NC) {
-        const float2* p = reinterpret_cast<const float2*>(partials) + (long long)i * tiles;
-        for (int t = sub; t < tiles; t += 8) {
-            const float2 v = p[t];
-            s += (double)v.x;
-            q += (double)v.y;
-        }
-    }
-#pragma unroll
-    for (int sh = 1; sh < 8; sh <<= 1) {
-        s += __shfl_xor(s, sh, 64);
-        q += __shfl_xor(q, sh, 64);
-    }
-    if (i >= NC || sub != 0) return;
-    const double m = s * inv_count;
-    double var = q * inv_count - m * m;   // biased variance, as F.instance_norm
-    var = var > 0.0 ? var : 0.0;
-    mean[i] = (float)m;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
+// One wave per (n, c) plane: the conv epilogue's per-tile (sum, sumsq) are combined in fp64 (sums of fp32 values in fp64
+// are exact here, so the lane grouping does not change the result).
+//
 // E[x^2] - E[x]^2 from fp32 tile sums loses log2(mean^2 / var) bits: a plane whose |mean| is many standard deviations
 // (a PatchGAN fed a mostly-white masked crop, base_model.py:245-247) would get a variance that is rounding noise,
-// hidden by the var > 0 clamp.  Planes with mean^2 > kRefineRatio * var are therefore recomputed from the data with
-// the shifted two-pass formula (shift = the first estimate of the mean, itself accurate): one workgroup per plane,
-// which exits at once for a well-conditioned plane.  The same rule is inlined in norm_split_kernel.
-__global__ __launch_bounds__(256) void instnorm_refine_kernel(const float* __restrict__ y, int HW, float eps,
-                                                              float* __restrict__ mean, float* __restrict__ rstd) {
-    __shared__ double red[2][4];
-    const int i = blockIdx.x;
-    const float m = mean[i], r = rstd[i];
-    const float var0 = 1.f / (r * r) - eps;
-    if (!(m * m > kInstNormRefineRatio * var0)) return;
-    const float* p = y + (long long)i * HW;
+// hidden by the var > 0 clamp.  When `y` is given, planes with mean^2 > kInstNormRefineRatio * var are therefore
+// recomputed from the data with the shifted two-pass formula (shift = the first estimate of the mean, itself
+// accurate) by the same wave -- a well-conditioned plane skips that loop.  The same rule is inlined in
+// norm_split_kernel.
+__global__ __launch_bounds__(64) void instnorm_finalize_kernel(const float* __restrict__ partials,
+                                                               const float* __restrict__ y, int tiles, int HW,
+                                                               float eps, float* __restrict__ mean,
+                                                               float* __restrict__ rstd) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const double inv_count = 1.0 / (double)HW;
     double s = 0.0, q = 0.0;
-    for (int k = threadIdx.x; k < HW; k += 256) {
-        const float d = p[k] - m;
-        s += (double)d;
-        q += (double)d * (double)d;
+    const float2* p = reinterpret_cast<const float2*>(partials) + (long long)i * tiles;
+    for (int t = lane; t < tiles; t += 64) {
+        const float2 v = p[t];
+        s += (double)v.x;
+        q += (double)v.y;
     }
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) {
         s += __shfl_xor(s, sh, 64);
         q += __shfl_xor(q, sh, 64);
     }
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const double S = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const double Q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        const double dm = S / (double)HW;
-        double var = Q / (double)HW - dm * dm;
+    double m = s * inv_count;
+    double var = q * inv_count - m * m;   // biased variance, as F.instance_norm
+    var = var > 0.0 ? var : 0.0;
+    if (y != nullptr && m * m > (double)kInstNormRefineRatio * var) {       // wave-uniform
+        const float m0 = (float)m;
+        const float* py = y + (long long)i * HW;
+        double ds = 0.0, dq = 0.0;
+        for (int k = lane; k < HW; k += 64) {
+            const float d = py[k] - m0;
+            ds += (double)d;
+            dq += (double)d * (double)d;
+        }
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) {
+            ds += __shfl_xor(ds, sh, 64);
+            dq += __shfl_xor(dq, sh, 64);
+        }
+        const double dm = ds * inv_count;
+        var = dq * inv_count - dm * dm;
         var = var > 0.0 ? var : 0.0;
-        mean[i] = (float)((double)m + dm);
+        m = (double)m0 + dm;
+    }
+    if (lane == 0) {
+        mean[i] = (float)m;
         rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
     }
 }
@@ -119,10 +108,8 @@ int ap_instnorm_finalize(const float* stat_partials, const float* y, int32_t NC,
                          float* mean, float* rstd, ap_stream_t stream) {
     if (!stat_partials || !mean || !rstd) return fail(AP_ERR_INVALID, "instnorm_finalize: null pointer");
     if (NC < 1 || tiles < 1 || count < 1) return fail(AP_ERR_INVALID, "instnorm_finalize: bad sizes");
-    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((NC * 8 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       stat_partials, NC, tiles, 1.0 / (double)count, eps, mean, rstd);
-    if (y != nullptr)     // ill-conditioned planes (|mean| >> std) are recomputed from the data
-        hipLaunchKernelGGL(instnorm_refine_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, y, count, eps, mean, rstd);
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(NC), dim3(64), 0, (hipStream_t)stream, stat_partials, y, tiles, count,
+                       eps, mean, rstd);
     return check_launch("instnorm_finalize_kernel");
 }
 
