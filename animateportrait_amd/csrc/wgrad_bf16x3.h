@@ -399,4 +399,62 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
     }
 }
 
+// Fast path of split_transpose_kernel for an unpadded operand whose rows are whole octet rows (pad == 0, X8 * 8 == W:
+// the gradient operand of every 64 / 128 / 256-pixel-wide layer): a workgroup converts 32 consecutive octets = 256
+// consecutive pixels of 64 channels.  Loads are 16 bytes per lane and 1 KiB contiguous per wave (the general kernel
+// reads 256-byte runs from 16 planes per thread: 2.6 TB/s); stores are the same 1 KiB slot rows.
+// grid: (ceil(Hp * X8 / 32), Cp / 64, N)
+__global__ __launch_bounds__(256) void split_transpose_vec_kernel(const SplitTParams p) {
+    extern __shared__ float fv[];                    // [64][257]
+    constexpr int LP = 257;
+    const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int HW = p.H * p.W, noct = p.Hp * p.X8;
+    const int oct0 = blockIdx.x * 32;
+    const SrcSeg sg = p.seg[0];
+    {
+        const int oct = oct0 + (lane >> 1);
+        const int y = oct / p.X8, x = (oct - y * p.X8) * 8 + (lane & 1) * 4;
+        const bool ok = oct < noct && y < p.H;       // (x < W by construction: X8 * 8 == W)
+        const long long soff = (long long)y * p.W + x;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cl = i * 4 + wave, c = cg * 64 + cl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && c < p.C) {
+                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + c) * HW + soff);
+                if (sg.mean != nullptr) {
+                    const float m = sg.mean[n * sg.C + c], r = sg.rstd[n * sg.C + c];
+                    v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+                }
+                if (sg.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (sg.act == 2) {
+                    v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+                }
+            }
+            float* d = fv + cl * LP + lane * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    }
+    __syncthreads();
+    const int c = lane;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int o = wave + 4 * k, oct = oct0 + o;
+        if (oct < noct) {
+            bf16x8 hv, lv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 h, l;
+                split_bf16(fv[c * LP + o * 8 + j], h, l);
+                hv[j] = h;
+                lv[j] = l;
+            }
+            *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * noct + oct) * p.Cp + cg * 64 + c) = hv;
+            if (!p.heads_only) *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cg * 64 + c) = lv;
+        }
+    }
+}
+
 }  // namespace apamd

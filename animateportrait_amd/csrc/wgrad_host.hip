@@ -244,6 +244,19 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     p.s2d_c = s2d_c;
     p.heads_only = heads_only;
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
+    if (nseg == 1 && pad == 0 && s2d_c == 0 && X8 * 8 == W && !getenv("APAMD_NO_SPLIT_VEC")) {
+        // unpadded operand with whole octet rows: 16-byte loads, 1 KiB per wave (split_transpose_vec_kernel)
+        static bool attr = false;
+        const size_t lds = 64 * 257 * sizeof(float);
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&split_transpose_vec_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
+        hipLaunchKernelGGL(split_transpose_vec_kernel, dim3((Hp * X8 + 31) / 32, Cp / 64, N), dim3(256), lds, stream, p);
+        return check_launch("split_transpose_vec_kernel");
+    }
     hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
     return check_launch("split_transpose_kernel");
 }
