@@ -48,7 +48,21 @@ class BaseModel(ABC):
         # one process per GPU: every rank built (and randomly initialised) its own replica; start all of them from
         # rank 0's weights, as the reference's single replicated nn.DataParallel module does (networks.py:115-118)
         parallel.broadcast_model(self)
+        self.attach_flow_network()
         self.print_networks(opt.verbose)
+
+    FLOW_CHECKPOINT_DIR = 'checkpoints'
+
+    def attach_flow_network(self, model_id='FlowReg_id_flow_faces', epoch='best'):
+        """The frozen intrinsic-flow regressor (``self.netF = load_flow_network()``, geomgm_ifw_fore_model.py:57-68,
+        :386 / geomcgt_ifw_test_model.py:50-61, :214) when its checkpoint directory is present; without it the models
+        read iw_flow / if_mask from the batch."""
+        aux = getattr(self, 'aux', None)
+        if aux is None or 'netF' not in aux or aux['netF'] is not None:
+            return
+        if os.path.exists(os.path.join(self.FLOW_CHECKPOINT_DIR, model_id, 'train_opt.json')):
+            from ..flow_unet import load_flow_network
+            aux['netF'] = load_flow_network(model_id, epoch, self.FLOW_CHECKPOINT_DIR, self.device)
 
     def eval(self):
         for name in self.model_names:

@@ -210,6 +210,34 @@ def test_kp_to_map_and_flow_post_vs_reference_golden(dev, golden):
     assert linf(wf2, ref_f) < 2e-5 and linf(rm2, ref_m) < 1e-6
 
 
+def test_flow_network_warp_with_the_flowunet_mirror(dev):
+    """The FlowUnet_v2 mirror (flow_unet.py, pinned on the CPU by test_flow_unet_cpu.py) on the device behind the device
+    pre / post stages == the oracle's flow_network_warp around the same module on the CPU."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    from make_flowunet_golden import CONFIG
+    from make_module1_golden import seeded_state
+    from animateportrait_amd import flow_unet, losses
+    from oracle import aux_glue as oa
+    net = flow_unet.FlowUnetV2(**CONFIG)
+    net.load_state_dict(seeded_state([(k, tuple(v.shape), str(v.dtype)) for k, v in net.state_dict().items()], seed=55))
+    net.eval()
+    g = torch.Generator().manual_seed(12)
+    lm1 = torch.rand(2, 68, 2, generator=g) * 200 + 28
+    lm2 = lm1 + torch.randn(2, 68, 2, generator=g) * 3
+    want_f, want_m = oa.flow_network_warp(net, torch.zeros(2, 3, 256, 256), lm1, lm2)
+    import copy
+    wf, rm = losses.flow_network_warp(copy.deepcopy(net).to(dev), torch.zeros(2, 3, 256, 256, device=dev), lm1, lm2)
+    assert wf.shape == (2, 2, 256, 256) and rm.shape == (2, 1, 256, 256)
+    tie = float((rm.cpu() - want_m).abs().gt(1e-6).float().mean())          # visibility argmax ties flip mask pixels
+    assert tie < 2e-3
+    if tie == 0.0:
+        assert linf(wf, want_f) < 1e-3 * max(1.0, float(want_f.abs().max()))
+    else:
+        assert float((wf.cpu() - want_f).abs().gt(1e-3 * max(1.0, float(want_f.abs().max()))).float().mean()) < 4e-3
+
+
 def test_landmark_discs_vs_oracle_rule(dev):
     """ap_landmark_discs == the oracle's draw2(op=0) (OpenCV's filled-circle rows; cv2 itself is absent: unpinned)."""
     from animateportrait_amd import losses
