@@ -1,4 +1,6 @@
 """GPU (-m gpu): train-step pieces (TPS warp, Adam, full G/D step) against goldens and the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -79,9 +81,10 @@ def _relerr(a, b64):
     return float((a.detach().cpu().double() - b64).abs().max() / b64.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize('precision', ['bf16x3', 'fp32'])
-def test_train_step_losses_and_grads_vs_oracle(dev, precision, monkeypatch):
-    """One G step and one D step of the drawing configuration (ngf=ndf=8, B=2) WITH the geometry and identity
+@pytest.mark.parametrize('precision,width,nb', [('bf16x3', 8, 2), ('fp32', 8, 2), ('bf16x3', 64, 1), ('fp32', 64, 1)])
+def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkeypatch):
+    """One G step and one D step of the drawing configuration (ngf=ndf=8, B=2; and at the FULL width of BASELINE
+    configs[2], ngf=ndf=64, B=1 -- the CPU oracle's fp64 pass takes ~30 s there) WITH the geometry and identity
     branches (stand-in landmark / face nets): every loss term, and every gradient tensor
     ELEMENTWISE, against the CPU oracle composition evaluated in fp64.  Bar per tensor: as close to the fp64 truth as
     the oracle's own fp32 evaluation is (x3), which is how the reference itself would fare -- weight gradients behind
@@ -101,20 +104,20 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, monkeypatch):
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
     from oracle import generator as og, discriminator as od, train_step as ts
     torch.manual_seed(0)
-    model, opt = _make_model(dev)
-    sdG = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=11)
+    model, opt = _make_model(dev, width, width)
+    sdG = og.init_params(og.generator_param_shapes(3, 1, width, 9, 3, 3), seed=11)
     model.netG_A.load_state_dict(sdG, strict=True)
     sdD = {}
     dnames = ['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']
     for i, name in enumerate(dnames):
-        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, 8), seed=20 + i)
+        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, width), seed=20 + i)
         getattr(model, 'net' + name).load_state_dict(sdD[name], strict=True)
     model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
     model.aux['faceloss'] = N.FaceLoss(standins.StandinFaceNet().to(dev))
-    batch = make_train_batch(2, seed=5)
-    batch['winB'] = torch.tensor([[32, 224, 32, 224], [-12, 200, 24, 230]])        # one window leaves the frame
-    batch['winB2'] = torch.tensor([[30, 226, 28, 220], [40, 260, 50, 256]])
-    batch['winA'] = torch.tensor([[36, 220, 30, 210], [20, 230, 20, 228]])
+    batch = make_train_batch(nb, seed=5)
+    batch['winB'] = torch.tensor([[32, 224, 32, 224], [-12, 200, 24, 230]])[-nb:]  # one window leaves the frame
+    batch['winB2'] = torch.tensor([[30, 226, 28, 220], [40, 260, 50, 256]])[-nb:]
+    batch['winA'] = torch.tensor([[36, 220, 30, 210], [20, 230, 20, 228]])[-nb:]
     # ---------------- product
     model.set_input(batch)
     model.forward()
@@ -168,7 +171,20 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, monkeypatch):
         a, t = float(getattr(model, 'loss_' + name)), float(r64['dl'][name])
         assert abs(a - t) <= 1e-3 * abs(t) + 1e-6, (name, a, t)
     # ---------------- gradients, elementwise, every tensor
-    bad = []
+    bad, all_ = [], []
+    # Full width: 40 M activations sit in front of a (leaky) ReLU, so a handful of them are within rounding of zero
+    # and take the other branch in ANY two evaluations (the oracle's own fp32 pass against its fp64 pass shows ~1e-2
+    # L-inf on the generator for that reason; measured on D_A_coh: one flipped pixel in one 31x31 plane moves that
+    # output channel's weight-gradient row by 3e-2 of the tensor maximum, every other row by 2e-6, and the layers below
+    # it by a diffuse 5e-4).  The L-inf bar gets a flip allowance there; the per-output-channel MEDIAN of the row errors
+    # (insensitive to the directly hit rows) gets half of it.
+    flip = 2e-2 if width == 64 else 0.0
+
+    def rowmed(a, b64):
+        if a.dim() < 2:
+            return _relerr(a, b64)
+        d = (a.detach().cpu().double() - b64.double()).abs().flatten(1).amax(1)
+        return float(d.median() / b64.double().abs().max().clamp_min(1e-30))
 
     def check(tag, k, mine, g32, g64):
         if float(g64.abs().max()) < 1e-12 or (k.endswith('.bias') and float(mine.abs().max()) == 0.0):
@@ -176,13 +192,18 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, monkeypatch):
             assert float(g64.abs().max()) < 1e-6 * max(1.0, float(r64['gG']['model_tri_merge.weight'].abs().max())), (tag, k)
             return
         e, noise = _relerr(mine, g64), _relerr(g32, g64)
-        if e > 3.0 * noise + (floor if tag == 'G' else floor_d):
-            bad.append((tag, k, e, noise))
+        me, mnoise = rowmed(mine, g64), rowmed(g32, g64)
+        all_.append((tag, k, round(e, 6), round(noise, 6), round(me, 6), round(mnoise, 6)))
+        fl = floor if tag == 'G' else floor_d
+        if e > 3.0 * noise + fl + flip or me > 3.0 * mnoise + fl + 0.5 * flip:
+            bad.append((tag, k, e, noise, me, mnoise))
     for k in sdG:
         check('G', k, gG[k], r32['gG'][k], r64['gG'][k])
     for n in dnames:
         for k in sdD[n]:
             check(n, k, gD[n][k], r32['gD'][n][k], r64['gD'][n][k])
+    if os.environ.get('APAMD_TEST_DUMP'):
+        open(os.environ['APAMD_TEST_DUMP'], 'a').write('%s %d %r\n' % (precision, width, all_)) 
     assert not bad, bad
 
 
