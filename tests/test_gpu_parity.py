@@ -532,6 +532,19 @@ def test_warp_backward(dev):
         gx = ops.warp_concat_bwd(up.to(dev), d['motion'].to(dev), d['flow'].to(dev), d['ifmask'].to(dev), level)
         diff = (gx.cpu() - x.grad).abs()
         assert float((diff > 1e-3).float().mean()) < 1e-4 and float(diff.mean()) < 1e-5
+    # the accumulation's corner cases: a strongly compressing map (hundreds of pixels of a tile hit the same window
+    # element: same-instruction conflicts, claim losers), a magnifying one (the window does not fit: direct scatter),
+    # and every pixel sampling ONE point
+    for name, scale in (('compress', 0.06), ('magnify', 3.0), ('point', 0.0)):
+        motion = (d['motion'] * scale).contiguous()
+        x = torch.randn(2, 10, 64, 64, generator=torch.Generator().manual_seed(3), dtype=torch.float64).requires_grad_(True)
+        y = ow.double_feature_warping(x, motion.double(), d['flow'].double(), d['ifmask'].double(), 2)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(8), dtype=torch.float64)
+        (y * up).sum().backward()
+        gx = ops.warp_concat_bwd(up.float().to(dev), motion.to(dev), d['flow'].to(dev), d['ifmask'].to(dev), 2)
+        ref = x.grad
+        # (fp32 sampling coordinates against the fp64 evaluation: 1e-4 of the maximum under 3x magnification)
+        assert float((gx.cpu().double() - ref).abs().max()) < 2e-4 * float(ref.abs().max()), name
 
 
 def test_generator_ngf8_grads(dev, golden):

@@ -3,6 +3,7 @@
 under profiles/.
 
   python tools/rocpd_summary.py stats  <db> <out.md>          # --kernel-trace --stats run
+  python tools/rocpd_summary.py bygrid <db> <out.md> [name-substring]   # per launch shape
   python tools/rocpd_summary.py pmc    <db> <out.md> [json]   # --pmc run: per-kernel counter averages
 
 For FETCH_SIZE / WRITE_SIZE the per-launch HBM bytes are also written (KiB -> bytes; FETCH_SIZE doubled
@@ -29,6 +30,28 @@ def stats(db, out):
     print(open(out).read())
 
 
+def bygrid(db, out, pattern):
+    """Per launch shape: the `kernels` view of a --kernel-trace database grouped by (name, grid, workgroup)."""
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute('pragma table_info(kernels)')]
+    if not cols:
+        print('views:', [r[0] for r in c.execute("select name from sqlite_master where type in ('view','table')")])
+        return
+    gx = [k for k in ('grid_x', 'grid_size_x', 'grid_size') if k in cols][0]
+    gy = [k for k in ('grid_y', 'grid_size_y') if k in cols]
+    gz = [k for k in ('grid_z', 'grid_size_z') if k in cols]
+    dur = 'duration' if 'duration' in cols else '(end - start)'
+    grid = ', '.join([gx] + gy + gz)
+    q = ('select name, %s, count(*), avg(%s), sum(%s) from kernels where name like ? group by name, %s '
+         'order by sum(%s) desc' % (grid, dur, dur, grid, dur))
+    with open(out, 'w') as f:
+        f.write('| kernel | grid | launches | avg us | total us |\n|---|---|---|---|---|\n')
+        for row in c.execute(q, ('%' + pattern + '%',)):
+            n, g, (cnt, avg, tot) = row[0], row[1:-3], row[-3:]
+            f.write('| `%s` | %s | %d | %.1f | %.1f |\n' % (short(n)[:60], 'x'.join(str(v) for v in g), cnt, avg / 1e3, tot / 1e3))
+    print(open(out).read())
+
+
 def pmc(db, out, js=None):
     c = sqlite3.connect(db)
     q = ('select kernel_name, counter_name, count(*), avg(value), avg(duration), max(grid_size) from counters_collection '
@@ -49,5 +72,7 @@ if __name__ == '__main__':
     mode = sys.argv[1]
     if mode == 'stats':
         stats(sys.argv[2], sys.argv[3])
+    elif mode == 'bygrid':
+        bygrid(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else '')
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
