@@ -457,4 +457,147 @@ __global__ __launch_bounds__(256) void split_transpose_vec_kernel(const SplitTPa
     }
 }
 
+// Row forms of split_transpose_kernel: a workgroup converts whole padded rows of 64 channels, so that every source row
+// is read with 16-byte loads (1 KiB contiguous per wave in the interior) instead of 256-byte runs of 4-byte loads.
+//
+// (1) pad == 1 (reflection or zero), W in {32, 64, 128, 256}: R = 256 / W padded rows per workgroup; one wave-load
+//     covers the R rows of one channel; the two border columns and the zero slots up to the octet boundary are written
+//     by the lanes that hold the neighbouring values.            grid: (ceil(Hp / R), Cp / 64, N)
+__device__ __forceinline__ float4 norm_act4(float4 v, const SrcSeg& sg, int nc) {
+    if (sg.mean != nullptr) {
+        const float m = sg.mean[nc], r = sg.rstd[nc];
+        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+    }
+    if (sg.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (sg.act == 2) {
+        v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+        v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void split_store_octets(const SplitTParams& p, const float* fv, int LP, int n, int cg, int oct0,
+                                                   int nocts_tile, int wave, int lane) {
+    const int noct = p.Hp * p.X8;
+    for (int o = wave; o < nocts_tile; o += 4) {
+        const int oct = oct0 + o;
+        if (oct >= noct) break;
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 h, l;
+            split_bf16(fv[lane * LP + o * 8 + j], h, l);
+            hv[j] = h;
+            lv[j] = l;
+        }
+        *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * noct + oct) * p.Cp + cg * 64 + lane) = hv;
+        if (!p.heads_only) *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cg * 64 + lane) = lv;
+    }
+}
+
+__global__ __launch_bounds__(256) void split_transpose_pad_kernel(const SplitTParams p) {
+    extern __shared__ float fv[];                    // [64][R * X8 * 8 + 1]
+    const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int LPR = p.W >> 2, R = 64 / LPR;          // lanes per row, rows per workgroup
+    const int RS = p.X8 * 8, LP = R * RS + 1;        // slots per padded row, LDS row pitch
+    const int He = p.H + 2, HW = p.H * p.W;
+    const int y0 = blockIdx.x * R;
+    {
+        const int r = lane / LPR, xl = (lane - r * LPR) * 4;
+        const int y = y0 + r;
+        int sy = y - 1;
+        bool ok = y < He;
+        if (p.pad_mode == 1) sy = reflect_clamp(sy, p.H);
+        else ok = ok && sy >= 0 && sy < p.H;
+        const long long soff = ok ? (long long)sy * p.W + xl : 0;
+        const bool refl = p.pad_mode == 1 && ok;
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int cl = i * 4 + wave, c = cg * 64 + cl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && c < p.C) {
+                int sgi = 0;
+                if (p.nseg > 1 && c >= p.seg[1].chunk_begin) sgi = 1;
+                if (p.nseg > 2 && c >= p.seg[2].chunk_begin) sgi = 2;
+                const SrcSeg sg = sgi == 0 ? p.seg[0] : (sgi == 1 ? p.seg[1] : p.seg[2]);   // wave-uniform
+                const int cs = c - sg.chunk_begin;
+                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + cs) * HW + soff);
+                v = norm_act4(v, sg, n * sg.C + cs);
+            }
+            float* d = fv + cl * LP + r * RS;
+            d[1 + xl] = v.x; d[2 + xl] = v.y; d[3 + xl] = v.z; d[4 + xl] = v.w;
+            if (xl == 0) d[0] = refl ? v.y : 0.f;                        // padded column 0 <- source column 1
+            if (xl == p.W - 4) {
+                d[p.W + 1] = refl ? v.z : 0.f;                           // padded column W + 1 <- source column W - 2
+                for (int z = p.W + 2; z < RS; ++z) d[z] = 0.f;           // the slots up to the octet boundary
+            }
+        }
+    }
+    __syncthreads();
+    split_store_octets(p, fv, LP, n, cg, y0 * p.X8, R * p.X8, wave, lane);
+}
+
+// (2) the space-to-depth view (s2d_c = C0, C0 % 32 == 0, source W0 in {64, 128, 256}): a workgroup reads R = 256 / W0
+//     source rows of equal parity of 32 source channels -- whole rows, every element used -- and writes both column
+//     parities rx = 0, 1: view channels (ry * 2 + rx) * C0 + c of view rows y = (sy + 1 - ry) / 2.  The 64 LDS rows are
+//     [rx][32 channels]; a wave-store is two 512-byte runs.
+//     grid: (ceil(Hv / R) * 2 [ry], C0 / 32, N), Hv = H0 / 2 + 1 view rows (the operand has Hp >= Hv rows: the rest is
+//     zero-filled by the workgroups of the last row group)
+__global__ __launch_bounds__(256) void split_transpose_s2d_kernel(const SplitTParams p) {
+    extern __shared__ float fv[];                    // [2 * 32][R * X8 * 8 + 1]
+    const int n = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int C0 = p.s2d_c;
+    const int LPR = p.W >> 2, R = 64 / LPR;
+    const int RS = p.X8 * 8, LP = R * RS + 1;
+    const int Hv = p.H / 2 + 1, Wv = p.W / 2 + 1, HW = p.H * p.W;
+    const int ry = blockIdx.x & 1, y0 = (blockIdx.x >> 1) * R;
+    const int cb = blockIdx.y * 32;
+    const SrcSeg sg = p.seg[0];
+    {
+        const int r = lane / LPR, l = lane - r * LPR, xl = l * 4;
+        const int y = y0 + r, sy = 2 * y + ry - 1;
+        const bool ok = y < Hv && sy >= 0 && sy < p.H;
+        const long long soff = ok ? (long long)sy * p.W + xl : 0;
+#pragma unroll 4
+        for (int i = 0; i < 8; ++i) {
+            const int cl = i * 4 + wave, c = cb + cl;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + c) * HW + soff);
+                v = norm_act4(v, sg, n * sg.C + c);
+            }
+            // rx = 0: view column x <- source column 2x - 1 (odd columns; x = 0 is the zero border)
+            float* d0 = fv + cl * LP + r * RS;
+            d0[2 * l + 1] = v.y; d0[2 * l + 2] = v.w;
+            // rx = 1: view column x <- source column 2x (even columns; x = W0 / 2 is the zero border)
+            float* d1 = fv + (32 + cl) * LP + r * RS;
+            d1[2 * l] = v.x; d1[2 * l + 1] = v.z;
+            if (l == 0) d0[0] = 0.f;
+            if (l == LPR - 1) {
+                d1[Wv - 1] = 0.f;
+                for (int z = Wv; z < RS; ++z) { d0[z] = 0.f; d1[z] = 0.f; }
+            }
+        }
+    }
+    __syncthreads();
+    // thread = (rx, channel) of the 64 LDS rows; view channel (ry * 2 + rx) * C0 + cb + c
+    const int noct = p.Hp * p.X8;
+    const int rx = lane >> 5, c = lane & 31;
+    const long long cofs = (long long)(ry * 2 + rx) * C0 + cb + c;
+    for (int o = wave; o < R * p.X8; o += 4) {
+        const int oct = y0 * p.X8 + o;
+        if (oct >= noct) break;
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __bf16 h, l2;
+            split_bf16(fv[lane * LP + o * 8 + j], h, l2);
+            hv[j] = h;
+            lv[j] = l2;
+        }
+        *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 0) * noct + oct) * p.Cp + cofs) = hv;
+        if (!p.heads_only) *reinterpret_cast<bf16x8*>(p.out + ((long long)(n * 2 + 1) * noct + oct) * p.Cp + cofs) = lv;
+    }
+}
+
 }  // namespace apamd

@@ -229,6 +229,18 @@ static int launch_pad(const ap_src* segs, int nseg, int N, int C, int H, int W, 
     return check_launch("pad_materialize_kernel");
 }
 
+// raises a kernel's dynamic-LDS limit once per process
+static int set_dyn_lds(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::vector<const void*> done;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const void* f : done) if (f == fn) return AP_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    done.push_back(fn);
+    return AP_OK;
+}
+
 static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode,
                                   int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c, int heads_only) {
     SplitTParams p;
@@ -256,6 +268,25 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         }
         hipLaunchKernelGGL(split_transpose_vec_kernel, dim3((Hp * X8 + 31) / 32, Cp / 64, N), dim3(256), lds, stream, p);
         return check_launch("split_transpose_vec_kernel");
+    }
+    const bool rows_ok = !getenv("APAMD_NO_SPLIT_ROWS") && (W == 64 || W == 128 || W == 256 || (W == 32 && s2d_c == 0));
+    if (rows_ok && s2d_c == 0 && pad == 1) {
+        // padded rows, 16-byte loads (split_transpose_pad_kernel)
+        const int R = 256 / W;
+        const size_t lds = (size_t)64 * (R * X8 * 8 + 1) * sizeof(float);
+        int rc = set_dyn_lds(reinterpret_cast<const void*>(&split_transpose_pad_kernel), 96 * 1024);
+        if (rc != AP_OK) return rc;
+        hipLaunchKernelGGL(split_transpose_pad_kernel, dim3((Hp + R - 1) / R, Cp / 64, N), dim3(256), lds, stream, p);
+        return check_launch("split_transpose_pad_kernel");
+    }
+    if (rows_ok && s2d_c > 0 && s2d_c % 32 == 0 && nseg == 1 && C == 4 * s2d_c && Cp == C) {
+        // space-to-depth view, whole source rows (split_transpose_s2d_kernel)
+        const int R = 256 / W;
+        const size_t lds = (size_t)64 * (R * X8 * 8 + 1) * sizeof(float);
+        int rc = set_dyn_lds(reinterpret_cast<const void*>(&split_transpose_s2d_kernel), 96 * 1024);
+        if (rc != AP_OK) return rc;
+        hipLaunchKernelGGL(split_transpose_s2d_kernel, dim3(((Hp + R - 1) / R) * 2, s2d_c / 32, N), dim3(256), lds, stream, p);
+        return check_launch("split_transpose_s2d_kernel");
     }
     hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
     return check_launch("split_transpose_kernel");

@@ -31,6 +31,10 @@ CASES = [
     ('down 3x3 s2', [64], 128, 3, 2, 1, 'zero', False, 64, 64),
     ('patchgan 4x4 s1', [64], 96, 4, 1, 1, 'zero', False, 32, 32),
     ('patchgan 4x4 s2 (space-to-depth)', [64], 128, 4, 2, 1, 'zero', False, 64, 48),
+    ('res3x3 reflect, 128-wide rows', [64], 64, 3, 1, 1, 'reflect', False, 32, 128),
+    ('res3x3 zero, 256-wide rows, 2 segments', [16, 16], 48, 3, 1, 1, 'zero', False, 16, 256),
+    ('down 3x3 s2, 128-wide rows', [64], 64, 3, 2, 1, 'zero', False, 32, 128),
+    ('patchgan 4x4 s2, 256-wide rows', [64], 64, 4, 2, 1, 'zero', False, 16, 256),
     ('stem 7x7 (row form)', [3], 64, 7, 1, 3, 'reflect', False, 40, 70),
     ('up 3x3 s2 transposed (fused phases)', [64], 64, 3, 2, 1, 'zero', True, 32, 32),
 ]

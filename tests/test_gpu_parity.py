@@ -491,6 +491,9 @@ def test_conv_backward_vs_autograd(dev, case, norm):
     ([256], 256, 3, 1, 'reflect', 64, 64, 2),
     ([64], 128, 4, 1, 'zero', 32, 32, 2),               # PatchGAN 4x4 stride 1 (output 31 x 31)
     ([40], 48, 3, 1, 'zero', 40, 40, 1),                # channel counts that are not multiples of 64
+    ([40, 24, 8], 80, 3, 1, 'zero', 19, 64, 2),         # padded-row operand kernel: 3 segments, odd rows, partial group
+    ([32], 64, 3, 1, 'reflect', 10, 128, 1),            # ... two rows per workgroup
+    ([32], 48, 3, 1, 'reflect', 5, 256, 1),             # ... one row per workgroup
 ])
 def test_wgrad_bf16x3(dev, case):
     """Weight gradient on the bf16 matrix pipe (split operands) against the fp64 gradient, beside the exact-fp32
