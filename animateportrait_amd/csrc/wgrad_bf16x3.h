@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
             ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
         }
         const int soff = ok ? sy * p.W + sx : 0;
-        const int cq = (tid >> 6) * 16;                            // this thread's 16 channels of the group
+        const int cq = __builtin_amdgcn_readfirstlane(tid >> 6) * 16;   // this wave's 16 channels of the group (scalar: see split_transpose_pad_kernel)
         float v[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -399,6 +399,19 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
     }
 }
 
+__device__ __forceinline__ float4 norm_act4(float4 v, const SrcSeg& sg, int nc) {
+    if (sg.mean != nullptr) {
+        const float m = sg.mean[nc], r = sg.rstd[nc];
+        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+    }
+    if (sg.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    else if (sg.act == 2) {
+        v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
+        v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
+    }
+    return v;
+}
+
 // Fast path of split_transpose_kernel for an unpadded operand whose rows are whole octet rows (pad == 0, X8 * 8 == W:
 // the gradient operand of every 64 / 128 / 256-pixel-wide layer): a workgroup converts 32 consecutive octets = 256
 // consecutive pixels of 64 channels.  Loads are 16 bytes per lane and 1 KiB contiguous per wave (the general kernel
@@ -408,7 +421,7 @@ __global__ __launch_bounds__(256) void split_transpose_vec_kernel(const SplitTPa
     extern __shared__ float fv[];                    // [64][257]
     constexpr int LP = 257;
     const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int HW = p.H * p.W, noct = p.Hp * p.X8;
     const int oct0 = blockIdx.x * 32;
     const SrcSeg sg = p.seg[0];
@@ -417,22 +430,18 @@ __global__ __launch_bounds__(256) void split_transpose_vec_kernel(const SplitTPa
         const int y = oct / p.X8, x = (oct - y * p.X8) * 8 + (lane & 1) * 4;
         const bool ok = oct < noct && y < p.H;       // (x < W by construction: X8 * 8 == W)
         const long long soff = (long long)y * p.W + x;
-#pragma unroll 4
+        float4 vv[16];                               // all loads first (see split_transpose_pad_kernel)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = cg * 64 + i * 4 + wave;
+            vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok && c < p.C) vv[i] = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + c) * HW + soff);
+        }
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int cl = i * 4 + wave, c = cg * 64 + cl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && c < p.C) {
-                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + c) * HW + soff);
-                if (sg.mean != nullptr) {
-                    const float m = sg.mean[n * sg.C + c], r = sg.rstd[n * sg.C + c];
-                    v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
-                }
-                if (sg.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                else if (sg.act == 2) {
-                    v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-                    v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-                }
-            }
+            float4 v = vv[i];
+            if (ok && c < p.C) v = norm_act4(v, sg, n * sg.C + c);
             float* d = fv + cl * LP + lane * 4;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
@@ -463,19 +472,6 @@ __global__ __launch_bounds__(256) void split_transpose_vec_kernel(const SplitTPa
 // (1) pad == 1 (reflection or zero), W in {32, 64, 128, 256}: R = 256 / W padded rows per workgroup; one wave-load
 //     covers the R rows of one channel; the two border columns and the zero slots up to the octet boundary are written
 //     by the lanes that hold the neighbouring values.            grid: (ceil(Hp / R), Cp / 64, N)
-__device__ __forceinline__ float4 norm_act4(float4 v, const SrcSeg& sg, int nc) {
-    if (sg.mean != nullptr) {
-        const float m = sg.mean[nc], r = sg.rstd[nc];
-        v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
-    }
-    if (sg.act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    else if (sg.act == 2) {
-        v.x = v.x > 0.f ? v.x : 0.2f * v.x; v.y = v.y > 0.f ? v.y : 0.2f * v.y;
-        v.z = v.z > 0.f ? v.z : 0.2f * v.z; v.w = v.w > 0.f ? v.w : 0.2f * v.w;
-    }
-    return v;
-}
-
 __device__ __forceinline__ void split_store_octets(const SplitTParams& p, const float* fv, int LP, int n, int cg, int oct0,
                                                    int nocts_tile, int wave, int lane) {
     const int noct = p.Hp * p.X8;
@@ -497,7 +493,11 @@ __device__ __forceinline__ void split_store_octets(const SplitTParams& p, const 
 
 __global__ __launch_bounds__(256) void split_transpose_pad_kernel(const SplitTParams p) {
     extern __shared__ float fv[];                    // [64][R * X8 * 8 + 1]
-    const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (the wave index as a SCALAR: the channel a wave works on, its segment, base pointer and statistics then live in
+    // SGPRs; left in a VGPR the compiler fetches the selected SrcSeg with vector loads and every iteration becomes a
+    // chain of three dependent memory round trips)
+    const int cg = blockIdx.y, n = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int LPR = p.W >> 2, R = 64 / LPR;          // lanes per row, rows per workgroup
     const int RS = p.X8 * 8, LP = R * RS + 1;        // slots per padded row, LDS row pitch
     const int He = p.H + 2, HW = p.H * p.W;
@@ -511,26 +511,44 @@ __global__ __launch_bounds__(256) void split_transpose_pad_kernel(const SplitTPa
         else ok = ok && sy >= 0 && sy < p.H;
         const long long soff = ok ? (long long)sy * p.W + xl : 0;
         const bool refl = p.pad_mode == 1 && ok;
-#pragma unroll 4
+        // all 16 loads of the wave first (the compiler does not hoist them over the LDS stores on its own: one memory
+        // round trip per channel otherwise), then the arithmetic and the LDS writes
+        float4 v[16];
+#pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int cl = i * 4 + wave, c = cg * 64 + cl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && c < p.C) {
+            const int c = cg * 64 + i * 4 + wave;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < p.C) {
                 int sgi = 0;
                 if (p.nseg > 1 && c >= p.seg[1].chunk_begin) sgi = 1;
                 if (p.nseg > 2 && c >= p.seg[2].chunk_begin) sgi = 2;
-                const SrcSeg sg = sgi == 0 ? p.seg[0] : (sgi == 1 ? p.seg[1] : p.seg[2]);   // wave-uniform
-                const int cs = c - sg.chunk_begin;
-                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + cs) * HW + soff);
-                v = norm_act4(v, sg, n * sg.C + cs);
+                const float* base = (sgi == 0 ? p.seg[0].data : (sgi == 1 ? p.seg[1].data : p.seg[2].data));
+                const int sc = sgi == 0 ? p.seg[0].C : (sgi == 1 ? p.seg[1].C : p.seg[2].C);
+                const int cs = c - (sgi == 0 ? 0 : (sgi == 1 ? p.seg[1].chunk_begin : p.seg[2].chunk_begin));
+                if (ok) v[i] = *reinterpret_cast<const float4*>(base + ((long long)n * sc + cs) * HW + soff);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int cl = i * 4 + wave, c = cg * 64 + cl;
+            float4 w = v[i];
+            if (c < p.C && ok) {
+                int sgi = 0;
+                if (p.nseg > 1 && c >= p.seg[1].chunk_begin) sgi = 1;
+                if (p.nseg > 2 && c >= p.seg[2].chunk_begin) sgi = 2;
+                const SrcSeg sg = sgi == 0 ? p.seg[0] : (sgi == 1 ? p.seg[1] : p.seg[2]);   // wave-uniform, scalar
+                w = norm_act4(w, sg, n * sg.C + c - sg.chunk_begin);
             }
             float* d = fv + cl * LP + r * RS;
-            d[1 + xl] = v.x; d[2 + xl] = v.y; d[3 + xl] = v.z; d[4 + xl] = v.w;
-            if (xl == 0) d[0] = refl ? v.y : 0.f;                        // padded column 0 <- source column 1
-            if (xl == p.W - 4) {
-                d[p.W + 1] = refl ? v.z : 0.f;                           // padded column W + 1 <- source column W - 2
-                for (int z = p.W + 2; z < RS; ++z) d[z] = 0.f;           // the slots up to the octet boundary
-            }
+            d[1 + xl] = w.x; d[2 + xl] = w.y; d[3 + xl] = w.z; d[4 + xl] = w.w;
+            if (xl == 0) d[0] = refl ? w.y : 0.f;                        // padded column 0 <- source column 1
+            if (xl == p.W - 4) d[p.W + 1] = refl ? w.z : 0.f;            // padded column W + 1 <- source column W - 2
+        }
+        // the slots between the padded row's end and the octet boundary
+        const int rsh = __ffs(R) - 1;
+        for (int e = tid; e < 64 * R; e += 256) {
+            float* d = fv + (e >> rsh) * LP + (e & (R - 1)) * RS;
+            for (int z = p.W + 2; z < RS; ++z) d[z] = 0.f;
         }
     }
     __syncthreads();
@@ -545,7 +563,8 @@ __global__ __launch_bounds__(256) void split_transpose_pad_kernel(const SplitTPa
 //     zero-filled by the workgroups of the last row group)
 __global__ __launch_bounds__(256) void split_transpose_s2d_kernel(const SplitTParams p) {
     extern __shared__ float fv[];                    // [2 * 32][R * X8 * 8 + 1]
-    const int n = blockIdx.z, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C0 = p.s2d_c;
     const int LPR = p.W >> 2, R = 64 / LPR;
     const int RS = p.X8 * 8, LP = R * RS + 1;
@@ -558,14 +577,17 @@ __global__ __launch_bounds__(256) void split_transpose_s2d_kernel(const SplitTPa
         const int y = y0 + r, sy = 2 * y + ry - 1;
         const bool ok = y < Hv && sy >= 0 && sy < p.H;
         const long long soff = ok ? (long long)sy * p.W + xl : 0;
-#pragma unroll 4
+        float4 vv[8];                                // all loads first (see split_transpose_pad_kernel)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            vv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) vv[i] = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + cb + i * 4 + wave) * HW + soff);
+        }
+#pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int cl = i * 4 + wave, c = cb + cl;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(sg.data + ((long long)n * sg.C + c) * HW + soff);
-                v = norm_act4(v, sg, n * sg.C + c);
-            }
+            float4 v = vv[i];
+            if (ok) v = norm_act4(v, sg, n * sg.C + c);
             // rx = 0: view column x <- source column 2x - 1 (odd columns; x = 0 is the zero border)
             float* d0 = fv + cl * LP + r * RS;
             d0[2 * l + 1] = v.y; d0[2 * l + 2] = v.w;
