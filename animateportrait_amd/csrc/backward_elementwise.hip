@@ -231,6 +231,70 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_fused_kernel(const float* __r
     }
 }
 
+// The same for 256 x 256 planes (unfolded gradient, HW % 4 == 0, HW <= 65536): 1024 threads x 16 float4 groups.  The
+// activated gradient of the first 8 groups stays in registers, the other 8 are parked in LDS (128 KiB); the normalised
+// activation is recomputed from a second read of y, which the plane's first pass left in the memory-side cache --
+// 2 + (1 cached) reads + 1 write per element instead of the 4 + 1 of the reduce / apply pair.  grid: (N*C)
+__global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const float* __restrict__ g1,
+                                                                     const float* __restrict__ g2,
+                                                                     const float* __restrict__ y,
+                                                                     const float* __restrict__ mean,
+                                                                     const float* __restrict__ rstd, int act, int HW,
+                                                                     float* __restrict__ dy) {
+    extern __shared__ float4 park[];                 // [8][1024]
+    __shared__ float red[16];
+    const int nc = blockIdx.x, tid = threadIdx.x, Q = HW >> 2;
+    const float m = mean[nc], r = rstd[nc];
+    const float4* y4 = reinterpret_cast<const float4*>(y + (long long)nc * HW);
+    const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
+    const float4* gb = g2 ? reinterpret_cast<const float4*>(g2 + (long long)nc * HW) : nullptr;
+    float4* o4 = reinterpret_cast<float4*>(dy + (long long)nc * HW);
+    float4 keep[8];
+    float s1 = 0.f, s2 = 0.f;
+    auto take = [&](int k) -> float4 {
+        const int i = k * 1024 + tid;
+        float4 yv = make_float4(m, m, m, m), gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < Q) {
+            yv = y4[i];
+            gq = ga[i];
+            if (gb) { const float4 t = gb[i]; gq.x += t.x; gq.y += t.y; gq.z += t.z; gq.w += t.w; }
+        }
+        const float x0 = (yv.x - m) * r, x1 = (yv.y - m) * r, x2 = (yv.z - m) * r, x3 = (yv.w - m) * r;
+        gq.x *= act_grad_from_xhat(x0, act); gq.y *= act_grad_from_xhat(x1, act);
+        gq.z *= act_grad_from_xhat(x2, act); gq.w *= act_grad_from_xhat(x3, act);
+        s1 += (gq.x + gq.y) + (gq.z + gq.w);
+        s2 += (gq.x * x0 + gq.y * x1) + (gq.z * x2 + gq.w * x3);
+        return gq;
+    };
+    // (at most four groups' loads in flight: hoisted all at once they would take the registers `keep` needs)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        keep[k] = take(k);
+        if ((k & 3) == 3) asm volatile("" ::: "memory");
+    }
+#pragma unroll 4
+    for (int k = 8; k < 16; ++k) park[(k - 8) * 1024 + tid] = take(k);
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float inv = 1.f / (float)HW;
+    const float a1 = s1 * inv, a2 = s2 * inv;
+    auto put = [&](int k, float4 g) {
+        const int i = k * 1024 + tid;
+        if (i < Q) {
+            const float4 yv = y4[i];
+            o4[i] = make_float4(r * (g.x - a1 - (yv.x - m) * r * a2), r * (g.y - a1 - (yv.y - m) * r * a2),
+                                r * (g.z - a1 - (yv.z - m) * r * a2), r * (g.w - a1 - (yv.w - m) * r * a2));
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        put(k, keep[k]);
+        if ((k & 3) == 3) asm volatile("" ::: "memory");
+    }
+#pragma unroll 4
+    for (int k = 8; k < 16; ++k) put(k, park[(k - 8) * 1024 + tid]);
+}
+
 // dy = (fold(g1) + g2) * act'(out): act 1 relu / 2 lrelu (sign of the ACTIVATED output) / 3 tanh (1 - out^2)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g1, int p1, const float* __restrict__ g2,
                                                       const float* __restrict__ outv, int act, int H, int W,
@@ -343,6 +407,19 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
         hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1024, 16>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g1_pad,
                            g2, y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
+    }
+    if (fused_ok && H * W <= 65536 && g1_pad == 0 && (H * W) % 4 == 0) {
+        static bool attr = false;
+        const size_t lds = 8 * 1024 * sizeof(float4);
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr = true;
+        }
+        hipLaunchKernelGGL(instnorm_bwd_fused_big_kernel, dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g2, y, mean,
+                           rstd, act, H * W, dy);
+        return check_launch("instnorm_bwd_fused_big_kernel");
     }
     hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, y,
                        mean, rstd, act, H, W, sums_ws);

@@ -717,9 +717,15 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
     const int pix = (blockIdx.x * 256 + tid) * VEC;
     const bool live = pix < HW;
     if (VEC == 1 && !live) return;
-    float v[8][VEC];
+    // Every load of the thread is issued before the first store: x, res and y are not declared disjoint, so the compiler
+    // keeps a load behind any earlier store -- written channel by channel this loop was 16 serial memory round trips.
+    float v[8][VEC], rv[8][VEC];
+    float rm[8], rr[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[c][j] = rv[c][j] = 0.f;
+        rm[c] = 0.f; rr[c] = 1.f;
         if (!live) continue;
         const long long off = ((long long)n * C + cg * 8 + c) * HW + pix;
         if constexpr (VEC == 4) {
@@ -728,23 +734,27 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
         } else {
             v[c][0] = p.x[off];
         }
+        if (p.res != nullptr) {
+            if (p.res_mean != nullptr) { rm[c] = p.res_mean[n * C + cg * 8 + c]; rr[c] = p.res_rstd[n * C + cg * 8 + c]; }
+            if constexpr (VEC == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(p.res + off);
+                rv[c][0] = t.x; rv[c][1] = t.y; rv[c][2] = t.z; rv[c][3] = t.w;
+            } else {
+                rv[c][0] = p.res[off];
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (!live) continue;
+        const long long off = ((long long)n * C + cg * 8 + c) * HW + pix;
         const float m = normed ? s_m[c] : 0.f, r = normed ? s_r[c] : 1.f;
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             float t = normed ? (v[c][j] - m) * r : v[c][j];
             t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
+            if (p.res != nullptr) t += (rv[c][j] - rm[c]) * rr[c];
             v[c][j] = t;
-        }
-        if (p.res != nullptr) {
-            float rm = 0.f, rr = 1.f;
-            if (p.res_mean != nullptr) { rm = p.res_mean[n * C + cg * 8 + c]; rr = p.res_rstd[n * C + cg * 8 + c]; }
-            if constexpr (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(p.res + off);
-                v[c][0] += (t.x - rm) * rr; v[c][1] += (t.y - rm) * rr;
-                v[c][2] += (t.z - rm) * rr; v[c][3] += (t.w - rm) * rr;
-            } else {
-                v[c][0] += (p.res[off] - rm) * rr;
-            }
         }
         if (p.y != nullptr) {
             if constexpr (VEC == 4) *reinterpret_cast<float4*>(p.y + off) = make_float4(v[c][0], v[c][1], v[c][2], v[c][3]);

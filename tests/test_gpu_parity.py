@@ -522,6 +522,27 @@ def test_wgrad_bf16x3(dev, case):
     assert linf(got[ops.PRECISION_BF16X3], ref) < 5e-5 * scale, linf(got[ops.PRECISION_BF16X3], ref) / scale
 
 
+@pytest.mark.parametrize('shape,act,two', [((2, 5, 40, 36), 1, True), ((2, 3, 128, 128), 2, False),
+                                            ((1, 3, 256, 256), 1, True), ((1, 2, 200, 256), 0, False),
+                                            ((1, 2, 300, 300), 1, True)])
+def test_instnorm_backward_all_plane_sizes(dev, shape, act, two):
+    """ap_instnorm_bwd against autograd through act(instance_norm(y)): the register-resident kernels (planes up to
+    64^2 and 128^2), the 256^2 kernel that parks half of the plane in LDS, and the reduce / apply pair beyond."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + act)
+    y = (torch.randn(shape, generator=g, dtype=torch.float64) * 1.3 + 0.4).requires_grad_(True)
+    xh = F.instance_norm(y)
+    out = xh if act == 0 else (F.relu(xh) if act == 1 else F.leaky_relu(xh, 0.2))
+    ga, gb = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    (out * (ga.double() + (gb.double() if two else 0.0))).sum().backward()
+    yf = y.detach().float()
+    m = yf.double().mean((2, 3)).reshape(-1).float()
+    r = (1.0 / torch.sqrt(yf.double().var((2, 3), unbiased=False).reshape(-1) + 1e-5)).float()
+    f = ops.Feat(yf.to(dev), m.to(dev), r.to(dev), act)
+    dy = ops.instnorm_bwd([(ga.to(dev), 0)] + ([(gb.to(dev), 0)] if two else []), f)
+    assert linf(dy, y.grad) < 2e-5 * float(y.grad.abs().max())
+
+
 def test_warp_backward(dev):
     from animateportrait_amd import ops
     from animateportrait_amd.synthetic import make_generator_inputs
