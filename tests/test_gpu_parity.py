@@ -522,25 +522,50 @@ def test_wgrad_bf16x3(dev, case):
     assert linf(got[ops.PRECISION_BF16X3], ref) < 5e-5 * scale, linf(got[ops.PRECISION_BF16X3], ref) / scale
 
 
-@pytest.mark.parametrize('shape,act,two', [((2, 5, 40, 36), 1, True), ((2, 3, 128, 128), 2, False),
-                                            ((1, 3, 256, 256), 1, True), ((1, 2, 200, 256), 0, False),
-                                            ((1, 2, 300, 300), 1, True)])
-def test_instnorm_backward_all_plane_sizes(dev, shape, act, two):
-    """ap_instnorm_bwd against autograd through act(instance_norm(y)): the register-resident kernels (planes up to
-    64^2 and 128^2), the 256^2 kernel that parks half of the plane in LDS, and the reduce / apply pair beyond."""
+@pytest.mark.parametrize('shape,act,two,pad', [((2, 5, 40, 36), 1, True, 0), ((2, 3, 128, 128), 2, False, 0),
+                                                ((1, 3, 256, 256), 1, True, 0), ((1, 2, 200, 256), 0, False, 0),
+                                                ((1, 2, 300, 300), 1, True, 0), ((2, 3, 64, 64), 1, True, 1),
+                                                ((1, 2, 30, 30), 1, False, 1), ((1, 2, 128, 128), 2, True, 1),
+                                                ((1, 2, 256, 256), 1, True, 1)])
+def test_instnorm_backward_all_plane_sizes(dev, shape, act, two, pad):
+    """ap_instnorm_bwd against autograd through act(instance_norm(y)) [and ReflectionPad2d(1) when the incoming
+    gradient is a padded convolution's]: the register-resident kernels (planes up to 64^2 and 128^2; 16-byte-lane and
+    scalar fold readers), the 256^2 kernel that parks half of the plane in LDS, and the reduce / apply pair beyond."""
     from animateportrait_amd import ops
-    g = torch.Generator().manual_seed(sum(shape) + act)
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(sum(shape) + act + pad)
     y = (torch.randn(shape, generator=g, dtype=torch.float64) * 1.3 + 0.4).requires_grad_(True)
     xh = F.instance_norm(y)
     out = xh if act == 0 else (F.relu(xh) if act == 1 else F.leaky_relu(xh, 0.2))
-    ga, gb = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
-    (out * (ga.double() + (gb.double() if two else 0.0))).sum().backward()
+    ga, gb = torch.randn(n, c, h + 2 * pad, w + 2 * pad, generator=g), torch.randn(shape, generator=g)
+    outp = F.pad(out, (pad,) * 4, mode='reflect') if pad else out
+    ((outp * ga.double()).sum() + ((out * gb.double()).sum() if two else 0.0)).backward()
     yf = y.detach().float()
     m = yf.double().mean((2, 3)).reshape(-1).float()
     r = (1.0 / torch.sqrt(yf.double().var((2, 3), unbiased=False).reshape(-1) + 1e-5)).float()
     f = ops.Feat(yf.to(dev), m.to(dev), r.to(dev), act)
-    dy = ops.instnorm_bwd([(ga.to(dev), 0)] + ([(gb.to(dev), 0)] if two else []), f)
+    dy = ops.instnorm_bwd([(ga.to(dev), pad)] + ([(gb.to(dev), 0)] if two else []), f)
     assert linf(dy, y.grad) < 2e-5 * float(y.grad.abs().max())
+
+
+@pytest.mark.parametrize('shape,pad,act,two', [((2, 3, 64, 64), 1, 0, True), ((1, 2, 5, 8), 1, 2, True),
+                                                ((1, 2, 3, 4), 1, 1, False), ((2, 2, 9, 10), 1, 3, True),
+                                                ((1, 2, 12, 16), 3, 0, True), ((1, 3, 16, 16), 0, 2, True)])
+def test_act_bwd_fold_forms(dev, shape, pad, act, two):
+    """ap_act_bwd: dy = (fold(g1) + g2) * act'(out) against autograd through act(.) and ReflectionPad2d: the pad-1
+    16-byte-lane kernel (incl. H = 3 / W = 4, where both border terms land on one row / one lane group), the general
+    fold (pad 3, W % 4 != 0) and the unpadded form."""
+    from animateportrait_amd import ops
+    n, c, h, w = shape
+    g = torch.Generator().manual_seed(h * 100 + w + act)
+    pre = torch.randn(shape, generator=g, dtype=torch.float64).requires_grad_(True)
+    out = pre if act == 0 else (F.relu(pre) if act == 1 else (F.leaky_relu(pre, 0.2) if act == 2 else torch.tanh(pre)))
+    g1 = torch.randn(n, c, h + 2 * pad, w + 2 * pad, generator=g)
+    g2 = torch.randn(shape, generator=g)
+    padded = F.pad(out, (pad,) * 4, mode='reflect') if pad else out
+    ((padded * g1.double()).sum() + ((out * g2.double()).sum() if two else 0.0)).backward()
+    got = ops.act_bwd([(g1.to(dev), pad)] + ([(g2.to(dev), 0)] if two else []), out.detach().float().to(dev), act)
+    assert linf(got, pre.grad) < 1e-5 * float(pre.grad.abs().max())
 
 
 def test_warp_backward(dev):
