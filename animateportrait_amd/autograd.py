@@ -226,7 +226,7 @@ def _weights_stamp(params):
     """What the backward pass assumes unchanged since forward: it reads ``layer.weight`` live (the packed copies are
     rebuilt from it), so an optimiser step in between would silently give gradients of a different network, where
     torch.autograd raises its saved-tensor version error."""
-    return (ops.WEIGHTS_EPOCH, tuple(p._version for p in params))
+    return tuple(ops.weight_key(p) for p in params)
 
 
 class _NetFn(torch.autograd.Function):

@@ -56,7 +56,7 @@ class ConvLayer(nn.Module):
 
     def packed_dgrad(self, seg, spec, w):
         """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
-        key = (self.weight._version, self.weight.data_ptr(), ops.WEIGHTS_EPOCH)
+        key = ops.weight_key(self.weight)
         hit = self._packed_dgrad.get(seg)
         if hit is None or hit[0] != key:
             hit = (key, ops.pack_weights(spec, w() if callable(w) else w))     # callable: built on a miss only
@@ -65,7 +65,7 @@ class ConvLayer(nn.Module):
 
     def packed(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        key = ops.weight_key(w)
         if self._packed is None or self._packed_key != key:
             self._packed = ops.pack_weights(self.spec, w.detach())
             self._packed_key = key
@@ -99,7 +99,7 @@ class ConvLayer(nn.Module):
 
     def packed_s2d(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        key = ops.weight_key(w)
         if self._packed_s2d is None or self._packed_s2d[0] != key:
             self._packed_s2d = (key, ops.pack_weights(self.s2d_spec(), ops.s2d_weight(w.detach())))
         return self._packed_s2d[1]
@@ -111,7 +111,7 @@ class ConvLayer(nn.Module):
 
     def packed_rows(self):
         w = self.weight
-        key = (w._version, w.data_ptr(), ops.WEIGHTS_EPOCH)
+        key = ops.weight_key(w)
         if self._packed_rows is None or self._packed_rows[0] != key:
             self._packed_rows = (key, ops.pack_weights(self.rows_spec(), ops.stem_rows_weight(w.detach())))
         return self._packed_rows[1]

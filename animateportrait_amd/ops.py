@@ -20,6 +20,15 @@ EPS = 1e-5  # nn.InstanceNorm2d default (networks.py:33-34)
 # per-layer packed-weight caches
 WEIGHTS_EPOCH = 0
 
+
+def weight_key(w):
+    """What a packed copy of parameter ``w`` is valid for: torch's version counter (in-place torch ops), the address, the
+    package-wide epoch (raw-storage updates such as the start-up broadcast) and the epoch of the FlatAdam that owns the
+    parameter (its update goes through a raw pointer) -- per optimizer, so that a discriminator step does not throw
+    the generator's packed weights away and vice versa."""
+    owner = getattr(w, '_flat_owner', None)
+    return (w._version, w.data_ptr(), WEIGHTS_EPOCH, owner.epoch if owner is not None else 0)
+
 # Arithmetic of the wide 3x3 layers (include/animateportrait_amd.h, ap_conv_desc.precision):
 #   'fp32'   exact fp32 MFMA everywhere;
 #   'bf16x3' operands split into bf16 head + tail, three bf16 MFMAs per tile, fp32 accumulation: fp32-class

@@ -19,6 +19,7 @@ class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8):
         params = [p for p in params]
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self.epoch = 0
         self._params = params
         n = sum(p.numel() for p in params)
         dev = params[0].device
@@ -64,5 +65,6 @@ class FlatAdam(torch.optim.Optimizer):
         C.check(C.lib().ap_adam_step(_ptr(self.flat), _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                      self.flat.numel(), float(g['lr']), float(g['betas'][0]), float(g['betas'][1]),
                                      float(g['eps']), self.step_count, _stream()), 'adam_step')
-        # the update went through a raw pointer: tell the layers their packed-weight caches are stale
-        ops.WEIGHTS_EPOCH += 1
+        # the update went through a raw pointer: tell the layers of THIS optimizer's networks that their packed-weight
+        # caches are stale (ops.weight_key)
+        self.epoch += 1
