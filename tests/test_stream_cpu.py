@@ -26,6 +26,56 @@ def test_module1_content_network_matches_reference(golden):
     assert linf(out, gd['out']) < 1e-6 and fid.shape == (6, 204)
 
 
+def _seeded(net, gd, tag, seed):
+    from make_module1_golden import seeded_state
+    mine = [(k, str(tuple(v.shape)), str(v.dtype)) for k, v in net.state_dict().items()]
+    ref = list(zip(gd[tag + 'keys'].tolist(), gd[tag + 'shapes'].tolist(), gd[tag + 'dtypes'].tolist()))
+    assert mine == ref                      # same keys, order, shapes: the reference checkpoint loads strictly
+    sd = seeded_state([(k, eval(s), d) for k, s, d in ref], seed=seed)
+    sd = {k: (net.state_dict()[k] if k.endswith('pe.pe') else v) for k, v in sd.items()}   # constant table (as the golden)
+    net.load_state_dict(sd, strict=True)
+    return net.eval()
+
+
+def test_module1_speaker_aware_network_and_test_configuration_match_reference(golden):
+    """``Audio2LandmarkPos`` against ``Audio2landmark_pos`` and the content net in the configuration
+    ``Audio2landmark_model`` builds (use_prior_net=True): keys / order / shapes, outputs for seeded weights."""
+    from animateportrait_amd.module1 import Audio2LandmarkContent, Audio2LandmarkPos
+    gd = golden('module1.npz')
+    netc = _seeded(Audio2LandmarkContent(use_prior_net=True, drop_out=0.5), gd, 'c_', 78)
+    netg = _seeded(Audio2LandmarkPos(drop_out=0.5), gd, 'g_', 79)
+    with torch.no_grad():
+        assert linf(netc(gd['au'], gd['fid'])[0], gd['c_out']) < 1e-6
+        pred, face, spk = netg(gd['au'], gd['g_emb'], gd['fid'].repeat(6, 1), None, torch.zeros(6, 128))
+    assert linf(pred, gd['g_out']) < 1e-6 and face.shape == (1, 204) and spk.shape == (6, 128)
+
+
+def test_module1_clip_pipeline_matches_reference_methods(golden):
+    """predict_landmarks_speaker_aware == the reference's __train_face_and_pos__ / __calib_baseline_pred_fls__ /
+    __solve_inverse_lip2__ + the loop of __train_pass__ on a 600-window clip (two segments); the inverted-lip fix and
+    add_naive_eye on their own against the reference functions."""
+    from animateportrait_amd import module1 as m1
+    gd = golden('module1.npz')
+    netc = _seeded(m1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5), gd, 'c_', 78)
+    netg = _seeded(m1.Audio2LandmarkPos(drop_out=0.5), gd, 'g_', 79)
+    gp = torch.Generator().manual_seed(int(gd['p_seed']))
+    au = torch.randn(int(gd['p_T']), 18, 80, generator=gp)
+    spk = torch.randn(256, generator=gp)
+    fl = m1.predict_landmarks_speaker_aware(netg, netc, au, spk, gd['fid'].view(-1))
+    assert fl.shape == (600, 204)
+    ref = gd['p_sub'].numpy()
+    assert np.abs(fl[::16] - ref).max() < 2e-5 * np.abs(ref).max()
+    assert abs(fl.sum() - float(gd['p_sum'])) < 1e-4 * float(gd['p_abs'])
+    lips = gd['lip_in'].numpy().astype(np.float64)
+    fixed = m1.solve_inverse_lip(lips.copy())
+    assert np.abs(fixed - gd['lip_out'].numpy()).max() < 1e-12 and np.abs(fixed - lips).max() > 0.1   # (some frames were fixed)
+    np.random.seed(5)
+    eyes = m1.add_naive_eye(gd['eye_in'].numpy().copy())
+    assert np.abs(eyes - gd['eye_out'].numpy()).max() < 1e-6
+    img = m1.to_image_landmarks(fl, scale=0.01, shift=(-128.0, -120.0), rng=np.random.RandomState(1))
+    assert img.shape == (600, 68, 3) and np.isfinite(img).all()
+
+
 def test_predict_landmarks_postprocessing():
     from animateportrait_amd.module1 import Audio2LandmarkContent, predict_landmarks
     from scipy.signal import savgol_filter
