@@ -25,6 +25,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 GFLOP_PER_FRAME = 140.125          # 70.063 GMAC conv + conv-transpose
@@ -182,7 +183,9 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
         torch.manual_seed(1234)
         model = create_model(opt)
     model.aux['netF'] = standins.StandinFlowNet().to(dev)
-    content = module1.Audio2LandmarkContent().to(dev).eval()
+    content = module1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5).to(dev).eval()      # train_audio2landmark.py:71-73
+    pose = module1.Audio2LandmarkPos(drop_out=0.5).to(dev).eval()                                  # :55-59
+    spk = torch.randn(256, generator=torch.Generator().manual_seed(7))
     g = torch.Generator().manual_seed(1234)
     photo = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
@@ -195,7 +198,11 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     streamer = stream.ClipStreamer(model, batch=batch)
 
     def clip(profile=False):
-        module1.predict_landmarks(content, au, fid)          # Module1 content branch over the whole clip (timed, see above)
+        # Module1 over the whole clip: both networks + the landmark post-processing of Audio2landmark_model.test and
+        # main_end2end_module2.py:262-272 (timed; its output is not fed on -- random weights do not draw faces -- the
+        # synthetic sequence of the same length is)
+        fl = module1.predict_landmarks_speaker_aware(pose, content, au, spk, fid)
+        module1.to_image_landmarks(fl, scale=0.01, shift=(-128.0, -128.0), rng=np.random.RandomState(0))
         return streamer.run(photo, lm0, seq, matte=matte, profile=profile)
     clip()                                                   # warm-up (first-use compilation of torch LSTM kernels etc.)
     torch.cuda.synchronize()
@@ -236,8 +243,9 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
                              'sample': 'oracle per-frame path: landmark txt round trip, scipy.griddata motion, cv2-rule landmark '
                                        'maps, netF pre/post, static drawing @512^2, generator, blend; batch 1'},
             'speedup_vs_cpu': round(cpu_s * frames / wall, 1),
-            'note': 'random-init weights; stand-in netF and matte; Module1 = content LSTM only (random init) on synthetic '
-                    'mel windows: AutoVC front end / pose branch / checkpoints absent from the reference tree'}
+            'note': 'random-init weights; stand-in netF and matte; Module1 = both landmark networks (content + speaker-aware '
+                    'pose branch) and their post-processing on synthetic mel windows / speaker embedding: the AutoVC front end '
+                    'and the checkpoints are absent from the reference tree'}
 
 
 def main():
