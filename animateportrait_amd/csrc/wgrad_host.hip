@@ -54,7 +54,7 @@ struct WgradPlan {
     bool s2d = false;
     int Kb = 0, Cb = 0, Hb = 0, Wb = 0;     // kernel size, channels and operand size the bf16 GEMM kernel sees
     // streaming kernel for 1..2 input channels (wgrad_narrow.h): > 0 = output channels per workgroup
-    int narrow_cob = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
+    int narrow_cob = 0, narrow_ppt = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
 };
 
 // split-bf16 instantiations by kernel size (stride 1)
@@ -136,7 +136,14 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             const long long total_rows = (long long)d->N * d->GH;
             long long P = std::max<long long>(1, 1024 / groups);
             long long rpb = (total_rows + P - 1) / P;
-            rpb = (rpb + pl.rpi - 1) / pl.rpi * pl.rpi;
+            // K = 4 stride 2 with zero pad 1 on rows a workgroup spans exactly (the PatchGAN first layer): the LDS-staged
+            // form (one output pixel per thread and iteration: 2 and 4 measured slower, 277 registers) (wgrad_narrow_s2k4_kernel)
+            constexpr int kNarrowPPT = 1;
+            if (K == 4 && S == 2 && d->pad == 1 && d->pad_mode == AP_PAD_ZERO && gwc == d->GW && d->W == 2 * d->GW &&
+                d->H == 2 * d->GH && (d->GH % (pl.rpi * kNarrowPPT)) == 0 && !getenv("APAMD_NO_NARROW_LDS"))
+                pl.narrow_ppt = kNarrowPPT;
+            const int rit = pl.rpi * (pl.narrow_ppt ? pl.narrow_ppt : 1);
+            rpb = (rpb + rit - 1) / rit * rit;
             pl.rows_per_block = (int)rpb;
             pl.P = (int)((total_rows + rpb - 1) / rpb);
             pl.part_floats = (long long)pl.P * d->M * pl.Q;
@@ -414,7 +421,10 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         p.rows_per_block = pl.rows_per_block; p.gwc = pl.gwc; p.gwc_shift = pl.gwc_shift; p.rpi = pl.rpi;
         p.partial = workspace;
         const dim3 grid(pl.P, (d->M + pl.narrow_cob - 1) / pl.narrow_cob);
+        const size_t nlds = (size_t)2 * pl.Cin * (2 * pl.rpi * pl.narrow_ppt + 2) * (d->W + 2) * sizeof(float);
         if (d->K == 3) hipLaunchKernelGGL((wgrad_narrow_kernel<3, 1, 1, 8>), grid, dim3(256), 0, stream, p);
+        else if (pl.narrow_ppt && pl.Cin == 1) hipLaunchKernelGGL((wgrad_narrow_s2k4_kernel<1, 4, 1>), grid, dim3(256), nlds, stream, p);
+        else if (pl.narrow_ppt) hipLaunchKernelGGL((wgrad_narrow_s2k4_kernel<2, 4, 1>), grid, dim3(256), nlds, stream, p);
         else if (pl.Cin == 1) hipLaunchKernelGGL((wgrad_narrow_kernel<4, 2, 1, 4>), grid, dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((wgrad_narrow_kernel<4, 2, 2, 4>), grid, dim3(256), 0, stream, p);
         rc = check_launch("wgrad_narrow_kernel");

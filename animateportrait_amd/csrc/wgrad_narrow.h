@@ -100,4 +100,142 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradNarrowPara
     }
 }
 
+// The PatchGAN first layer (K = 4, stride 2, zero pad 1, GW a power of two <= 256 = the x extent of a workgroup): the
+// general kernel above spends ~10 VALU instructions of address / padding logic on each of the 16 CIN taps of a pixel --
+// 3.5x its 128 FMAs (230 us per launch on 48 x 2 x 256 x 256).  Here the input rows of an iteration are staged once per
+// workgroup in LDS with InstanceNorm / activation applied and the zero border in place, and a tap row is two 8-byte LDS
+// reads at a constant offset.  The kernel is latency-bound (4 waves per SIMD at best: 128 accumulators per thread, one
+// barrier per iteration), so an iteration covers PPT * rpi output rows -- PPT pixels per thread -- and the global loads
+// of iteration i + 1 (its RIN = 2 PPT rpi + 2 staged rows and gradient values) fly while iteration i multiplies.
+// grid: (P, ceil(M / COB)), 256 threads; dynamic LDS: 2 * CIN * RIN * (W + 2) floats
+template <int CIN, int COB, int PPT>
+__global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarrowParams p) {
+    constexpr int K = 4, Q = CIN * K * K;
+    extern __shared__ float xs[];
+    __shared__ float red[4][COB * Q];
+    const int tid = threadIdx.x, tx = tid & (p.gwc - 1), ty = tid >> p.gwc_shift;
+    const int co0 = blockIdx.y * COB;
+    const int total_rows = p.N * p.GH;
+    const int r0 = blockIdx.x * p.rows_per_block;
+    int r1 = r0 + p.rows_per_block;
+    if (r1 > total_rows) r1 = total_rows;
+    const int HW = p.H * p.W, GHW = p.GH * p.GW;
+    const int RPI = p.rpi * PPT;                                   // output rows per iteration
+    const int RIN = 2 * RPI + 2, WP = p.W + 2, BUF = CIN * RIN * WP;
+    const int W4 = p.W >> 2;                                       // float4 groups per input row
+    const float slope = p.src.act == 1 ? 0.f : (p.src.act == 2 ? 0.2f : 1.f);
+    float acc[COB][Q];
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[c][q] = 0.f;
+    // staged float4 groups per thread: CIN RIN W4 / 256 = CIN (PPT rpi + 1) gwc / 256 = CIN (PPT + 1 / rpi)
+    constexpr int MAXS = CIN * (PPT + 1);
+    float4 sv[MAXS];
+    float gn[PPT][COB];
+    // what a thread stages does not change with the iteration: (channel, row j of the RIN, four columns) per group --
+    // worked out once (integer divisions by run-time values cost ~40 VALU instructions each)
+    int s_src[MAXS], s_dst[MAXS], s_j[MAXS], s_ci[MAXS], s_edge[MAXS];   // s_edge: 1 first / 2 last group of a row
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        const int e = tid + k * 256;
+        const int rr = e / W4, x4 = (e - rr * W4) * 4;             // staged row (ci, j), first of four columns
+        const int ci = rr / RIN, j = rr - ci * RIN;
+        const bool on = e < CIN * RIN * W4;
+        s_ci[k] = on ? ci : 0;
+        s_j[k] = on ? j : -(1 << 20);                              // (an inactive group never passes the row test)
+        s_src[k] = ci * HW + (j - 1) * p.W + x4;                   // + (n CIN HW + 2 oy0 W)
+        s_dst[k] = on ? rr * WP + 1 + x4 : -1;
+        s_edge[k] = (x4 == 0 ? 1 : 0) | (x4 == p.W - 4 ? 2 : 0);
+    }
+    auto fetch = [&](int rowb) __attribute__((always_inline)) {
+        const int n = rowb / p.GH, oy0 = rowb - n * p.GH;
+        const float* base = p.src.data + (long long)n * CIN * HW + 2 * oy0 * p.W;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            sv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int iy = oy0 * 2 - 1 + s_j[k];
+            if (iy >= 0 && iy < p.H) {
+                float4 v = *reinterpret_cast<const float4*>(base + s_src[k]);
+                if (p.src.mean != nullptr) {
+                    const float m = p.src.mean[n * CIN + s_ci[k]], r = p.src.rstd[n * CIN + s_ci[k]];
+                    v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+                }
+                v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+                v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
+                sv[k] = v;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int row = rowb + u * p.rpi + ty;
+#pragma unroll
+            for (int c = 0; c < COB; ++c)
+                gn[u][c] = (row < r1 && co0 + c < p.M)
+                               ? p.g[((long long)n * p.M + co0 + c) * GHW + (oy0 + u * p.rpi + ty) * p.GW + tx] : 0.f;
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        float* xb = xs + buf * BUF;
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) {
+            if (s_dst[k] >= 0) {
+                float* d = xb + s_dst[k];                          // staged column = image column + 1
+                d[0] = sv[k].x; d[1] = sv[k].y; d[2] = sv[k].z; d[3] = sv[k].w;
+                if (s_edge[k] & 1) d[-1] = 0.f;
+                if (s_edge[k] & 2) d[4] = 0.f;
+            }
+        }
+    };
+    int buf = 0;
+    if (r0 < r1) {
+        fetch(r0);
+        stage(0);
+    }
+    __syncthreads();
+    for (int rowb = r0; rowb < r1; rowb += RPI, buf ^= 1) {
+        // rows rowb .. rowb + RPI - 1 belong to one image (RPI divides GH, r0 is a multiple of RPI)
+        float gv[PPT][COB];
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+#pragma unroll
+            for (int c = 0; c < COB; ++c) gv[u][c] = gn[u][c];
+        const bool more = rowb + RPI < r1;
+        if (more) fetch(rowb + RPI);
+        const float* xb = xs + buf * BUF;
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int ky = 0; ky < K; ++ky) {
+                    const float2* rp = reinterpret_cast<const float2*>(xb + (ci * RIN + (u * p.rpi + ty) * 2 + ky) * WP + tx * 2);
+                    const float2 a = rp[0], b = rp[1];
+                    const float xw[4] = {a.x, a.y, b.x, b.y};
+#pragma unroll
+                    for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+                        for (int c = 0; c < COB; ++c) acc[c][(ci * K + ky) * K + kx] += gv[u][c] * xw[kx];
+                }
+        if (more) stage(buf ^ 1);
+        __syncthreads();                                           // next buffer written; this one free for the one after
+    }
+    // block sums (fixed order: lanes by butterfly, then the four waves)
+#pragma unroll
+    for (int c = 0; c < COB; ++c)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            float a = acc[c][q];
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) a += __shfl_xor(a, sh, 64);
+            if ((tid & 63) == 0) red[tid >> 6][c * Q + q] = a;
+        }
+    __syncthreads();
+    if (tid < COB * Q) {
+        const int c = tid / Q, q = tid - c * Q;
+        if (co0 + c < p.M)
+            p.partial[((long long)blockIdx.x * p.M + co0 + c) * Q + q] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    }
+}
+
 }  // namespace apamd

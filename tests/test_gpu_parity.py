@@ -425,6 +425,8 @@ BWD_CASES = [
     ([12], 20, 3, 2, 1, 'zero', False, 36, 40),
     ([2], 64, 4, 2, 1, 'zero', False, 64, 64),         # 1..2 input channels: streaming weight gradient (wgrad_narrow.h)
     ([1], 64, 4, 2, 1, 'zero', False, 36, 40),
+    ([1], 20, 4, 2, 1, 'zero', False, 128, 128),       # ... the LDS-staged form (power-of-two rows), 4 rows per iteration
+    ([2], 10, 4, 2, 1, 'zero', False, 24, 256),        # ... one row per iteration, partial cout group
     ([1], 8, 3, 1, 1, 'zero', False, 40, 70),
     ([16], 48, 4, 1, 1, 'zero', False, 32, 32),
     ([32], 1, 4, 1, 1, 'zero', False, 31, 31),
