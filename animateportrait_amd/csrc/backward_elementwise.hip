@@ -260,15 +260,19 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_fused_kernel(const float* __r
 // activated gradient of the first 8 groups stays in registers, the other 8 are parked in LDS (128 KiB); the normalised
 // activation is recomputed from a second read of y, which the plane's first pass left in the memory-side cache --
 // 2 + (1 cached) reads + 1 write per element instead of the 4 + 1 of the reduce / apply pair.  grid: (N*C)
-__global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const float* __restrict__ g1,
+template <bool FOLD>
+__global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const float* __restrict__ g1, int p1,
                                                                      const float* __restrict__ g2,
                                                                      const float* __restrict__ y,
                                                                      const float* __restrict__ mean,
-                                                                     const float* __restrict__ rstd, int act, int HW,
+                                                                     const float* __restrict__ rstd, int act, int H, int W,
                                                                      float* __restrict__ dy) {
     extern __shared__ float4 park[];                 // [8][1024]
     __shared__ float red[16];
-    const int nc = blockIdx.x, tid = threadIdx.x, Q = HW >> 2;
+    const int nc = blockIdx.x, tid = threadIdx.x, HW = H * W, Q = HW >> 2, W4 = W >> 2;
+    // p1 > 0: the gradient of a reflection-padded convolution, still in padded coordinates (W % 4 == 0: a group of four
+    // pixels stays in one row)
+    const FoldReader fr{g1 + (long long)nc * (H + 2 * p1) * (W + 2 * p1), H, W, p1, W + 2 * p1};
     const float m = mean[nc], r = rstd[nc];
     const float4* y4 = reinterpret_cast<const float4*>(y + (long long)nc * HW);
     const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
@@ -281,7 +285,13 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const floa
         float4 yv = make_float4(m, m, m, m), gq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < Q) {
             yv = y4[i];
-            gq = ga[i];
+            if constexpr (!FOLD) {
+                gq = ga[i];
+            } else {
+                const int yy = i / W4, xx = (i - yy * W4) * 4;
+                if (p1 == 1 && H >= 3) gq = fold1_at4(fr.g, H, W, yy, xx);
+                else gq = make_float4(fr.at(yy, xx), fr.at(yy, xx + 1), fr.at(yy, xx + 2), fr.at(yy, xx + 3));
+            }
             if (gb) { const float4 t = gb[i]; gq.x += t.x; gq.y += t.y; gq.z += t.z; gq.w += t.w; }
         }
         const float x0 = (yv.x - m) * r, x1 = (yv.y - m) * r, x2 = (yv.z - m) * r, x3 = (yv.w - m) * r;
@@ -495,17 +505,24 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
                            g2, y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
     }
-    if (fused_ok && H * W <= 65536 && g1_pad == 0 && (H * W) % 4 == 0) {
+    if (fused_ok && H * W <= 65536 && (W % 4) == 0 && W >= 4) {
         static bool attr = false;
         const size_t lds = 8 * 1024 * sizeof(float4);
         if (!attr) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel<false>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel<true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr = true;
         }
-        hipLaunchKernelGGL(instnorm_bwd_fused_big_kernel, dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g2, y, mean,
-                           rstd, act, H * W, dy);
+        if (g1_pad == 0)
+            hipLaunchKernelGGL(instnorm_bwd_fused_big_kernel<false>, dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g1_pad,
+                               g2, y, mean, rstd, act, H, W, dy);
+        else
+            hipLaunchKernelGGL(instnorm_bwd_fused_big_kernel<true>, dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g1_pad,
+                               g2, y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_big_kernel");
     }
     hipLaunchKernelGGL(instnorm_bwd_reduce_kernel, dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, y,

@@ -528,7 +528,8 @@ def test_wgrad_bf16x3(dev, case):
                                                 ((1, 3, 256, 256), 1, True, 0), ((1, 2, 200, 256), 0, False, 0),
                                                 ((1, 2, 300, 300), 1, True, 0), ((2, 3, 64, 64), 1, True, 1),
                                                 ((1, 2, 30, 30), 1, False, 1), ((1, 2, 128, 128), 2, True, 1),
-                                                ((1, 2, 256, 256), 1, True, 1)])
+                                                ((1, 2, 256, 256), 1, True, 1), ((1, 2, 256, 256), 0, False, 3),
+                                                ((1, 2, 40, 44), 1, True, 3)])
 def test_instnorm_backward_all_plane_sizes(dev, shape, act, two, pad):
     """ap_instnorm_bwd against autograd through act(instance_norm(y)) [and ReflectionPad2d(1) when the incoming
     gradient is a padded convolution's]: the register-resident kernels (planes up to 64^2 and 128^2; 16-byte-lane and
