@@ -1,0 +1,111 @@
+"""Module2 side of the end-to-end driver, in one process -- counterpart of ``test_gan_new`` and the frame / video steps of
+main_end2end_module2.py:90-124, 294-343.
+
+The reference writes one landmark txt + one landmark PNG per frame, shells out to ``python test.py --model
+geomcgt_ifw_test`` (which re-reads them, builds the motion grids with scipy on the CPU and runs the model at batch 1),
+copies the PNGs it wrote and calls ffmpeg at 62.5 fps.  Here: photo + a landmark clip in, frames (and the video, when
+ffmpeg exists) out, through ``stream.ClipStreamer`` in batches.
+
+    python -m animateportrait_amd.end2end --photo face.png --landmarks Data/Alm_txt/MTCNN/<db>_MTCNN \\
+        --landmark_scale 0.5 --name formal/drawing --epoch 70 --out output/<db> [--audio a.wav]
+
+Landmark sources: ``--landmarks DIR`` (the reference's ``Alm_txt`` layout: ``ori.txt`` + ``%05d.txt``, 512-px coordinates
+for a 256-px photo -> ``--landmark_scale 0.5``) or ``--landmarks_npy FILE`` ((T + 1, 68, 2): row 0 = the photo's).  The
+matte comes from ``--matte PNG`` (white = foreground) unless the model has its matting network.
+"""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import torch
+
+from . import stream
+from .models import create_model
+from .options.base_options import TestOptions
+
+
+def tensor2im(t):
+    """util/util.py:9-29 for one (C, H, W) frame in [-1, 1] -> uint8 (H, W, 3)."""
+    a = t.detach().float().cpu().numpy()
+    if a.shape[0] == 1:
+        a = np.tile(a, (3, 1, 1))
+    elif a.shape[0] == 2:
+        a = np.concatenate([a, a[1:2]], 0)
+    return ((np.transpose(a, (1, 2, 0)) + 1) / 2.0 * 255.0).astype(np.uint8)
+
+
+def load_photo(path, size):
+    from PIL import Image
+    im = Image.open(path).convert('RGB')
+    if im.size != (size, size):
+        im = im.resize((size, size), Image.BICUBIC)
+    a = np.asarray(im, dtype=np.float32) / 255.0
+    return torch.from_numpy(a).permute(2, 0, 1).unsqueeze(0) * 2 - 1                # transforms.Normalize(0.5, 0.5)
+
+
+def load_matte(path, size):
+    from PIL import Image
+    im = Image.open(path).convert('L')
+    if im.size != (size, size):
+        im = im.resize((size, size), Image.BILINEAR)
+    return torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).view(1, 1, size, size)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--photo', required=True)
+    ap.add_argument('--landmarks', default=None, help='directory in the Alm_txt layout')
+    ap.add_argument('--landmarks_npy', default=None)
+    ap.add_argument('--landmark_scale', type=float, default=1.0)
+    ap.add_argument('--matte', default=None)
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--fps', type=float, default=62.5)                              # main_end2end_module2.py:343
+    ap.add_argument('--audio', default=None)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--size', type=int, default=256)
+    a, rest = ap.parse_known_args(argv)
+    if (a.landmarks is None) == (a.landmarks_npy is None):
+        ap.error('exactly one of --landmarks / --landmarks_npy')
+    # the model's own options: the test settings of test_gan_new (:95-104) unless given
+    defaults = ['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--netg_resb_div', '3',
+                '--netg_resb_disp', '3', '--output_nc', '1', '--dataset_mode', 'synthetic', '--blendbg', '1', '--gpu_ids', '0']
+    opt = TestOptions().parse(defaults + rest)
+    torch.cuda.set_device(opt.gpu_ids[0])
+    model = create_model(opt)
+    model.setup(opt)                    # '<epoch>_net_G_A.pth' + the static drawing generator; missing files are errors
+    model.eval()
+    if a.landmarks is not None:
+        lm0, seq = stream.load_landmark_dir(a.landmarks, a.landmark_scale)
+    else:
+        arr = np.load(a.landmarks_npy).astype(np.float32) * a.landmark_scale
+        lm0, seq = arr[0], arr[1:]
+    photo = load_photo(a.photo, a.size)
+    matte = load_matte(a.matte, a.size) if a.matte else None
+    if matte is None and model.aux.get('modnet') is None:
+        raise SystemExit('no matting network is attached (aux["modnet"]): pass --matte PNG')
+    frames = stream.ClipStreamer(model, batch=a.batch).run(photo, lm0, seq, matte=matte)
+    fdir = os.path.join(a.out, 'frames')
+    os.makedirs(fdir, exist_ok=True)
+    from PIL import Image
+    for k in range(frames.shape[0]):
+        Image.fromarray(tensor2im(frames[k])).save(os.path.join(fdir, '%05d.png' % k))
+    print('wrote %d frames to %s' % (frames.shape[0], fdir))
+    ffmpeg = shutil.which('ffmpeg')
+    if ffmpeg is None:
+        print('ffmpeg not found: frames only (the reference assembles them at %.1f fps, :118-121)' % a.fps)
+        return 0
+    video = os.path.join(a.out, 'output.mp4')
+    subprocess.check_call([ffmpeg, '-loglevel', 'panic', '-framerate', str(a.fps), '-i', os.path.join(fdir, '%05d.png'),
+                           '-c:v', 'libx264', '-y', '-vf', 'format=yuv420p', video])
+    if a.audio:
+        subprocess.check_call([ffmpeg, '-loglevel', 'panic', '-i', video, '-i', a.audio, '-vcodec', 'copy', '-acodec', 'copy',
+                               '-y', video.replace('.mp4', '.mov')])
+    print('output is', video)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,6 +1,8 @@
 """GPU (-m gpu): the in-process clip pipeline (ClipStreamer: landmarks -> motion grids -> landmark maps -> netF pre/post
 -> GeomCGTIFWTestModel) against the oracle's per-frame composition of the reference's data path
 (scipy.griddata motion, cv2-rule discs, flow_network_warp, static drawing, generator, blend)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -57,3 +59,52 @@ def test_clip_streamer_vs_oracle_frames():
     # same clip in one batch and without stage synchronisation: identical frames
     out2 = stream.ClipStreamer(model, batch=8).run(photo, lm0, seq, matte=matte).cpu()
     assert linf(out2, out) < 1e-4          # another batch size picks another tile shape: fp32 summation order
+
+
+def test_end2end_cli_writes_the_clip(tmp_path, monkeypatch):
+    """animateportrait_amd.end2end (the in-process test_gan_new of main_end2end_module2.py:90-124): checkpoints loaded by
+    name, photo / matte PNGs and an Alm_txt landmark directory in, PNG frames out == ClipStreamer on the same inputs."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    from PIL import Image
+    from animateportrait_amd import end2end, stream
+    from animateportrait_amd.synthetic import make_landmarks
+    from oracle import generator as og, static_generator as osg
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('checkpoints/e2e')
+    os.makedirs('checkpoints/static')
+    torch.save(og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=1234), 'checkpoints/e2e/7_net_G_A.pth')
+    torch.save(og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321), 'checkpoints/static/drawing.pth')
+    yy, xx = np.meshgrid(np.linspace(-1, 1, 256), np.linspace(-1, 1, 256), indexing='ij')
+    photo = np.stack([np.sin(3 * xx + yy), np.cos(2 * yy - xx), xx * yy], -1)
+    Image.fromarray(((photo + 1) * 127.5).astype(np.uint8)).save('photo.png')
+    Image.fromarray(((((yy / 0.8) ** 2 + (xx / 0.6) ** 2) < 1) * 255).astype(np.uint8)).save('matte.png')
+    g = torch.Generator().manual_seed(9)
+    lm0 = make_landmarks(1, g)[0]
+    t = torch.arange(5).view(5, 1, 1).float()
+    seq = lm0.unsqueeze(0) + 2.0 * torch.sin(0.3 * t + lm0.unsqueeze(0) / 40.0)
+    os.makedirs('lm')
+    stream.write_landmark_txt('lm/ori.txt', (lm0 * 2).numpy())                    # the reference writes 512-px coordinates
+    for k in range(5):
+        stream.write_landmark_txt('lm/%05d.txt' % k, (seq[k] * 2).numpy())
+    argv = ['--photo', 'photo.png', '--matte', 'matte.png', '--landmarks', 'lm', '--landmark_scale', '0.5', '--out', 'out',
+            '--batch', '4', '--name', 'e2e', '--epoch', '7', '--ngf', '8', '--checkpoints_dir', 'checkpoints']
+    assert end2end.main(argv) == 0
+    files = sorted(os.listdir('out/frames'))
+    assert files == ['%05d.png' % k for k in range(5)]
+    got = np.stack([np.asarray(Image.open(os.path.join('out/frames', f))) for f in files])
+    assert got.shape == (5, 256, 256, 3) and got.std() > 1.0
+    # the same clip through the streamer directly
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--netg_resb_div',
+                               '3', '--netg_resb_disp', '3', '--output_nc', '1', '--dataset_mode', 'synthetic', '--blendbg', '1',
+                               '--gpu_ids', '0', '--name', 'e2e', '--epoch', '7', '--ngf', '8', '--checkpoints_dir', 'checkpoints'])
+    model = create_model(opt)
+    model.setup(opt)
+    model.eval()
+    lm_ori, lm_seq = stream.load_landmark_dir('lm', 0.5)
+    frames = stream.ClipStreamer(model, batch=2).run(end2end.load_photo('photo.png', 256), lm_ori, lm_seq,
+                                                     matte=end2end.load_matte('matte.png', 256))
+    want = np.stack([end2end.tensor2im(frames[k]) for k in range(5)])
+    assert np.abs(got.astype(np.int32) - want.astype(np.int32)).max() <= 1        # (batch 4 vs 2: same frames)
