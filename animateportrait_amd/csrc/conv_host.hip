@@ -7,6 +7,7 @@
 #include "conv_registry.h"
 #include "conv_direct.h"
 #include "conv_bf16x3.h"
+#include "conv_ph4.h"
 #include "conv_small.h"
 #include "conv_head.h"
 #include "conv_tsmall.h"
@@ -67,6 +68,15 @@ static Bf3Kernel bk2(const char* name) {
     return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, C::ROW, reinterpret_cast<const void*>(&conv_bf16x3<C>),
                      &C::wfloats, &C::lds_bytes, name, reinterpret_cast<const void*>(&conv_bf16x3<C1>), &C1::lds_bytes};
 }
+// the four phases of a stride-2 transposed layer in one tile (conv_ph4.h): 32 couts x 8 rows x 4 phases
+template <int KK>
+static const Bf3Kernel* ph4_kernel() {
+    using C = Ph4Cfg<KK, 2>;
+    using C1 = Ph4Cfg<KK, 1>;
+    static const Bf3Kernel k{1, 0, C::CO_TILE, C::TH, 4, 0, reinterpret_cast<const void*>(&conv_ph4<C>), &C::wfloats, &C::lds_bytes,
+                             KK == 3 ? "Ph4Cfg<3>" : "Ph4Cfg<4>", reinterpret_cast<const void*>(&conv_ph4<C1>), &C1::lds_bytes};
+    return &k;
+}
 static const std::vector<Bf3Kernel>& bf3_registry() {
     static std::vector<Bf3Kernel> v = {
         bk2<1, 3, 1, 2, 4, 1>("Bf3Cfg<1, 3, 1, 2, 4, 1>"),      // 3x3 s1, small batches: 64 couts x 4 rows
@@ -115,6 +125,7 @@ struct Plan {
     long long head_w_off = -1;     // >= 0: plain copy of the caller's weights at this offset of the packed image
     bool bf3 = false;              // split-bf16 matrix path
     bool fused_phases = false;     // transposed, split-bf16: the four sub-pixel phases are one launch
+    int ph4 = 0;                   // 3 / 4: ... and one TILE (conv_ph4.h)
     bool k0_small = false;         // run-time-tap family: the half-height 4-tap instantiation (two workgroups per CU)
     const Bf3Kernel* bk = nullptr;
     std::vector<Launch> launches;
@@ -253,6 +264,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                                                         !env_int("APAMD_NO_FUSED_PHASES", 0));
                 pl.k0_small = all4 && env_int("APAMD_K0_SMALL", 1) != 0;
                 if (pl.k0_small) pl.bk = small;
+                // stride-2 transposed 3x3 / 4x4 with pad 1 and an even output: all four phases in one tile
+                if (d->transposed && (K == 3 || K == 4) && d->pad == 1 && d->stride == 2 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 &&
+                    !env_int("APAMD_NO_FUSED_PHASES", 0) && !env_int("APAMD_NO_PH4", 0)) {
+                    pl.ph4 = K;
+                    pl.bk = K == 3 ? ph4_kernel<3>() : ph4_kernel<4>();
+                }
             }
             if (tall && small != tall && KT != 0) {
                 const long long tiles = (long long)d->N * ((pl.Hout + tall->TH - 1) / tall->TH) * ((pl.Wout + 31) / 32) *
@@ -814,7 +831,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             return fail(AP_ERR_INVALID, "this layer runs on the split-bf16 path: pass sources prepared by "
                                         "ap_split_prepass and set desc.presplit (see ap_conv2d_wants_presplit)");
         for (const auto& L : pl.launches) {
-            const Bf3Kernel* kern = bf3_for_taps(pl.bk, (int)L.taps.size());
+            const Bf3Kernel* kern = pl.ph4 ? pl.bk : bf3_for_taps(pl.bk, (int)L.taps.size());
             if (!kern) return fail(AP_ERR_UNSUPPORTED, "no split-bf16 kernel for a phase with %d taps", (int)L.taps.size());
             const void* kfn = kern->kernel(d->precision);
             rc = ensure_lds_attr(kfn);
@@ -867,6 +884,25 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                     for (size_t t = 0; t < Lp.taps.size() && t < 4; ++t)
                         if (Lp.taps[t].ky >= 0) p.ph_tapmask[ph] |= 1u << t;
                     if (env_int("APAMD_NO_TAP_SKIP", 0)) p.ph_tapmask[ph] = 0xFu;
+                }
+                if (pl.ph4) {
+                    // conv_ph4 walks cout tiles only and derives the phase geometry from K: check the plan agrees
+                    if (view) return fail(AP_ERR_UNSUPPORTED, "conv_ph4: output views are not supported");
+                    p.co_tiles = pl.co_tiles;
+                    const int base = pl.ph4 == 3 ? 0 : -1;
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const Launch& Lp = pl.launches[ph];
+                        const unsigned want = ((pl.ph4 == 3 && !(ph >> 1)) ? 1u : 3u) * 1u;          // taps along y
+                        const unsigned wanx = (pl.ph4 == 3 && !(ph & 1)) ? 1u : 3u;
+                        unsigned m = 0;
+                        for (int t = 0; t < 4; ++t) if (((want >> (t >> 1)) & 1u) && ((wanx >> (t & 1)) & 1u)) m |= 1u << t;
+                        const int oy = pl.ph4 == 3 ? 0 : (ph >> 1), ox = pl.ph4 == 3 ? 0 : (ph & 1);
+                        unsigned have = 0;
+                        for (size_t t = 0; t < Lp.taps.size() && t < 4; ++t) if (Lp.taps[t].ky >= 0) have |= 1u << t;
+                        if (have != m || Lp.dy0 != base + oy || Lp.dx0 != base + ox || Lp.oy_off != (ph >> 1) || Lp.ox_off != (ph & 1) ||
+                            Lp.osy != 2 || Lp.osx != 2 || Lp.OH != pl.launches[0].OH || Lp.OW != pl.launches[0].OW)
+                            return fail(AP_ERR_UNSUPPORTED, "conv_ph4: phase %d geometry (taps %x/%x, origin %d,%d)", ph, have, m, Lp.dy0, Lp.dx0);
+                    }
                 }
             }
             p.tap_bits = 0;

@@ -1,0 +1,295 @@
+// conv_ph4.h -- the four sub-pixel phases of a stride-2 transposed convolution (ConvTranspose2d(3, 2, 1, 1) of the
+// generator's decoder; the data gradients of the stride-2 3x3 / 4x4 layers) in ONE tile.
+//
+// conv_bf16x3's fused-phase launch walks (phase, cout tile) pairs as separate tiles: every pair stages the same
+// activation tile again (8 times for 128 output channels) and a 4-tap weight block of which a 3x3 layer uses 9 of 16
+// taps, so its stages are LDS-DMA-bound (12..48 MFMAs against 36 KB of DMA).  Here a tile owns 32 output channels of
+// ALL four phases: one activation tile per stage, four phase accumulators, only the taps that exist are multiplied
+// (compile-time tables for the two geometries that occur: K = 3 and K = 4 with pad 1), and the two x-phases of an
+// output row leave as 8-byte stores (the phases interleave along x).
+//
+// Operands are the ones conv_bf16x3 uses: XS split tensors, and the packed phase blocks [phase][cout tile][chunk] of
+// [part][tap][k-group][32 couts] 16-byte slots written by pack_bf16x3_kernel for a 32-cout tile.
+#pragma once
+#include "conv_bf16x3.h"
+
+namespace apamd {
+
+template <int KK_, int PARTS_>
+struct Ph4Cfg {
+    static_assert(KK_ == 3 || KK_ == 4, "pad-1 3x3 and 4x4 stride-2 layers");
+    static constexpr int KK = KK_, PARTS = PARTS_;
+    static constexpr int CO_TILE = 32, NT = 2, WPX = 4, TH = WPX * NT;
+    static constexpr int EXT = KK == 3 ? 1 : 2;                    // reach of the union window of the four phases
+    static constexpr int IH = TH + EXT, IW = 32 + EXT, PLANE = IH * IW;
+    static constexpr int XP = (2 * PLANE + 63) / 64 * 64;          // slots per part: [k-group][pixel]
+    static constexpr int NXP = XP / 64;                            // wave-wide DMA pieces per part
+    static constexpr int WB = 256;                                 // slots of one part of a packed phase block: 4 taps x 2 x 32
+    static constexpr int NTAPS = KK == 3 ? 9 : 16;                 // taps that exist: only those are staged, one 64-slot
+    static constexpr int W_SLOTS = NTAPS * PARTS * 64;             // piece (2 k-groups x 32 couts) per tap and part
+    static constexpr int X_SLOTS = PARTS * XP, STAGE = W_SLOTS + X_SLOTS;
+    static int wfloats(int) { return 2 * 4 * 2 * CO_TILE * 4; }    // a packed phase block always holds both parts
+    static size_t lds_bytes(int) { return (size_t)2 * STAGE * 16; }   // (the statistics slots live in the free stage buffer)
+    // phase ph = phy * 2 + phx; its window origin inside the union window and the taps (ly * 2 + lx) it has
+    static constexpr int org(int phz) { return KK == 3 ? 0 : phz; }           // K = 4: phase 0 starts one pixel earlier
+    static constexpr unsigned mask1(int phz) { return KK == 3 ? (phz ? 3u : 1u) : 3u; }   // taps along one axis
+    static constexpr bool has(int ph, int tp) {
+        return ((mask1(ph >> 1) >> (tp >> 1)) & 1u) && ((mask1(ph & 1) >> (tp & 1)) & 1u);
+    }
+    static constexpr int base_d = KK == 3 ? 0 : -1;                // input coordinate of the union window's origin
+    static constexpr int tap_code(int i) {                         // phase * 4 + tap of the i-th existing tap
+        int n = 0;
+        for (int c = 0; c < 16; ++c)
+            if (has(c >> 2, c & 3)) {
+                if (n == i) return c;
+                ++n;
+            }
+        return 0;
+    }
+    static constexpr int tap_ph(int i) { return tap_code(i) >> 2; }
+    static constexpr int tap_tp(int i) { return tap_code(i) & 3; }
+};
+
+template <class C>
+__global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
+    constexpr int PARTS = C::PARTS, NT = C::NT, IW = C::IW, PLANE = C::PLANE, XP = C::XP, NXP = C::NXP, WB = C::WB;
+    constexpr int W_SLOTS = C::W_SLOTS, STAGE = C::STAGE, CO_TILE = C::CO_TILE;
+    constexpr int NXW = (NXP + 3) / 4;                             // activation pieces per wave and part
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4* const smem = reinterpret_cast<uint4*>(smem_raw);
+    float* const sred = reinterpret_cast<float*>(smem + STAGE);       // [4 phases][WPX][CO_TILE][2]: stage buffer 1, free in the epilogue
+    static_assert(STAGE * 16 >= 4 * C::WPX * CO_TILE * 2 * 4, "statistics slots fit a stage buffer");
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int wpx = wave;
+    const int H = p.H, W = p.W, HW = H * W;
+    const int nchunks = p.nchunks, nreal = p.cin_pad >> 4;
+    const int co_tiles = p.co_tiles_phase;
+
+    // persistent workgroups over (image, pixel tile, cout tile), cout tile fastest (conv_bf16x3's order)
+    int tile, tile_end, tile_step;
+    {
+        const int G = gridDim.x, b = blockIdx.x;
+        const int nx = G < 8 ? G : 8;
+        const int xcd = b % nx, idx = b / nx;
+        const int ntl = p.N * p.tiles_y * p.tiles_x * co_tiles;
+        const int q = ntl / nx, r = ntl % nx;
+        const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile_step = (G - xcd + nx - 1) / nx;
+        tile = base + idx;
+        tile_end = base + q + (xcd < r ? 1 : 0);
+    }
+    if (tile >= tile_end) return;
+
+    // ---- DMA geometry of this lane: activation piece k of the wave covers slot (wave + 4k) * 64 + lane of a part
+    int pgeo[NXW];
+#pragma unroll
+    for (int k = 0; k < NXW; ++k) {
+        const int s = (wave + 4 * k) * 64 + lane;
+        const int kg = s >= PLANE ? 1 : 0;
+        const int pix = s - kg * PLANE;
+        const int ly = pix / IW, lx = pix - ly * IW;
+        pgeo[k] = (wave + 4 * k < NXP && s < 2 * PLANE) ? ((kg << 15) | (ly << 8) | lx) : -1;
+    }
+    struct TileId { int n, cot, ty, tx; };
+    auto locate = [&](int logical, TileId& t, int (&goff)[NXW]) __attribute__((always_inline)) {
+        t.cot = logical % co_tiles;
+        int t_ = logical / co_tiles;
+        t.tx = t_ % p.tiles_x;
+        t_ /= p.tiles_x;
+        t.ty = t_ % p.tiles_y;
+        t.n = t_ / p.tiles_y;
+        const int iy0 = t.ty * C::TH + C::base_d, ix0 = t.tx * 32 + C::base_d;
+#pragma unroll
+        for (int k = 0; k < NXW; ++k) {
+            int gy = iy0 + ((pgeo[k] >> 8) & 127), gx = ix0 + (pgeo[k] & 255);
+            bool ok = pgeo[k] >= 0;
+            if (p.pad_mode == 1) {
+                gy = reflect_clamp(gy, H);
+                gx = reflect_clamp(gx, W);
+            } else {
+                ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            }
+            goff[k] = (ok ? ((pgeo[k] >> 15) & 1) * (HW + 1) + gy * W + gx : HW) * 16;
+        }
+    };
+    auto seg_of = [&](int chunk) {
+        int s = 0;
+        if (p.nseg > 1 && chunk >= p.seg[1].chunk_begin) s = 1;
+        if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
+        return s;
+    };
+    // weight piece j = (tap i = j / PARTS of the list, part j % PARTS): its phase and byte offset inside the packed block
+    constexpr int NWJ = (C::NTAPS * PARTS + 3) / 4;
+    int wph[NWJ], wsrc[NWJ];
+#pragma unroll
+    for (int jj = 0; jj < NWJ; ++jj) {
+        const int j = jj * 4 + wave, i = j / PARTS, part = j - i * PARTS;
+        int code = 0, n = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (C::has(c >> 2, c & 3)) {
+                if (n == i) code = c;
+                ++n;
+            }
+        wph[jj] = code >> 2;
+        wsrc[jj] = (part * WB + (code & 3) * 64) * 16;
+    }
+    // one stage = the existing taps of the four phase blocks of (cout tile, chunk) + the activation tile of the chunk
+    auto issue = [&](const TileId& t, const int (&goff)[NXW], int chunk_, int buf) __attribute__((always_inline)) {
+        const int n = __builtin_amdgcn_readfirstlane(t.n), cot = __builtin_amdgcn_readfirstlane(t.cot);
+        chunk_ = __builtin_amdgcn_readfirstlane(chunk_);
+        const unsigned stage0 = lds0 + buf * STAGE * 16;
+        // weights: one 64-slot piece per (existing tap, part); piece j of the stage goes to wave j % 4
+#pragma unroll
+        for (int jj = 0; jj < NWJ; ++jj) {
+            const int j = jj * 4 + wave;
+            if (j < C::NTAPS * PARTS) {
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(
+                    p.wp + ((long long)(wph[jj] * co_tiles + cot) * nchunks + chunk_) * p.wfloats);
+                glds16_sv(src, (unsigned)(wsrc[jj] + lane * 16), stage0 + j * 64 * 16);
+            }
+        }
+        if (chunk_ < nreal) {                                       // (a padding chunk has zero weights: stale, finite data stays)
+            const int s = seg_of(chunk_);
+            const int cg0 = (chunk_ - p.seg[s].chunk_begin) * 2;
+            const int CG = p.seg[s].C >> 3;
+            const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
+#pragma unroll
+            for (int part = 0; part < PARTS; ++part) {
+                const unsigned char* xb = xs + ((long long)(n * 2 + part) * CG + cg0) * (HW + 1) * 16;
+#pragma unroll
+                for (int k = 0; k < NXW; ++k)
+                    if (wave + 4 * k < NXP)
+                        glds16_sv(xb, (unsigned)goff[k], stage0 + (W_SLOTS + part * XP + (wave + 4 * k) * 64) * 16);
+            }
+        }
+    };
+
+    f32x16 acc[4][NT];
+    TileId cur, nxt;
+    int cgoff[NXW], ngoff[NXW];
+    locate(tile, cur, cgoff);
+    issue(cur, cgoff, 0, 0);
+    for (;;) {
+        const bool has_next = tile + tile_step < tile_end;
+        locate(has_next ? tile + tile_step : tile, nxt, ngoff);
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][q][r] = 0.f;
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;                                  // (nchunks is even: every tile starts in buffer 0)
+            dma_wait_all();
+            __syncthreads();        // stage c has landed for every wave; nobody reads the other buffer any more
+            if (c + 1 < nchunks) issue(cur, cgoff, c + 1, buf ^ 1);
+            else if (has_next) issue(nxt, ngoff, 0, buf ^ 1);
+            const uint4* Wc = smem + buf * STAGE + half * CO_TILE + l32;
+            const uint4* Xc = smem + buf * STAGE + W_SLOTS + half * PLANE + (wpx * NT) * IW + l32;
+            // the taps that exist, in (phase, tap) order; the fragments of tap i + 1 are read while tap i multiplies
+            bf16x8 ah[2], al[2], xh[2][NT], xl[2][NT];
+            auto fetch = [&](int i, int fb) __attribute__((always_inline)) {
+                const int ph = C::tap_ph(i), tp = C::tap_tp(i);
+                const int toff = (C::org(ph >> 1) + (tp >> 1)) * IW + C::org(ph & 1) + (tp & 1);
+                ah[fb] = *reinterpret_cast<const bf16x8*>(Wc + (i * PARTS) * 64);
+                if constexpr (PARTS == 2) al[fb] = *reinterpret_cast<const bf16x8*>(Wc + (i * PARTS + 1) * 64);
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    xh[fb][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * IW);
+                    if constexpr (PARTS == 2) xl[fb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * IW);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int i = 0; i < C::NTAPS; ++i) {
+                const int fb = i & 1, ph = C::tap_ph(i);
+                if (i + 1 < C::NTAPS) fetch(i + 1, fb ^ 1);
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    if constexpr (PARTS == 2) {
+                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fb], xh[fb][q], acc[ph][q], 0, 0, 0);
+                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xl[fb][q], acc[ph][q], 0, 0, 0);
+                    }
+                    acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xh[fb][q], acc[ph][q], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue.  MFMA C/D layout: pixel column = lane & 31, cout row = (r & 3) + 8 (r >> 2) + 4 half.  The phases
+        // (phy, 0) and (phy, 1) are the even / odd output columns of one row: one 8-byte store per lane.
+        {
+            const int n = cur.n, cot = cur.cot;
+            const int ox = cur.tx * 32 + l32;
+            const bool want = p.stats != nullptr;
+            if (want) __syncthreads();          // every wave is done with the fragments of stage buffer 1: it holds sred now
+#pragma unroll
+            for (int phy = 0; phy < 2; ++phy)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int co = cot * CO_TILE + row;
+                    const bool cok = co < p.Cout;
+                    const float bv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+                    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const int oy = cur.ty * C::TH + wpx * NT + q;
+                        const bool inside = oy < p.OH && ox < p.OW;
+                        const float v0 = acc[phy * 2][q][r] + bv, v1 = acc[phy * 2 + 1][q][r] + bv;
+                        if (inside) { s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1; }
+                        if (inside && cok) {
+                            float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
+                                         (long long)(oy * 2 + phy) * p.o_rstride + ox * 2;
+                            *reinterpret_cast<float2*>(dst) = make_float2(apply_act(v0, p.act), apply_act(v1, p.act));
+                        }
+                    }
+                    if (want) {
+                        float v[4] = {s0, q0, s1, q1};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {               // sum over the 32 lanes of the half-wave
+                            v[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[k]), (1 << 10) | 0x1f));
+                            v[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[k]), (2 << 10) | 0x1f));
+                            v[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[k]), (4 << 10) | 0x1f));
+                            v[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[k]), (8 << 10) | 0x1f));
+                            v[k] += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v[k]), (16 << 10) | 0x1f));
+                        }
+                        if (l32 == 0) {
+                            float* d0 = sred + (((phy * 2) * C::WPX + wpx) * CO_TILE + row) * 2;
+                            float* d1 = sred + (((phy * 2 + 1) * C::WPX + wpx) * CO_TILE + row) * 2;
+                            d0[0] = v[0]; d0[1] = v[1];
+                            d1[0] = v[2]; d1[1] = v[3];
+                        }
+                    }
+                }
+            if (want) {
+                __syncthreads();
+                if (tid < 4 * CO_TILE) {
+                    const int ph = tid >> 5, c = tid & 31;
+                    const int co = cot * CO_TILE + c;
+                    if (co < p.Cout) {
+                        float s = 0.f, q2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < C::WPX; ++w) {
+                            s += sred[((ph * C::WPX + w) * CO_TILE + c) * 2];
+                            q2 += sred[((ph * C::WPX + w) * CO_TILE + c) * 2 + 1];
+                        }
+                        float* d = p.stats + (((long long)n * p.Cout + co) * p.stat_tiles + p.ph_stat[ph] + cur.ty * p.tiles_x + cur.tx) * 2;
+                        d[0] = s;
+                        d[1] = q2;
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+#pragma unroll
+        for (int k = 0; k < NXW; ++k) cgoff[k] = ngoff[k];
+        tile += tile_step;
+    }
+}
+
+}  // namespace apamd
