@@ -31,7 +31,7 @@ class ApConvDesc(ctypes.Structure):
                 ('transposed', ctypes.c_int32), ('output_padding', ctypes.c_int32),
                 ('w_layout', ctypes.c_int32), ('w_flip', ctypes.c_int32), ('act', ctypes.c_int32),
                 ('nsrc', ctypes.c_int32), ('precision', ctypes.c_int32),
-                ('presplit', ctypes.c_int32), ('reserved', ctypes.c_int32),
+                ('presplit', ctypes.c_int32), ('s2d_k', ctypes.c_int32),
                 ('src', ApSrc * 3)]
 
 

@@ -349,6 +349,8 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         // one pipeline stage = one 16-channel chunk; P = its LDS stage buffer (compile-time in each copy)
         auto stage = [&](auto ptag, int c) __attribute__((always_inline)) {
             constexpr int P = decltype(ptag)::value;
+            // taps of this stage: of the tile's phase, or (space-to-depth 3x3) of the chunk's input phase
+            const unsigned tm = (K == 0 && p.s2d_div > 0) ? p.s2d_mask[c / p.s2d_div < 3 ? c / p.s2d_div : 3] : tmask;
             constexpr int FP = (XPF && (TMAX & 1)) ? P : 0;        // register buffer of tap 0
             constexpr int WP = (XPF && (K & 1)) ? P : 0;           // window buffer of kx = 0
             if (!XPF || c == 0) {
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                     } else {
                         fetch(P, t + 1, cb ^ 1);
                     }
-                    if (K != 0 || ((tmask >> tp) & 1u)) {       // (an absent tap of a fused phase: zero weights, nothing to add)
+                    if (K != 0 || ((tm >> tp) & 1u)) {       // (an absent tap of a fused phase: zero weights, nothing to add)
 #pragma unroll
                     for (int i = 0; i < NM; ++i) mfma_one(i);
                     }
@@ -430,7 +432,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                     constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
                     constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
                     constexpr int R0 = NM - (NRD + RPS - 1) / RPS;              // first slot that carries reads
-                    const bool real_tap = K != 0 || ((tmask >> tp) & 1u);
+                    const bool real_tap = K != 0 || ((tm >> tp) & 1u);
 #pragma unroll
                     for (int i = 0; i < NM; ++i) {
                         if (real_tap) mfma_one(i);

@@ -906,6 +906,16 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 }
             }
             p.tap_bits = 0;
+            if (d->s2d_k == 3 && !d->transposed && pl.bk->K == 0 && d->KW == 2 && d->nsrc == 1 && d->src[0].C % 64 == 0 &&
+                !env_int("APAMD_NO_TAP_SKIP", 0)) {
+                // space-to-depth form of a 3x3 stride-2 layer: input phase (ry, rx) = 16-channel chunks [r C/16, (r+1) C/16)
+                p.s2d_div = d->src[0].C / 64;
+                for (int r = 0; r < 4; ++r) {
+                    p.s2d_mask[r] = 0;
+                    for (int t = 0; t < 4; ++t)
+                        if (2 * (t >> 1) + (r >> 1) <= 2 && 2 * (t & 1) + (r & 1) <= 2) p.s2d_mask[r] |= 1u << t;
+                }
+            }
             if (pl.bk->K == 0) {
                 if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);
                 for (int t = 0; t < p.ntaps; ++t)

@@ -72,6 +72,8 @@ struct ConvKParams {
     // ox_off / stat_tile_off with its table entry.  nphase <= 1: plain launch, the scalar fields above apply.
     int nphase, co_tiles_phase;
     int ph_dy0[4], ph_dx0[4], ph_oy[4], ph_ox[4], ph_stat[4];
+    int s2d_div;              // > 0: space-to-depth form of a 3x3 stride-2 layer -- chunk c belongs to input phase c / s2d_div,
+    unsigned s2d_mask[4];     // whose existing taps are s2d_mask[phase] (run-time-tap split-bf16 kernels skip the others)
     unsigned ph_tapmask[4];   // bit t: tap t of the 2 x 2 window exists in that phase (split-bf16 run-time-tap kernels skip
                               // the MFMAs of the others -- their weights are zero: 7 of the 16 taps of a fused 3x3 up-convolution)
 };

@@ -142,6 +142,7 @@ class ConvSpec:
         d.w_layout, d.w_flip, d.act = self.w_layout, int(self.w_flip), act
         d.nsrc = len(self.cin_segments)
         d.precision = self.precision
+        d.s2d_k = getattr(self, 's2d_k', 0)
         for i, c in enumerate(self.cin_segments):
             d.src[i].C = c
         if srcs is not None:
@@ -256,9 +257,14 @@ def presplit_rows(f, k, pad, pad_mode):
 
 
 def s2d_eligible(spec, h, w):
-    """4x4 stride-2 pad-1 layers with >= 32 input channels (PatchGAN body, networks.py:2620-2636) run as a 2x2
-    stride-1 split-bf16 convolution over the space-to-depth copy of their input."""
-    return (spec.precision != PRECISION_FP32 and spec.k == 4 and spec.stride == 2 and spec.pad == 1 and
+    """4x4 stride-2 pad-1 layers with >= 32 input channels (PatchGAN body, networks.py:2620-2636) -- and, in split-bf16
+    arithmetic, the 3x3 stride-2 encoder layers (7 of their 16 space-to-depth taps are zero and skipped, desc.s2d_k) --
+    run as a 2x2 stride-1 split-bf16 convolution over the space-to-depth copy of their input."""
+    # (3x3: split arithmetic only -- measured +1 % on the generator forward; in plain bf16 the stride-2 kernel already
+    # shares a CU with a second workgroup and the space-to-depth copy costs more than it saves: 60.3 -> 62.0 ms train step)
+    k_ok = spec.k == 4 or (spec.k == 3 and spec.precision == PRECISION_BF16X3 and spec.cin_segments[0] % 16 == 0 and
+                           not os.environ.get('APAMD_NO_S2D3'))
+    return (spec.precision != PRECISION_FP32 and k_ok and spec.stride == 2 and spec.pad == 1 and
             spec.pad_mode == PAD_ZERO and not spec.transposed and len(spec.cin_segments) == 1 and
             spec.cin_segments[0] >= 32 and spec.cin_segments[0] % 8 == 0 and spec.cout >= 48 and h % 2 == 0 and
             w % 2 == 0 and spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_S2D'))
@@ -267,12 +273,15 @@ def s2d_eligible(spec, h, w):
 def s2d_spec(spec):
     s = ConvSpec([4 * spec.cin_segments[0]], spec.cout, 2, 1, 0, PAD_ZERO)
     s.precision = spec.precision
+    s.s2d_k = 3 if spec.k == 3 else 0
     return s
 
 
 def s2d_weight(weight):
     """W[co][c][2 ty + ry][2 tx + rx] -> W'[co][(ry*2 + rx)*C + c][ty][tx]."""
-    co, c = weight.shape[:2]
+    co, c, k = weight.shape[:3]
+    if k == 3:                                   # a 3x3 layer: the fourth row / column of taps does not exist
+        weight = torch.nn.functional.pad(weight, (0, 1, 0, 1))
     return weight.reshape(co, c, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(co, 4 * c, 2, 2).contiguous()
 
 

@@ -81,7 +81,9 @@ typedef struct ap_conv_desc {
                            * pack_weights and fwd. */
     int32_t presplit;     /* 1: src[s].data are split tensors written by ap_split_prepass (mean/rstd/act already applied
                            * there and ignored here).  Required iff ap_conv2d_wants_presplit(d) == 1. */
-    int32_t reserved;
+    int32_t s2d_k;        /* 0, or 3: this 2x2 stride-1 layer over 4 C channels is the space-to-depth form of a 3x3
+                           * stride-2 pad-1 layer (networks.py:1221-1228 encoder): tap (ty, tx) of input phase (ry, rx) is
+                           * all-zero when 2 ty + ry > 2 or 2 tx + rx > 2, and the split-bf16 kernel skips it */
     ap_src src[3];
 } ap_conv_desc;
 
