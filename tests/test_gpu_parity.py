@@ -835,6 +835,8 @@ def test_conv_bf16x3_persistent_walk(dev, blocks, tall, monkeypatch):
     (128, 96, 3, 2, False, 38, 70),
     (256, 128, 3, 2, True, 16, 32),
     (64, 64, 4, 2, True, 20, 24),
+    (64, 48, 3, 2, True, 13, 21),                # conv_ph4: partial cout tile, phase grid not a multiple of the 8 x 32 tile
+    (96, 80, 4, 2, True, 9, 37),
 ])
 def test_conv_bf16x3_strided_and_transposed(dev, case):
     """Stride-2 3x3 and ConvTranspose2d (as sub-pixel phases) on the split-bf16 path, virtual (IN+ReLU) source."""
