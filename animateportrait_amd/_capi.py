@@ -49,7 +49,10 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
+ABI_VERSION = 3      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+
 SIGNATURES = {
+    'ap_abi_version': (ctypes.c_int32, []),
     'ap_version': (ctypes.c_char_p, []),
     'ap_last_error': (ctypes.c_char_p, []),
     'ap_conv2d_out_size': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ctypes.c_int32),
@@ -163,6 +166,9 @@ def lib():
                     fn = getattr(l, name)
                     fn.restype = res
                     fn.argtypes = args
+                if l.ap_abi_version() != ABI_VERSION:
+                    raise RuntimeError('animateportrait_amd: %s speaks ABI %d, this binding ABI %d: rebuild the library '
+                                       '(make -C animateportrait_amd/csrc)' % (LIB_PATH, l.ap_abi_version(), ABI_VERSION))
                 _lib = l
     return _lib
 

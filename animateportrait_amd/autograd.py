@@ -22,16 +22,27 @@ class Tape:
         self.block = None        # contiguous gradient block of the network (see grad_block), or None
         self.block_lo = 0
 
-    def grad_block(self, params):
+    def grad_block(self, params, needs=None):
         """When every trainable parameter of the network is a view of ONE optimiser's flat buffer (optim.FlatAdam) and
         the views are adjacent, the backward kernels write the parameter gradients straight into one contiguous block
         laid out like that range; the whole block is then added to the optimiser's flat gradient buffer with one launch
-        -- instead of one AccumulateGrad add per parameter and call (~200 launches per train step)."""
+        -- instead of one AccumulateGrad add per parameter and call (~200 launches per train step).
+
+        This bypasses autograd's own accumulation, so it is taken only when that is exactly what autograd would have
+        done: ``needs`` (ctx.needs_input_grad of the parameter positions) says the caller asked for the gradient of
+        EVERY trainable parameter -- ``torch.autograd.grad(loss, [input])`` / ``backward(inputs=...)`` must not touch
+        the optimiser's buffers -- and every ``p.grad`` still IS its view of the flat gradient buffer (after
+        ``module.zero_grad()`` / ``p.grad = None`` autograd would start from a fresh tensor, not add to stale sums)."""
         live = [p for p in params if p.requires_grad]
         if not live or any(getattr(p, '_flat_owner', None) is None for p in live):
             return False
+        if needs is not None and not all(n for p, n in zip(params, needs) if p.requires_grad):
+            return False
         owner = live[0]._flat_owner
         if any(p._flat_owner is not owner for p in live):
+            return False
+        base = owner.flat_grad.data_ptr()
+        if any(p.grad is None or p.grad.data_ptr() != base + 4 * p._flat_off for p in live):
             return False
         lo = min(p._flat_off for p in live)
         hi = max(p._flat_off + p.numel() for p in live)
@@ -253,7 +264,7 @@ class _NetFn(torch.autograd.Function):
                                'between forward and backward; its gradients would belong to different weights'
                                % type(ctx.net).__name__)
         with torch.no_grad():
-            direct = tape.grad_block(ctx.params)
+            direct = tape.grad_block(ctx.params, ctx.needs_input_grad[3 + ctx.n_inputs:])
             tape.add(ctx.out_feat, gout.contiguous(), 0)
             tape.backward()
             gin = [None] * ctx.n_inputs

@@ -529,7 +529,8 @@ using namespace apamd;
 
 extern "C" {
 
-const char* ap_version(void) { return "animateportrait_amd 0.1 (gfx950)"; }
+const char* ap_version(void) { return "animateportrait_amd 0.3 (gfx950)"; }
+int32_t ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return last_error_buf(); }
 
 int ap_conv2d_out_size(const ap_conv_desc* d, int32_t* Hout, int32_t* Wout) {

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, C::NA <= 20 ? 2 : 1) void wgrad_igemm_f32(cons
 
 // dW[i] = sum_s partial[s][i]   (fixed order)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, long long n, float* __restrict__ dw) {
-    if ((n & 3) == 0) {
+    // (dw may be a slot of a network's gradient block: 4-byte aligned only when an odd-sized parameter precedes it)
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0) {
         // 16-byte lanes, four partial buffers in flight per step (the sum order k = 0, 1, 2, ... is unchanged)
         const long long n4 = n >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(partial);

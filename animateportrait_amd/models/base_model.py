@@ -44,7 +44,13 @@ class BaseModel(ABC):
             self.schedulers = [networks.get_scheduler(o, opt) for o in self.optimizers]
         if not self.isTrain or opt.continue_train:
             load_suffix = 'iter_%d' % opt.load_iter if opt.load_iter > 0 else opt.epoch
-            self.load_networks(load_suffix)
+            try:
+                self.load_networks(load_suffix)
+            except FileNotFoundError:
+                # smoke mode only (--allow_random_init): the rest of setup -- broadcast, netF, summary -- still runs
+                if not getattr(opt, 'allow_random_init', False):
+                    raise
+                print('WARNING: --allow_random_init: no checkpoint found, the frames below come from RANDOM weights')
         # one process per GPU: every rank built (and randomly initialised) its own replica; start all of them from
         # rank 0's weights, as the reference's single replicated nn.DataParallel module does (networks.py:115-118)
         parallel.broadcast_model(self)

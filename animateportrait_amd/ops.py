@@ -63,13 +63,14 @@ class Feat:
     A convolution hands its InstanceNorm statistics over as per-tile partial sums (``pending``); they are
     finalised by whichever consumer comes first -- inside the fused norm/residual/split pass when that is the
     consumer (ap_norm_apply_split), by a standalone ap_instnorm_finalize when ``mean`` / ``rstd`` are read."""
-    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows')
+    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows', 'xs_heads_only')
 
     def __init__(self, data, mean=None, rstd=None, act=ACT_NONE, pending=None):
         self.data, self._mean, self._rstd, self.act = data, mean, rstd, act
         self.pending = pending   # (partials [N*C, tiles, 2], tiles) of the producing convolution, or None
         self.xs = None           # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
         self.xs_rows = None      # {(k, pad, pad_mode): row expansion for k x k stems (ap_split_prepass_rows)}
+        self.xs_heads_only = False   # the split copy was written without its tail planes (package mode plain bf16)
 
     @property
     def shape(self):
@@ -196,11 +197,16 @@ def pack_weights(spec, weight):
     return packed
 
 
-def presplit(f):
+def presplit(f, precision=None):
     """Split-bf16 copy of a (virtual) feature: XS[n][head|tail][C/8][H*W][8 x bf16] with the producer's
-    InstanceNorm + activation applied (ap_split_prepass).  Cached on the Feat: one pass serves every consumer."""
+    InstanceNorm + activation applied (ap_split_prepass).  Cached on the Feat: one pass serves every consumer.
+    precision: arithmetic of the consuming layer -- a bf16x3 consumer reads the tail planes, so a copy that was written
+    without them (package mode plain bf16 at the time) is refused instead of read uninitialised."""
     if f.xs is None:
         _norm_apply_split(f, None, want_y=False, want_xs=True)
+    if precision == PRECISION_BF16X3 and f.xs_heads_only:
+        raise RuntimeError('a split-bf16 (bf16x3) layer was handed a split copy written without its tail planes '
+                           '(made while the package mode was plain bf16)')
     return f.xs
 
 
@@ -344,6 +350,7 @@ def _norm_apply_split(f, residual, want_y, want_xs):
     f.pending = None
     if want_xs and residual is None:
         f.xs = xs
+        f.xs_heads_only = bool(flags & 1)
     return y, xs
 
 
@@ -384,7 +391,7 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
             raise RuntimeError('a split-bf16 (bf16x3) layer cannot run while the package mode is plain bf16: split copies '
                                'are then written without their tail planes')
         for i, f in enumerate(srcs):
-            d.src[i].data = presplit(f).data_ptr()
+            d.src[i].data = presplit(f, spec.precision).data_ptr()
             d.src[i].mean = d.src[i].rstd = None
             d.src[i].act = ACT_NONE
     else:
@@ -424,7 +431,7 @@ def _conv2d_view(spec, srcs, packed, out, view):
     d = spec.desc(n, h, w, None, ACT_NONE)
     d.presplit = 1
     for i, f in enumerate(srcs):
-        d.src[i].data = presplit(f).data_ptr()
+        d.src[i].data = presplit(f, spec.precision).data_ptr()
         d.src[i].mean = d.src[i].rstd = None
         d.src[i].act = ACT_NONE
     C.check(C.lib().ap_conv2d_fwd_view(ctypes.byref(d), ctypes.byref(view), _ptr(packed), None, _ptr(out), _stream()),
@@ -480,6 +487,7 @@ def materialize(f, residual=None, emit_xs=None):
         y, xs = _norm_apply_split(f, residual, want_y=True, want_xs=bool(emit_xs))
         out = Feat(y)
         out.xs = xs
+        out.xs_heads_only = xs is not None and DEFAULT_PRECISION == PRECISION_BF16
         return out
     x = f.data
     out = torch.empty_like(x)

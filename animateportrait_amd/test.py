@@ -17,12 +17,7 @@ def main(argv=None):
     torch.cuda.set_device(opt.gpu_ids[0])
     dataset = create_dataset(opt)
     model = create_model(opt)
-    try:
-        model.setup(opt)                       # loads '<epoch>_net_G_A.pth'; a missing file is an error, as in test.py:48
-    except FileNotFoundError:
-        if not opt.allow_random_init:
-            raise
-        print('WARNING: --allow_random_init: no checkpoint found, the frames below come from RANDOM weights')
+    model.setup(opt)       # loads '<epoch>_net_G_A.pth'; a missing file is an error (test.py:48) unless --allow_random_init
     if opt.eval:
         model.eval()
     out_dir = os.path.join(opt.results_dir, opt.name, '%s_%s' % (opt.phase, opt.epoch), opt.imagefolder)

@@ -87,6 +87,12 @@ typedef struct ap_conv_desc {
     ap_src src[3];
 } ap_conv_desc;
 
+/* Bumped whenever a signature or a descriptor field of this header changes meaning (round 2 inserted an argument in
+ * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
+ * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
+ * (animateportrait_amd/_capi.py does). */
+#define AP_ABI_VERSION 3
+int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
 
