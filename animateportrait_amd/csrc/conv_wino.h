@@ -66,6 +66,9 @@ __device__ __forceinline__ float wino_at(int i, int a) {
     return i == 0 ? (a < 3 ? 1.f : 0.f) : (a == 0 ? 0.f : (a == 1 ? 1.f : -1.f));
 }
 
+// ABL: experiment builds only (tools/wino_bench.hip): 1 no LDS-DMA, 2 no MFMAs, 4 no fold, 8 no output stores,
+// 16 weight stream only, 32 activation stream only
+template <int ABL = 0>
 __global__ __launch_bounds__(256, 1) void conv_wino(const WinoParams p) {
     using C = WinoCfg;
     constexpr int MT = C::MT, NT = C::NT, KG = C::KG, STAGE = C::STAGE, W_SLOTS = C::W_SLOTS;
@@ -121,6 +124,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino(const WinoParams p) {
         return d;
     };
     auto dma_piece = [&](const DmaCtx& d, int j) __attribute__((always_inline)) {
+        if (ABL & 1) return;
+        if ((ABL & 16) && j >= 4) return;
+        if ((ABL & 32) && j < 4) return;
         if (j < 4) glds16_sv(d.w + j * 1024, lane16, d.wdst + j * 1024);
         else if (j < 6) glds16_sv(d.x0 + (j - 4) * 1024, lane16, d.xdst + (j - 4) * 1024);
         else glds16_sv(d.x1 + (j - 6) * 1024, lane16, d.xdst + KG * C::PX_TILE * 16 + (j - 6) * 1024);
@@ -190,6 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino(const WinoParams p) {
             constexpr int P = decltype(ptag)::value;
             // product j of tile (m, q): small terms first
             auto mfma1 = [&](int fb, int m, int q, int j) __attribute__((always_inline)) {
+                if (ABL & 2) { M[m][q][j] += (float)ah[fb][m][0] * (float)bh[fb][q][0] + (float)al[fb][m][1] + (float)bl[fb][q][2]; return; }
                 if (j == 0) M[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fb][m], bh[fb][q], M[m][q], 0, 0, 0);
                 else if (j == 1) M[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb][m], bl[fb][q], M[m][q], 0, 0, 0);
                 else M[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb][m], bh[fb][q], M[m][q], 0, 0, 0);
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino(const WinoParams p) {
             auto fold = [&](int t) __attribute__((always_inline)) {
                 // the position is complete for tile t: fold M into the four output sets and clear it for the next one
                 const int m = t / NT, q = t % NT;
+                if (ABL & 4) { Y[0][0][m][q] = M[m][q]; return; }
                 if (c00 != 0.f) Y[0][0][m][q] += c00 * M[m][q];
                 if (c01 != 0.f) Y[0][1][m][q] += c01 * M[m][q];
                 if (c10 != 0.f) Y[1][0][m][q] += c10 * M[m][q];
@@ -275,7 +283,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino(const WinoParams p) {
                         const float v0 = Y[i][0][m][q][r] + bv, v1 = Y[i][1][m][q][r] + bv;
                         s[r] += v0 + v1;
                         sq[r] += v0 * v0 + v1 * v1;
-                        *reinterpret_cast<float2*>(dst + i * p.W) = make_float2(apply_act(v0, p.act), apply_act(v1, p.act));
+                        if (!(ABL & 8) || v0 == 123.456f)
+                            *reinterpret_cast<float2*>(dst + i * p.W) = make_float2(apply_act(v0, p.act), apply_act(v1, p.act));
                     }
                 }
             }

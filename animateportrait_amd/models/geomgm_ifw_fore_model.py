@@ -371,16 +371,37 @@ class GeomGMIFWForeModel(BaseModel):
         g_work = parallel.allreduce_optimizer_grads(self.optimizer_G, async_op=True)
         self.set_requires_grad(nets_D, True)
         self.optimizer_D.zero_grad()
+        # every discriminator's gradients start travelling as soon as its backward pass is enqueued (one collective per
+        # D over its slice of the flat gradient buffer), under the backward passes of the discriminators that follow
+        d_works, d_whole = [], False
+
+        def exchange(net):
+            nonlocal d_whole
+            w = parallel.allreduce_net_grads(self.optimizer_D, net)
+            if w is False:
+                d_whole = True              # no dense slice: one collective over the whole buffer at the end
+            elif w is not None:
+                d_works.append(w)
         self.backward_D_A()
+        exchange(self.netD_A)
         if o.use_mask:
             self.backward_D_A_l()
+            exchange(self.netD_A_l)
         if o.use_eye_mask:
             self.backward_D_A_le()
+            exchange(self.netD_A_le)
         if o.use_lip_mask:
             self.backward_D_A_ll()
+            exchange(self.netD_A_ll)
         if o.coherent:
             self.backward_D_A_coh()
+            exchange(self.netD_A_coh)
         parallel.wait_work(g_work)
         self.optimizer_G.step()
-        parallel.allreduce_optimizer_grads(self.optimizer_D)
+        if d_whole:
+            if d_works:
+                raise RuntimeError('optimizer_D: some discriminators have a dense gradient slice and some do not')
+            parallel.allreduce_optimizer_grads(self.optimizer_D)
+        for w in d_works:
+            parallel.wait_work(w)
         self.optimizer_D.step()

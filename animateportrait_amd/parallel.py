@@ -32,7 +32,14 @@ def init_distributed(backend=None):
     return rank, world, local
 
 
+# tests: True makes every helper below behave as at world size 1 (a single-process reference run of the same model
+# inside an initialised process group)
+DISABLED = False
+
+
 def world_size():
+    if DISABLED:
+        return 1
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
@@ -95,6 +102,50 @@ def allreduce_optimizer_grads(optimizer, params=None, async_op=False):
     allreduce_gradients(params if params is not None else
                         [p for g in optimizer.param_groups for p in g['params']])
     return None
+
+
+def net_grad_slice(optimizer, net):
+    """The contiguous range of a FlatAdam's flat gradient buffer that holds the gradients of ``net``'s parameters
+    (parameters of one network are adjacent: the optimiser is built over the concatenation of the networks' parameter
+    lists, geomgm_ifw_fore_model.py:346-360), or None when the optimiser keeps no flat buffer / the range is not dense."""
+    flat = getattr(optimizer, 'flat_grad', None)
+    ps = [p for p in net.parameters() if getattr(p, '_flat_owner', None) is optimizer]
+    if flat is None or not ps:
+        return None
+    lo = min(p._flat_off for p in ps)
+    hi = max(p._flat_off + p.numel() for p in ps)
+    if hi - lo != sum(p.numel() for p in ps):
+        return None
+    return flat[lo:hi]
+
+
+def allreduce_net_grads(optimizer, net, async_op=True):
+    """Mean over the ranks of ONE network's gradients inside a shared flat buffer, issued as soon as that network's
+    backward pass has been enqueued: the five discriminators' exchanges of a step (geomgm_ifw_fore_model.py:810-819)
+    travel under the backward passes of the discriminators that follow instead of as one exposed collective at the end.
+    Returns the work handle (None at world size 1), or False when the optimiser has no dense slice for the network
+    (the caller then falls back to allreduce_optimizer_grads)."""
+    if world_size() == 1:
+        return None
+    sl = net_grad_slice(optimizer, net)
+    if sl is None:
+        return False
+    return allreduce_flat_(sl, async_op=async_op)
+
+
+def reduce_losses(losses):
+    """Mean over the ranks of a dict of python floats with ONE small all-reduce (loss scalars for
+    logging every print_freq).  Every rank must call it with the same keys; returns the averaged dict on every rank."""
+    w = world_size()
+    if w == 1:
+        return dict(losses)
+    keys = list(losses.keys())
+    t = torch.tensor([float(losses[k]) for k in keys], dtype=torch.float64)
+    if dist.get_backend() == 'nccl':
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    t = (t / w).cpu()
+    return type(losses)((k, float(v)) for k, v in zip(keys, t))
 
 
 def broadcast_model(model, src=0):

@@ -34,11 +34,14 @@ def main(argv=None):
             total_iters += opt.batch_size
             model.set_input(data)
             model.optimize_parameters()
-            if total_iters % opt.print_freq < opt.batch_size and rank == 0:
+            if total_iters % opt.print_freq < opt.batch_size:
+                # every rank reads its shard's loss scalars; one small all-reduce makes the printed line the mean over
+                # the global batch (Module2/train.py:44-49 prints the losses of the whole nn.DataParallel batch)
                 torch.cuda.synchronize()
-                losses = model.get_current_losses()
-                print('(epoch: %d, iters: %d, time: %.3f) ' % (epoch, total_iters, (time.time() - t0) / opt.batch_size)
-                      + ' '.join('%s: %.3f' % kv for kv in losses.items()))
+                losses = parallel.reduce_losses(model.get_current_losses())
+                if rank == 0:
+                    print('(epoch: %d, iters: %d, time: %.3f) ' % (epoch, total_iters, (time.time() - t0) / opt.batch_size)
+                          + ' '.join('%s: %.3f' % kv for kv in losses.items()))
             if total_iters % opt.save_latest_freq < opt.batch_size and rank == 0:
                 model.save_networks('iter_%d' % total_iters if opt.save_by_iter else 'latest')
         if epoch % opt.save_epoch_freq == 0 and rank == 0:

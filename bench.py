@@ -11,10 +11,18 @@ or plainly as ``python bench.py --gpus N`` -- without WORLD_SIZE in the environm
 under torch.distributed.run with N ranks.  A world size that differs from --gpus is a hard error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying also
-  "roofline":     dominant kernel (conv_igemm_f32 instantiation with the largest total time),
-                  algorithmic FLOPs / HIP-event time on the launch stream vs the fp32 MFMA peak;
-  "cpu_baseline": the oracle (CPU restatement, kind "port") timed on this box's host cores on a
-                  bounded sample of the same workload.
+  "roofline":        the convolution kernel with the largest total time per step (today a split-bf16 matrix kernel:
+                     conv_wino / conv_bf16x3), HIP-event time on the launch stream; `achieved` = the bf16 MFMA FLOPs the
+                     kernel EXECUTES per second (3 per split product; Winograd: 16 products per 2x2 outputs), `peak` =
+                     the dense bf16 MFMA peak, `algorithmic_tflops` = 2 x MACs of the convolution per second;
+  "cpu_baseline":    the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the
+                     same workload;
+  "exact_fp32" / "plain_bf16_inference": the same step in the two other arithmetic modes (the strict-fp32 figure and the
+                     reduced-precision one; neither is `value`);
+  "train_step" / "train_step_bf16": the full geomgm_ifw_fore drawing-config step (all nine backward_G terms: the frozen
+                     aux nets are fixed-seed stand-ins, animateportrait_amd/standins.py), B=16 per GPU;
+  "stream":          BASELINE configs[4], the 10 s clip end to end (N=1 only);
+  "env_switches":    every APAMD_* variable that was set (they select alternative kernels; none skips work).
 """
 import argparse
 import json
@@ -124,7 +132,13 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
     with contextlib.redirect_stdout(io.StringIO()):      # the model prints its notices; keep stdout = one JSON line
         torch.manual_seed(1234)
         model = create_model(TrainOptions().parse(argv))
-        from animateportrait_amd import parallel
+        # the frozen third-party nets (MobileFaceNet, Sphere20a; checkpoints absent from the reference tree) as fixed-seed
+        # stand-ins with the same call contracts: the geometry and identity terms of backward_G
+        # (geomgm_ifw_fore_model.py:704-713, :741-752) -- window crop + bicubic / bilinear resize, both aux forwards and
+        # data gradients, FaceLoss -- are then INSIDE the timed step
+        from animateportrait_amd import parallel, standins, networks as _nets
+        model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
+        model.aux['faceloss'] = _nets.FaceLoss(standins.StandinFaceNet().to(dev))
         parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
         drift0 = parallel.replica_drift(model)
         batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
@@ -158,9 +172,11 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
             'dtype': 'f32 (split-bf16 products, fp32 accumulate)' if precision == 'bf16x3' else
                      'bf16 (bf16 products, fp32 accumulate, fp32 master weights)',
             'loss_G': round(losses.get('G', float('nan')), 4),
+            'losses': {k: round(v, 5) for k, v in losses.items()},
             'gflop_per_sample_algorithmic': 1234.0,
-            'note': 'geomgm_ifw_fore drawing config; frozen aux nets (MODNet/MobileFaceNet/Sphere20a/FlowUnet) absent '
-                    'from the reference tree: their outputs are synthetic inputs, geometry/identity terms skipped'}
+            'note': 'geomgm_ifw_fore drawing config, all nine backward_G terms in the timed region; the frozen landmark / '
+                    'identity nets (MobileFaceNet, Sphere20a: checkpoints absent from the reference tree) are fixed-seed '
+                    'stand-in aux nets (animateportrait_amd/standins.py); matte / intrinsic flow are synthetic batch inputs'}
 
 
 def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
@@ -256,6 +272,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32 comparison leg')
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
+    ap.add_argument('--no-stream', action='store_true', help='skip the 10 s clip sub-record (BASELINE configs[4]) of the default run')
     ap.add_argument('--stream', action='store_true',
                     help='BASELINE configs[4] instead of the default legs: wall-clock of a 10 s (625-frame) clip through the '
                          'in-process pipeline, next to the reference-style CPU path (prints its own JSON line)')
@@ -393,24 +410,24 @@ def main():
     # measured choice -- and the largest output difference between the two paths on this batch
     def other_precision_leg(precision, note):
         old = ops.DEFAULT_PRECISION
-        ops.DEFAULT_PRECISION = precision
-        try:
+        ops.DEFAULT_PRECISION = precision                        # the package mode stays set while the leg runs: it is
+        try:                                                     # what `--precision` gives (split copies, tail planes)
             with contextlib.redirect_stdout(io.StringIO()):
                 G2 = build_generator(dev)                        # same seed -> same weights
+            with torch.no_grad():
+                y2 = G2(*args)
+                diff = float((y2 - y).abs().max())
+                for _ in range(2):
+                    G2(*args)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n2 = min(a.steps, 5) if precision == ops.PRECISION_FP32 else a.steps
+                for _ in range(n2):
+                    G2(*args)
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t1) / n2
         finally:
             ops.DEFAULT_PRECISION = old
-        with torch.no_grad():
-            y2 = G2(*args)
-            diff = float((y2 - y).abs().max())
-            for _ in range(2):
-                G2(*args)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            n2 = min(a.steps, 5) if precision == ops.PRECISION_FP32 else a.steps
-            for _ in range(n2):
-                G2(*args)
-            torch.cuda.synchronize()
-            dt2 = (time.perf_counter() - t1) / n2
         return {'value': round(BATCH / dt2, 2), 'unit': 'frames/s per GPU', 'ms_per_step': round(dt2 * 1e3, 3),
                 'steps': n2, 'max_abs_diff_vs_headline_output': diff, 'note': note}
 
@@ -438,6 +455,12 @@ def main():
         finally:
             ops.DEFAULT_PRECISION = old
 
+    # ---- BASELINE configs[4]: the 10 s clip end to end, in the same JSON line (N = 1 only: one clip is one stream)
+    stream_rec = None
+    if world == 1 and not a.no_stream:
+        torch.cuda.empty_cache()
+        stream_rec = stream_leg(dev)
+
     if rank == 0:
         fps = world * BATCH * a.steps / dt
         out = {'metric': 'generator frames/sec @256x256 bs=16', 'value': round(fps, 2), 'unit': 'frames/s',
@@ -459,10 +482,19 @@ def main():
         if train is not None:
             out['train_step'] = train
         if train_bf16 is not None:
+            if train is not None:
+                # the nine backward_G terms (+ their sum) of the two arithmetic modes after the same steps on the same batch
+                gk = [k for k in train['losses'] if k.startswith('G') or k in ('geom_B', 'geom_B_lipline', 'warp_B',
+                                                                               'warp_inter1', 'iden_B')]
+                train_bf16['max_rel_loss_diff_vs_bf16x3'] = round(max(
+                    abs(train_bf16['losses'][k] - train['losses'][k]) / max(abs(train['losses'][k]), 1e-6) for k in gk), 5)
             out['train_step_bf16'] = train_bf16
+        if stream_rec is not None:
+            out['stream'] = stream_rec
         if cpu is not None:
             out['cpu_baseline'] = cpu
             out['speedup_vs_cpu'] = round(fps / world / cpu['value'], 1)
+        out['env_switches'] = {k: v for k, v in sorted(os.environ.items()) if k.startswith('APAMD_')}
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -139,26 +139,29 @@ def test_conv_bf16_backward_is_fp32_sum_of_bf16_products(dev, case):
         assert e16 < 3e-5, (name, 'stride-1 wgrad must run on the bf16 path', e16, eex)
 
 
-def test_train_step_bf16_mode_vs_fp64_oracle(dev, monkeypatch):
-    """The drawing-config train step (ngf=ndf=8, B=2) with every wide layer in plain-bf16 arithmetic against the fp64
-    oracle, at bf16-autocast tolerances: outputs within 3e-2 L-inf (the reference's own autocast(bf16) generator is
-    7.8e-2 from fp32, BASELINE.md), loss terms within 5 %, gradient direction (cosine) >= 0.98 on every large tensor;
-    fp32 master weights: one optimiser step moves the fp32 parameters by ~lr."""
+@pytest.mark.parametrize('width,nb', [(8, 2), (64, 1)])
+def test_train_step_bf16_mode_vs_fp64_oracle(dev, monkeypatch, width, nb):
+    """The drawing-config train step with every wide layer in plain-bf16 arithmetic against the fp64 oracle, at
+    bf16-autocast tolerances -- at ngf=ndf=8 / B=2 and at the FULL width the mode is timed at (BASELINE configs[2]:
+    ngf=ndf=64, B=1 here): outputs within 3e-2 L-inf (the reference's own autocast(bf16) generator is 7.8e-2 from fp32,
+    BASELINE.md), every loss term of backward_G and of the five D steps within 5 %, gradient direction (cosine) >= 0.98
+    on every large weight tensor of G AND of the five discriminators; fp32 master weights: one optimiser step moves the
+    fp32 parameters by ~lr.  Step order of the reference: geomgm_ifw_fore_model.py:782-819."""
     from animateportrait_amd import ops
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
     from oracle import generator as og, discriminator as od, train_step as ts
     import test_train_gpu as T
     monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_BF16)
     torch.manual_seed(0)
-    model, opt = T._make_model(dev)
+    model, opt = T._make_model(dev, width, width)
     assert model.netG_A.model_tri_merge.spec.precision == ops.PRECISION_BF16
-    sdG = og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=11)
+    sdG = og.init_params(og.generator_param_shapes(3, 1, width, 9, 3, 3), seed=11)
     model.netG_A.load_state_dict(sdG, strict=True)
     sdD, dnames = {}, ['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']
     for i, name in enumerate(dnames):
-        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, 8), seed=20 + i)
+        sdD[name] = og.init_params(od.patchgan_param_shapes(1 if name == 'D_A' else 2, width), seed=20 + i)
         getattr(model, 'net' + name).load_state_dict(sdD[name], strict=True)
-    batch = make_train_batch(2, seed=5)
+    batch = make_train_batch(nb, seed=5)
     model.set_input(batch)
     model.forward()
     nets_D = [getattr(model, 'net' + n) for n in model.model_names[1:]]
@@ -166,25 +169,48 @@ def test_train_step_bf16_mode_vs_fp64_oracle(dev, monkeypatch):
     model.optimizer_G.zero_grad()
     model.backward_G()
     gG = {k: p.grad.detach().clone().cpu().double() for k, p in model.netG_A.named_parameters()}
+    model.set_requires_grad(nets_D, True)
+    model.optimizer_D.zero_grad()
+    model.backward_D_A(); model.backward_D_A_l(); model.backward_D_A_le(); model.backward_D_A_ll(); model.backward_D_A_coh()
+    gD = {n: {k: p.grad.detach().clone().cpu().double() for k, p in getattr(model, 'net' + n).named_parameters()}
+          for n in dnames}
     ov = {k: getattr(model, k).detach().cpu().double() for k in ('mask1', 'mask2', 'fakeB_static_warp', 'fake_B_warp')}
+    # the D step is checked on the product's own generated frames (their parity is asserted below)
+    fakes = {k: getattr(model, k).detach().cpu().double() for k in ('fake_B', 'fake_B2', 'fake_B_l', 'fake_B2_l', 'fake_B_le',
+                                                                     'fake_B2_le', 'fake_B_ll', 'fake_B2_ll')}
     cast = lambda t: t.double() if torch.is_tensor(t) and t.is_floating_point() else t     # noqa: E731
     sG = {k: v.double().clone().requires_grad_(True) for k, v in sdG.items()}
-    sD = {n: {k: v.double() for k, v in sd.items()} for n, sd in sdD.items()}
+    sD = {n: {k: v.double().clone() for k, v in sd.items()} for n, sd in sdD.items()}
     b = {k: cast(v) for k, v in batch.items()}
     o = ts.forward(sG, b, overrides=ov)
     terms = ts.g_loss(sD, o, b, overrides=ov)
     terms['G'].backward()
+    for sd in sD.values():
+        for v in sd.values():
+            v.requires_grad_(True)
+    od_ = dict(o)
+    od_.update(fakes)
+    dl = ts.d_losses(sD, od_, b)
+    sum(dl.values()).backward()
     assert linf(model.fake_B_fore, o['fake_B_fore']) < 3e-2
     assert float((model.fake_B_fore.detach().cpu().double() - o['fake_B_fore']).abs().mean()) < 3e-3
     for k in ('G_A', 'G_A_l', 'G_A_le', 'G_A_ll', 'G_A_coh', 'geom_B_lipline', 'warp_B', 'warp_inter1', 'G'):
         a, t = float(getattr(model, 'loss_' + k)), float(terms[k])
         assert abs(a - t) <= 5e-2 * abs(t) + 1e-3, (k, a, t)
+    for name in dnames:
+        a, t = float(getattr(model, 'loss_' + name)), float(dl[name])
+        assert abs(a - t) <= 5e-2 * abs(t) + 1e-3, (name, a, t)
     worst = 1.0
     for k, v in sG.items():
         if k.endswith('.weight') and v.numel() >= 512:
             cos = float((gG[k] * v.grad).sum() / (gG[k].norm() * v.grad.norm()).clamp_min(1e-30))
             worst = min(worst, cos)
-            assert cos > 0.98, (k, cos)
+            assert cos > 0.98, ('G', k, cos)
+    for n in dnames:
+        for k, v in sD[n].items():
+            if k.endswith('.weight') and v.numel() >= 512:
+                cos = float((gD[n][k] * v.grad).sum() / (gD[n][k].norm() * v.grad.norm()).clamp_min(1e-30))
+                assert cos > 0.98, (n, k, cos)
     # fp32 master weights, finite step
     w0 = model.netG_A.model_tri_merge.weight.detach().clone()
     assert w0.dtype == torch.float32

@@ -1,0 +1,51 @@
+"""GPU (-m gpu): the data-parallel train step of the PRODUCT model with real collectives (BASELINE configs[3] as far as one
+GPU allows).  Two processes share cuda:0, gloo carries the collectives (tests/dp_worker.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_rank_optimize_parameters_matches_big_batch(tmp_path):
+    """Two ranks x B=2 through ``optimize_parameters`` (G all-reduce in flight under the five D backward passes, one
+    in-flight collective per discriminator, geomgm_ifw_fore_model.py:782-819) against ONE process on the B=4 batch:
+    * setup() broadcasts rank 0's weights (ranks were built from different seeds): drift > 0 before, == 0 after;
+    * the all-reduced mean gradients (read back from Adam's first moment after step 1) equal the big-batch gradients
+      tensor by tensor (2e-4 of each tensor's maximum: same per-sample arithmetic, different summation order);
+    * replicas stay bit-identical after two steps (drift == 0); the loss all-reduce returns finite means on both ranks."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dp_worker.py')
+    procs, outs = [], []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY='0')
+        out = str(tmp_path / ('rank%d.json' % r))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, worker, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors='replace')[-3000:])
+    assert all(p.returncode == 0 for p in procs), logs
+    for out in outs:
+        r = json.load(open(out))
+        assert r['drift_before_broadcast'] > 0.0 and r['drift_after_broadcast'] == 0.0, r
+        assert r['drift_after_step1'] == 0.0 and r['drift_after_step2'] == 0.0, r
+        assert r['losses_finite'] and r['n_losses'] >= 10, r
+        assert r['G_norm'] > 0 and r['G_rel'] < 5e-5 and r['D_rel'] < 5e-5, r
+        assert r['G_worst_tensor'] < 2e-4 and r['D_worst_tensor'] < 2e-4, r

@@ -156,3 +156,59 @@ def test_broadcast_initial_weights_and_dp_gradient_equivalence_world2():
         assert np.array_equal(a, b)
         r = ref.grad.numpy()            # (biases in front of InstanceNorm have pure rounding-noise gradients: atol)
         assert np.abs(a - r).max() <= 1e-4 * np.abs(r).max() + 1e-6, float(np.abs(a - r).max())
+
+
+# ------------------------------------------------------------------ per-network in-flight collectives, loss means
+def _slices_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import itertools
+    from collections import OrderedDict
+    from animateportrait_amd import parallel
+    from animateportrait_amd.optim import FlatAdam
+    parallel.init_distributed('gloo')
+    torch.manual_seed(7)                                        # same structure on every rank
+    nets = [torch.nn.Conv2d(1, 3, 3), torch.nn.Conv2d(2, 5, 1), torch.nn.Linear(4, 1)]
+    opt = FlatAdam(list(itertools.chain(*[n.parameters() for n in nets])), lr=1e-3)     # as optimizer_D: one buffer, five nets
+    g = torch.Generator().manual_seed(40 + rank)
+    opt.flat_grad.copy_(torch.randn(opt.flat_grad.shape, generator=g))
+    local = opt.flat_grad.clone()
+    works, lens = [], []
+    for n in nets:                                              # one collective per network, all in flight together
+        sl = parallel.net_grad_slice(opt, n)
+        lens.append(sl.numel())
+        works.append(parallel.allreduce_net_grads(opt, n))
+    for w in works:
+        parallel.wait_work(w)
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    ok_mean = bool(torch.allclose(opt.flat_grad, sum(both) / world, atol=1e-6))
+    # a network that is not (entirely) inside the optimiser has no slice
+    no_slice = parallel.allreduce_net_grads(opt, torch.nn.Conv2d(1, 1, 1))
+    parallel.DISABLED = True
+    off = parallel.allreduce_net_grads(opt, nets[0]) is None and parallel.world_size() == 1
+    parallel.DISABLED = False
+    losses = parallel.reduce_losses(OrderedDict([('G_A', 1.0 + rank), ('D_A', 10.0 * (rank + 1))]))
+    q.put((rank, ok_mean, lens, no_slice is False, off, list(losses.items())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_per_network_collectives_and_loss_means_world2():
+    """the discriminators' gradients travel as one in-flight collective per network over its slice
+    of the shared flat buffer; loss scalars for logging are averaged with one small all-reduce."""
+    world = 2
+    port = 30300 + random.randint(0, 300)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slices_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_mean, lens, no_slice, off, losses in res:
+        assert ok_mean and no_slice and off
+        assert lens == [3 * 9 + 3, 5 * 2 + 5, 4 + 1]
+        assert losses == [('G_A', 1.5), ('D_A', 15.0)]

@@ -34,7 +34,10 @@ using namespace apamd;
 
 static int reflect(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
 
-static void run_case(int N, std::vector<int> segC, int Cout, int H, int W, int pad_mode, bool stats, int iters) {
+template <int ABL>
+static const void* wino_fn() { return reinterpret_cast<const void*>(&conv_wino<ABL>); }
+
+static void run_case(int N, std::vector<int> segC, int Cout, int H, int W, int pad_mode, bool stats, int iters, bool ablate = false) {
     const int nseg = (int)segC.size();
     int Cin = 0;
     for (int c : segC) Cin += c;
@@ -101,14 +104,18 @@ static void run_case(int N, std::vector<int> segC, int Cout, int H, int W, int p
     p.N = N; p.H = H; p.W = W; p.TW = TW; p.T = T; p.Cout = Cout; p.kstages = kst;
     p.up = dup; p.bias = stats ? nullptr : db; p.act = 0; p.y = dy; p.stats = dstats; p.stat_tiles = stat_tiles;
     p.co_tiles = co_tiles; p.px_tiles = px_tiles;
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void* fns[] = {wino_fn<0>(), wino_fn<1>(), wino_fn<2>(), wino_fn<4>(), wino_fn<8>(), wino_fn<16>(), wino_fn<32>(), wino_fn<1 | 4>(), wino_fn<2 | 4 | 8>()};
+    const char* fnames[] = {"full", "no LDS-DMA", "no MFMA", "no fold", "no output stores", "weight stream only", "activation stream only",
+                            "no DMA, no fold (MFMA + fragment reads)", "DMA only (no MFMA / fold / stores)"};
+    for (const void* f : fns) CK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const void* fn = fns[0];
     int ncu = 256;
     CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
     int nblk = N * px_tiles * co_tiles;
     if (nblk > ncu) nblk = ncu;
     auto run_conv = [&]() {
         void* args[] = {&p};
-        CK(hipLaunchKernel(reinterpret_cast<const void*>(&conv_wino), dim3(nblk), dim3(256), args, WinoCfg::lds_bytes(), 0));
+        CK(hipLaunchKernel(fn, dim3(nblk), dim3(256), args, WinoCfg::lds_bytes(), 0));
     };
     for (int s = 0; s < nseg; ++s) run_input(s);
     CK(hipGetLastError());
@@ -184,6 +191,20 @@ static void run_case(int N, std::vector<int> segC, int Cout, int H, int W, int p
     const double exe = 2.0 * N * T * (double)co_tiles * 128 * kst * 32 * 16 * 3;
     printf("conv_wino: %.1f us   algorithmic %.1f TFLOP/s   executed %.1f TFLOP/s (bf16 MFMA)   L2->LDS %.2f TB/s\n", us,
            alg / us * 1e-6, exe / us * 1e-6, (double)N * px_tiles * co_tiles * 16 * kst * 32768.0 / us * 1e-6);
+    if (ablate) {
+        for (int v = 1; v < 9; ++v) {
+            fn = fns[v];
+            run_conv();
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < iters; ++i) run_conv();
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("   ablation %-44s %.1f us\n", fnames[v], ms * 1e3 / iters);
+        }
+        fn = fns[0];
+    }
     for (int s = 0; s < nseg; ++s) { CK(hipFree(dx[s])); CK(hipFree(dvs[s])); }
     CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(dy)); CK(hipFree(dup));
     if (dstats) CK(hipFree(dstats));
@@ -191,6 +212,10 @@ static void run_case(int N, std::vector<int> segC, int Cout, int H, int W, int p
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 16;
+    if (argc > 2) {                                           // profiling mode: the ResnetBlock layer only
+        run_case(N, {256}, 256, 64, 64, 1, true, 20, atoi(argv[2]) > 1);
+        return 0;
+    }
     run_case(2, {64}, 128, 32, 64, 1, true, 3);              // small: correctness of every path
     run_case(2, {64, 16, 16}, 128, 32, 64, 0, false, 3);
     run_case(N, {256}, 256, 64, 64, 1, true, 20);            // ResnetBlock conv (15 of the 22 launches)
