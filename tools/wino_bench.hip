@@ -1,6 +1,6 @@
-// wino_bench.hip -- go / no-go micro-benchmark of the Winograd F(2x2,3x3) split-bf16 path (csrc/conv_wino.h) at the
+// wino_bench.hip -- go / no-go micro-benchmark of the Winograd F(2x2,3x3) split-bf16 path (tools/conv_wino.h) at the
 // generator's trunk shapes, with a CPU spot check of the result.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ianimateportrait_amd/csrc tools/wino_bench.hip -o tools/wino_bench.bin
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Ianimateportrait_amd/csrc -Itools tools/wino_bench.hip -o tools/wino_bench.bin
 // Run on the GPU box: tools/wino_bench.bin [N=16]
 #include "conv_wino.h"
 

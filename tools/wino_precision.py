@@ -1,5 +1,5 @@
 """CPU emulation of the precision of Winograd F(2x2,3x3) on split-bf16 operands for the generator's wide 3x3
-stride-1 layers, against the exact-fp32 oracle (go / no-go input for csrc/conv_wino.h).
+stride-1 layers, against the exact-fp32 oracle (go / no-go input for tools/conv_wino.h).
 
 Every eligible F.conv2d of oracle.generator (3x3, stride 1, >= 256 input channels: the 15 + 3 + 3 ResNet-block
 convolutions and the merge convolution) is replaced by
