@@ -1,0 +1,101 @@
+"""GPU (-m gpu): the audio half of BASELINE configs[4] on the device -- both Module1 landmark networks and the
+``Audio2landmark_model.test`` post-processing against the reference-made golden (tests/golden/module1.npz), then the
+reference's example clip (tests/golden/female12.wav) from samples to frames: mel windows (animateportrait_amd/audio.py,
+pinned to the reference's own extraction on CPU) -> Module1 on the MI355X -> image landmarks -> ClipStreamer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import linf, GOLDEN
+
+sys.path.insert(0, GOLDEN)
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    return torch.device('cuda:0')
+
+
+def _nets(gd, dev):
+    from animateportrait_amd import module1 as m1
+    from test_stream_cpu import _seeded
+    netc = _seeded(m1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5), gd, 'c_', 78)
+    netg = _seeded(m1.Audio2LandmarkPos(drop_out=0.5), gd, 'g_', 79)
+    return netc.to(dev), netg.to(dev)
+
+
+def test_module1_networks_on_device_match_reference_golden(dev, golden):
+    """Module1/src/models/model_audio2landmark.py:28-90 (content) and :296-386 (speaker-aware) with seeded weights: the
+    device outputs against the outputs of the reference's own classes (CPU fp32)."""
+    gd = golden('module1.npz')
+    netc, netg = _nets(gd, dev)
+    with torch.no_grad():
+        c = netc(gd['au'].to(dev), gd['fid'].to(dev))[0]
+        pred, face, spk = netg(gd['au'].to(dev), gd['g_emb'].to(dev), gd['fid'].repeat(6, 1).to(dev), None,
+                               torch.zeros(6, 128, device=dev))
+    assert linf(c, gd['c_out']) < 2e-5 * float(gd['c_out'].abs().max()) + 1e-6
+    assert linf(pred, gd['g_out']) < 2e-5 * float(gd['g_out'].abs().max()) + 1e-6
+
+
+def test_module1_clip_pipeline_on_device_matches_reference_methods(dev, golden):
+    """predict_landmarks_speaker_aware on the device == the reference's ``test`` loop (600 windows, two segments,
+    train_audio2landmark.py:247-309) to 1e-4 of the landmark range."""
+    from animateportrait_amd import module1 as m1
+    gd = golden('module1.npz')
+    netc, netg = _nets(gd, dev)
+    gp = torch.Generator().manual_seed(int(gd['p_seed']))
+    au = torch.randn(int(gd['p_T']), 18, 80, generator=gp)
+    spk = torch.randn(256, generator=gp)
+    fl = m1.predict_landmarks_speaker_aware(netg, netc, au, spk, gd['fid'].view(-1))
+    ref = gd['p_sub'].numpy()
+    assert fl.shape == (600, 204) and np.abs(fl[::16] - ref).max() < 1e-4 * np.abs(ref).max()
+
+
+def test_example_clip_from_samples_to_frames(dev, golden):
+    """examples/female12.wav -> mel (62.5 frames/s) -> 18-frame windows -> Module1 (device) -> landmarks in image pixels ->
+    motion grids / landmark maps / generator (ClipStreamer).  Module1 on the device agrees with the same networks on the
+    CPU; the frames are those of the streamer driven by the CPU landmarks."""
+    import contextlib
+    import io
+    from animateportrait_amd import audio, module1 as m1, stream
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.synthetic import make_landmarks
+    gd = golden('module1.npz')
+    netc, netg = _nets(gd, dev)
+    w = audio.clip_audio_features(os.path.join(GOLDEN, 'female12.wav'), max_frames=64)
+    assert w.shape == (64, 18, 80)
+    spk = torch.randn(256, generator=torch.Generator().manual_seed(3))
+    fid = gd['fid'].view(-1)
+    fl = m1.predict_landmarks_speaker_aware(netg, netc, w, spk, fid)
+    fl_cpu = m1.predict_landmarks_speaker_aware(netg.cpu(), netc.cpu(), w, spk, fid)
+    assert fl.shape == (64, 204) and np.abs(fl - fl_cpu).max() < 1e-4 * np.abs(fl_cpu).max()
+
+    def to_pixels(f):
+        # Module1's normalised face -> displacements around the photo's landmarks (random weights do not draw a face: the
+        # motion of the prediction is kept, its mean shape replaced; main_end2end_module2.py:262-272 otherwise)
+        img = m1.to_image_landmarks(f, scale=0.01, shift=(-128.0, -128.0), rng=np.random.RandomState(0))[:, :, :2]
+        d = img - img.mean(0, keepdims=True)
+        return lm0.numpy()[None] + np.clip(d, -6.0, 6.0)
+    lm0 = make_landmarks(1, torch.Generator().manual_seed(9))[0]
+    seq, seq_cpu = to_pixels(fl), to_pixels(fl_cpu)
+    assert np.abs(seq - seq_cpu).max() < 2e-2            # px
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw',
+                               '--dataset_mode', 'synthetic', '--name', 'drawing_stream', '--output_nc', '1', '--ngf', '8',
+                               '--netg_resb_div', '3', '--netg_resb_disp', '3', '--gpu_ids', '0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(1)
+        model = create_model(opt)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
+    photo = torch.stack([torch.sin(3 * xx + yy), torch.cos(2 * yy - xx), xx * yy], 0).unsqueeze(0).contiguous()
+    matte = (((yy / 0.8) ** 2 + (xx / 0.6) ** 2) < 1).float().view(1, 1, 256, 256)
+    frames = stream.ClipStreamer(model, batch=16).run(photo, lm0, seq[:24], matte=matte)
+    assert frames.shape == (24, 1, 256, 256) and bool(torch.isfinite(frames).all()) and float(frames.std()) > 1e-3
+    frames_cpu = stream.ClipStreamer(model, batch=16).run(photo, lm0, seq_cpu[:24], matte=matte)
+    assert float((frames - frames_cpu).abs().mean()) < 1e-3

@@ -45,6 +45,8 @@ def test_clip_streamer_vs_oracle_frames():
     streamer = stream.ClipStreamer(model, batch=2)
     out = streamer.run(photo, lm0, seq, matte=matte, profile=True).cpu()
     assert out.shape == (5, 1, 256, 256) and set(streamer.timing) == {'motion_grid', 'landmark_maps', 'set_input_netF', 'generator'}
+    from animateportrait_amd import losses
+    n_bad, n_pix, worst_mean = 0, 0, 0.0
     with torch.no_grad():
         static = osg.static_drawing(sd_s, photo)
         a_lm = oa.draw2(256, 256, lm0.numpy(), 3).unsqueeze(0)
@@ -54,8 +56,24 @@ def test_clip_streamer_vs_oracle_frames():
             flow, ifm = oa.flow_network_warp(netF, photo, lm0.unsqueeze(0), seq[k:k + 1])
             fake, _, _, _ = osg.streaming_forward(lambda *a: og.generator_forward(sd_g, *a, div=3, disp=3), photo, matte,
                                                   static, a_lm, tb_lm, motion, flow, ifm)
+            # (1) the model on the ORACLE's motion grid (same sampling positions): the path's own budget, every pixel
+            data = {'A': photo.to(dev), 'warp_motion': motion.to(dev), 'A_lm': a_lm.to(dev), 'tB_lm': tb_lm.to(dev),
+                    'A_lm_68': lm0.view(1, 68, 2).to(dev), 'tB_lm_68': seq[k:k + 1].to(dev), 'matte': matte.to(dev),
+                    'image_paths': ['%05d' % k]}
+            model.set_input(data)
+            model.test()
+            assert linf(model.fake_B, fake) < 1e-3, (k, linf(model.fake_B, fake))
+            # (2) the streamer's frame (device motion rasteriser: grid within 2e-5 = 2.5e-3 px of scipy.griddata's,
+            # tests/test_gpu_parity.py).  The generated drawing has hard edges (mask > 0.5 thresholds in warp_acc_flow
+            # and in the blend), so a sampling position that moves by 1e-3 px flips isolated pixels: counted, not averaged
+            # away -- at most 0.05 % of the pixels of a frame may leave the 1e-3 budget, and the mean stays < 3e-4
             err = (out[k:k + 1] - fake).abs()
-            assert float(err.max()) < 2e-2 and float(err.mean()) < 3e-4, (k, float(err.max()), float(err.mean()))
+            n_bad += int((err > 1e-3).sum())
+            n_pix += err.numel()
+            worst_mean = max(worst_mean, float(err.mean()))
+            assert int((err > 1e-3).sum()) <= 0.0005 * err.numel(), (k, int((err > 1e-3).sum()), float(err.max()))
+            assert float(err.mean()) < 3e-4, (k, float(err.mean()))
+    print('stream vs oracle: %d of %d pixels beyond 1e-3 (device motion grid), worst frame mean %.2e' % (n_bad, n_pix, worst_mean))
     # same clip in one batch and without stage synchronisation: identical frames
     out2 = stream.ClipStreamer(model, batch=8).run(photo, lm0, seq, matte=matte).cpu()
     assert linf(out2, out) < 1e-4          # another batch size picks another tile shape: fp32 summation order
