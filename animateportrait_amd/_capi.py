@@ -49,7 +49,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 3      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 4      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -144,6 +144,11 @@ SIGNATURES = {
     'ap_landmark_discs': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
     'ap_circle_rows': (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    'ap_pixel_shuffle2': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p,
+                                         ctypes.c_void_p]),
+    'ap_lip_line_mask': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p,
+                                        ctypes.c_void_p]),
 }
 
 _lib = None

@@ -174,8 +174,13 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 return fail(AP_ERR_UNSUPPORTED, "2x2 kernels exist only as the space-to-depth form of a 4x4 stride-2 layer "
                                                 "(stride 1, pad 0, split-bf16 precision)");
             KT = 0;
+        } else if (K == 1) {
+            // 1x1 convolution (channel_mapping of the intrinsic-flow regressor, intrinsic_flow_models/networks.py:23-24):
+            // one run-time tap at offset (0, 0)
+            if (d->stride != 1 || d->pad != 0) return fail(AP_ERR_UNSUPPORTED, "1x1 kernels: stride 1, pad 0 only");
+            KT = 0;
         } else if (K != 3 && K != 4 && K != 7) {
-            return fail(AP_ERR_UNSUPPORTED, "kernel size %d (built: 3, 4, 7)", K);
+            return fail(AP_ERR_UNSUPPORTED, "kernel size %d (built: 1, 3, 4, 7)", K);
         }
         pl.Hout = (d->H + 2 * d->pad - K) / S + 1;
         pl.Wout = (d->W + 2 * d->pad - K) / S + 1;
@@ -278,7 +283,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 if ((tiles * 2 <= num_cus() || pl.Hout <= small->TH) && !env_int("APAMD_NO_SMALL_TILES", 0)) pl.bk = small;
             }
         }
-        if (KT == 0 && K != 2 && K != 3 && K != 4) pl.bk = nullptr;
+        if (KT == 0 && K != 1 && K != 2 && K != 3 && K != 4) pl.bk = nullptr;
     }
     if (pl.bk) {
         pl.bf3 = true;

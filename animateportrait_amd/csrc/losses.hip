@@ -303,6 +303,147 @@ __global__ __launch_bounds__(256) void landmark_discs_kernel(const float* __rest
 // (opencv-python 4.2.0.34 is what the reference pins, requirements.txt:2): err = 0, dx = r, dy = 0, plus = 1,
 // minus = 2r - 1; each step fills rows cy +- dy over [cx - dx, cx + dx] and rows cy +- dx over [cx - dy, cx + dy],
 // then dy++, err += plus, plus += 2, and when err > 0: err -= minus, dx--, minus -= 2.
+// ---- getlipline (Module2/models/geomgm_ifw_fore_model.py:507-515): the union of P0-P1 segments drawn by
+// cv2.line(mask, p0, p1, 255, thickness), thickness >= 2, LINE_8.  One lane per (sample, segment) runs OpenCV's own
+// integer algorithm (modules/imgproc/src/drawing.cpp, 4.2.0): ThickLine -> the quad p +- dp through FillConvexPoly at
+// 16.16 fixed point (outline by Line2, scanlines with the rounded edge slopes) + a filled Circle at both end points.
+// Restated in oracle/cv_raster.py with the source rules quoted; literal fixtures tests/golden/opencv_rules.json.
+// Lanes store the same value (1.0f), so overlapping segments need no ordering.  out must be zero on entry.
+struct LipPut {
+    float* img;
+    int H, W;
+    __device__ __forceinline__ void put(int x, int y) const {
+        if (x >= 0 && x < W && y >= 0 && y < H) img[y * W + x] = 1.f;
+    }
+    __device__ __forceinline__ void hline(int y, int x0, int x1) const {
+        if (y < 0 || y >= H) return;
+        x0 = x0 < 0 ? 0 : x0;
+        x1 = x1 >= W ? W - 1 : x1;
+        for (int x = x0; x <= x1; ++x) img[y * W + x] = 1.f;
+    }
+};
+
+__device__ static void lip_circle(const LipPut& o, int cx, int cy, int radius) {
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        o.hline(cy - dy, cx - dx, cx + dx);
+        o.hline(cy + dy, cx - dx, cx + dx);
+        o.hline(cy - dx, cx - dy, cx + dy);
+        o.hline(cy + dx, cx - dy, cx + dy);
+        ++dy;
+        err += plus;
+        plus += 2;
+        if (err > 0) { err -= minus; --dx; minus -= 2; }
+    }
+}
+
+__device__ static void lip_line2(const LipPut& o, long long x1, long long y1, long long x2, long long y2) {
+    constexpr int SH = 16;
+    constexpr long long ONE = 1 << SH;
+    long long dx = x2 - x1, dy = y2 - y1;
+    const long long ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    if (ax > ay) {
+        if (dx < 0) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dy = -dy; }
+        const long long y_step = (dy * ONE) / (ax | 1);            // C division: truncation toward zero
+        long long ecount = (x2 - x1) >> SH;
+        o.put((int)((x2 + (ONE >> 1)) >> SH), (int)((y2 + (ONE >> 1)) >> SH));
+        long long x = (x1 + (ONE >> 1)) >> SH, y = y1 + (ONE >> 1);
+        for (; ecount >= 0; --ecount) { o.put((int)x, (int)(y >> SH)); ++x; y += y_step; }
+    } else {
+        if (dy < 0) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dx = -dx; }
+        const long long x_step = (dx * ONE) / (ay | 1);
+        long long ecount = (y2 - y1) >> SH;
+        o.put((int)((x2 + (ONE >> 1)) >> SH), (int)((y2 + (ONE >> 1)) >> SH));
+        long long x = x1 + (ONE >> 1), y = (y1 + (ONE >> 1)) >> SH;
+        for (; ecount >= 0; --ecount) { o.put((int)(x >> SH), (int)y); x += x_step; ++y; }
+    }
+}
+
+__device__ static void lip_fill_quad(const LipPut& o, const long long (&vx)[4], const long long (&vy)[4]) {
+    constexpr int SH = 16, NP = 4;
+    constexpr long long ONE = 1 << SH, delta = ONE >> 1;
+    int imin = 0;
+    long long ymin = vy[0], ymax = vy[0], xmin = vx[0], xmax = vx[0];
+    long long px = vx[NP - 1], py = vy[NP - 1];
+    for (int i = 0; i < NP; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        ymax = vy[i] > ymax ? vy[i] : ymax;
+        xmax = vx[i] > xmax ? vx[i] : xmax;
+        xmin = vx[i] < xmin ? vx[i] : xmin;
+        lip_line2(o, px, py, vx[i], vy[i]);
+        px = vx[i]; py = vy[i];
+    }
+    xmin = (xmin + delta) >> SH; xmax = (xmax + delta) >> SH;
+    ymin = (ymin + delta) >> SH; ymax = (ymax + delta) >> SH;
+    if (xmax < 0 || ymax < 0 || xmin >= o.W || ymin >= o.H) return;
+    if (ymax > o.H - 1) ymax = o.H - 1;
+    int e_idx[2] = {imin, imin}, e_di[2] = {1, NP - 1};
+    long long e_x[2] = {-ONE, -ONE}, e_dx[2] = {0, 0}, e_ye[2] = {ymin, ymin};
+    int edges = NP;
+    long long y = ymin;
+    for (;;) {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= e_ye[i]) {
+                int idx0 = e_idx[i];
+                const int di = e_di[i];
+                int idx = (idx0 + di) % NP;
+                for (;;) {
+                    if (--edges < 0) break;
+                    const long long ty = (vy[idx] + delta) >> SH;
+                    if (ty > y) {
+                        const long long xs = vx[idx0], xe = vx[idx];
+                        e_ye[i] = ty;
+                        e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        e_x[i] = xs;
+                        e_idx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx = (idx + di) % NP;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            const int l = e_x[0] > e_x[1] ? 1 : 0, r = 1 - l;
+            const long long xx1 = (e_x[l] + delta) >> SH, xx2 = (e_x[r] + delta) >> SH;
+            if (xx2 >= 0 && xx1 < o.W) o.hline((int)y, (int)xx1, (int)xx2);
+        }
+        e_x[0] += e_dx[0];
+        e_x[1] += e_dx[1];
+        if (++y > ymax) break;
+    }
+}
+
+struct LipSegs { int a[32], b[32]; };
+
+__global__ void lip_line_kernel(const float* __restrict__ lands, int P, LipSegs segs, int nseg, int N, int S, int thickness,
+                                float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * nseg) return;
+    const int n = t / nseg, s = t - n * nseg;
+    const float* l = lands + (long long)n * P * 2;
+    // the Python binding truncates the float coordinates to int
+    const long long x0 = (long long)(int)l[segs.a[s] * 2] << 16, y0 = (long long)(int)l[segs.a[s] * 2 + 1] << 16;
+    const long long x1 = (long long)(int)l[segs.b[s] * 2] << 16, y1 = (long long)(int)l[segs.b[s] * 2 + 1] << 16;
+    LipPut o{out + (long long)n * S * S, S, S};
+    const double dx = (double)(x0 - x1) * (1.0 / 65536.0), dy = (double)(y1 - y0) * (1.0 / 65536.0);
+    double r = dx * dx + dy * dy;
+    const int odd = thickness & 1;
+    const long long tf = (long long)thickness << 15;
+    if (fabs(r) > 2.220446049250313e-16) {
+        r = ((double)tf + odd * 65536.0 * 0.5) / sqrt(r);
+        const long long dpx = (long long)rint(dy * r), dpy = (long long)rint(dx * r);       // cvRound
+        const long long vx[4] = {x0 + dpx, x0 - dpx, x1 - dpx, x1 + dpx};
+        const long long vy[4] = {y0 + dpy, y0 - dpy, y1 - dpy, y1 + dpy};
+        lip_fill_quad(o, vx, vy);
+    }
+    const int rad = (int)((tf + 32768) >> 16);
+    lip_circle(o, (int)((x0 + 32768) >> 16), (int)((y0 + 32768) >> 16), rad);
+    lip_circle(o, (int)((x1 + 32768) >> 16), (int)((y1 + 32768) >> 16), rad);
+}
+
+
 static DiscRows circle_rows(int r) {
     DiscRows t;
     for (int i = 0; i <= kMaxDiscRadius; ++i) t.hw[i] = -1;
@@ -446,6 +587,24 @@ int ap_landmark_discs(const float* lm, int32_t N, int32_t P, int32_t H, int32_t 
     hipLaunchKernelGGL(landmark_discs_kernel, dim3((H * W + 255) / 256, N), dim3(256), 2 * P * sizeof(int),
                        (hipStream_t)stream, lm, P, H, W, radius, circle_rows(radius), lo, hi, out);
     return check_launch("landmark_discs_kernel");
+}
+
+int ap_lip_line_mask(const float* lands, int32_t N, int32_t P, const int32_t* seg_a, const int32_t* seg_b, int32_t nseg,
+                     int32_t size, int32_t thickness, float* out, ap_stream_t stream) {
+    if (!lands || !seg_a || !seg_b || !out) return fail(AP_ERR_INVALID, "lip_line_mask: null pointer");
+    if (N < 1 || P < 1 || nseg < 1 || nseg > 32 || size < 1 || thickness < 2 || thickness > 16)
+        return fail(AP_ERR_INVALID, "lip_line_mask: bad sizes (1..32 segments, thickness 2..16)");
+    LipSegs sg;
+    for (int i = 0; i < nseg; ++i) {
+        if (seg_a[i] < 0 || seg_a[i] >= P || seg_b[i] < 0 || seg_b[i] >= P) return fail(AP_ERR_INVALID, "lip_line_mask: segment %d out of range", i);
+        sg.a[i] = seg_a[i];
+        sg.b[i] = seg_b[i];
+    }
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)N * size * size * sizeof(float), (hipStream_t)stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "lip_line_mask: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(lip_line_kernel, dim3((N * nseg + 63) / 64), dim3(64), 0, (hipStream_t)stream, lands, P, sg, nseg, N, size,
+                       thickness, out);
+    return check_launch("lip_line_kernel");
 }
 
 /* host-side table of the filled-circle rows (what ap_landmark_discs rasterises): hw[d], d = 0..radius */

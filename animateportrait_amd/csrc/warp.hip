@@ -717,3 +717,28 @@ extern "C" int ap_warp_concat_fwd(const float* x, const float* x_mean, const flo
     return ap_warp_concat_fwd_split(x, x_mean, x_rstd, x_act, motion, flow, ifmask, out, nullptr, N, C, H, W, S,
                                     flow_scale, stream);
 }
+
+
+// ---- nn.PixelShuffle(2) (the decoder upsampling of FlowUnet_v2, Module2/intrinsic_flow_models/networks.py:693-698):
+//   y[n][c][2 h + i][2 w + j] = x[n][4 c + 2 i + j][h][w]
+// One lane per OUTPUT pixel pair (two x-neighbours = channels 4c + 2i, 4c + 2i + 1 at the same input pixel): 8-byte stores,
+// coalesced 4-byte loads from two planes.  grid: (ceil(H * W / 256), 2 * C, N)  (y index = c * 2 + i)
+namespace apamd {
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* __restrict__ x, float* __restrict__ y, int C, int H, int W) {
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= H * W) return;
+    const int c = blockIdx.y >> 1, i = blockIdx.y & 1, n = blockIdx.z;
+    const int h = pix / W, w = pix - h * W;
+    const float* px = x + ((long long)n * 4 * C + 4 * c + 2 * i) * H * W + pix;
+    const float a = px[0], b = px[(long long)H * W];
+    *reinterpret_cast<float2*>(y + (((long long)n * C + c) * 2 * H + 2 * h + i) * 2 * W + 2 * w) = make_float2(a, b);
+}
+}  // namespace apamd
+
+extern "C" int ap_pixel_shuffle2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float* y, ap_stream_t stream) {
+    using namespace apamd;
+    if (!x || !y) return fail(AP_ERR_INVALID, "pixel_shuffle2: null pointer");
+    if (N < 1 || N > 65535 || C < 1 || 2 * C > 65535 || H < 1 || W < 1) return fail(AP_ERR_INVALID, "pixel_shuffle2: bad sizes");
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3((H * W + 255) / 256, 2 * C, N), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W);
+    return check_launch("pixel_shuffle2_kernel");
+}

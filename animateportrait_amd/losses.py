@@ -251,6 +251,20 @@ def landmark_discs(lm, height, width, radius=3, lo=-1.0, hi=1.0):
     return out
 
 
+def lip_line_mask(lands, segments, size, thickness):
+    """getlipline (geomgm_ifw_fore_model.py:507-515) for a batch: lands (N, P, 2) device (x, y) -> (N, 1, size, size) in
+    {0, 1}: the union of cv2.line(..., thickness) over ``segments`` (pairs of landmark indices), OpenCV's integer rule."""
+    lands = lands.detach().float().contiguous()
+    _require_device(lands, 'landmarks')
+    n, p, _ = lands.shape
+    k = len(segments)
+    a = (ctypes.c_int32 * k)(*[int(s[0]) for s in segments])
+    b = (ctypes.c_int32 * k)(*[int(s[1]) for s in segments])
+    out = torch.empty((n, 1, size, size), dtype=torch.float32, device=lands.device)
+    C.check(C.lib().ap_lip_line_mask(_ptr(lands), n, p, a, b, k, size, int(thickness), _ptr(out), _stream()), 'lip_line_mask')
+    return out
+
+
 def circle_rows(radius):
     """Row half-widths hw[0..radius] of the filled cv2.circle the rasteriser draws (host-side, no GPU needed)."""
     hw = (ctypes.c_int32 * (radius + 1))()

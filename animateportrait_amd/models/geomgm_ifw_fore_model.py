@@ -136,18 +136,9 @@ class GeomGMIFWForeModel(BaseModel):
         self.process = (epoch - 1) / float(self.opt.niter_decay + self.opt.niter)
 
     def getlipline(self, lands):
-        """:507-515 (cv2.line, thickness 2, value 1) restated as a distance-to-segment test, per sample."""
-        cs = self.opt.crop_size
-        yy = torch.arange(cs, device=self.device, dtype=torch.float32).view(1, 1, cs, 1)
-        xx = torch.arange(cs, device=self.device, dtype=torch.float32).view(1, 1, 1, cs)
-        idx0 = torch.tensor([a for a, _ in LIP_SEGMENTS], device=self.device)
-        idx1 = torch.tensor([b for _, b in LIP_SEGMENTS], device=self.device)
-        p0, p1 = lands[:, idx0].float(), lands[:, idx1].float()                  # (B, 20, 2) as (x, y)
-        ax, ay = p0[..., 0, None, None], p0[..., 1, None, None]
-        dx, dy = (p1 - p0)[..., 0, None, None], (p1 - p0)[..., 1, None, None]
-        t = (((xx - ax) * dx + (yy - ay) * dy) / (dx * dx + dy * dy).clamp_min(1e-6)).clamp(0, 1)
-        dist2 = (xx - ax - t * dx) ** 2 + (yy - ay - t * dy) ** 2
-        return (dist2 <= (self.thickness / 2.0 + 0.5) ** 2).any(dim=1, keepdim=True).float()
+        """:507-515: the 20 lip segments drawn with cv2.line(thickness 2 at 256 px, 4 at 512 px, value 1), per sample --
+        OpenCV's ThickLine rule run on the device (ap_lip_line_mask; restated with its source in oracle/cv_raster.py)."""
+        return losses.lip_line_mask(lands.to(self.device), LIP_SEGMENTS, self.opt.crop_size, self.thickness)
 
     def get_lm(self, x, win, out_size=112):
         """:390-415, per sample: window crop into a ones-filled box, BGR / x3 channels, bicubic (align_corners=False)

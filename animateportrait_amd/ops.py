@@ -543,6 +543,17 @@ def resize_bilinear(x, size):
     return y
 
 
+def pixel_shuffle2(x):
+    """nn.PixelShuffle(2) (intrinsic_flow_models/networks.py:696): (N, 4C, H, W) -> (N, C, 2H, 2W)."""
+    _require_device(x, 'pixel_shuffle input')
+    n, c4, h, w = x.shape
+    if c4 % 4:
+        raise ValueError('pixel_shuffle2: %d channels' % c4)
+    y = torch.empty((n, c4 // 4, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    C.check(C.lib().ap_pixel_shuffle2(_ptr(x), n, c4 // 4, h, w, _ptr(y), _stream()), 'pixel_shuffle2')
+    return y
+
+
 def grid_sample(x, grid, align_corners=False):
     """F.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=...) (geomcgt_ifw_test_model.py:294)."""
     _require_device(x, 'grid_sample input')

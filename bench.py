@@ -188,7 +188,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     import contextlib
     import io
     import tempfile
-    from animateportrait_amd import standins, stream, module1
+    from animateportrait_amd import standins, stream, module1, audio
     from animateportrait_amd.options.base_options import TestOptions
     from animateportrait_amd.models import create_model
     from animateportrait_amd.synthetic import make_landmarks
@@ -209,7 +209,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     lm0 = make_landmarks(1, g)[0]
     t = torch.arange(frames).view(frames, 1, 1).float()
     seq = lm0.unsqueeze(0) + 3.0 * torch.sin(0.1 * t + lm0.unsqueeze(0) / 40.0)
-    au = torch.randn(frames, 18, 80, generator=g)
+    wav = os.path.join(ROOT, 'tests', 'golden', 'female12.wav')      # the reference's example clip (examples/female12.wav)
     fid = torch.randn(204, generator=g) * 0.1
     streamer = stream.ClipStreamer(model, batch=batch)
 
@@ -217,6 +217,9 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
         # Module1 over the whole clip: both networks + the landmark post-processing of Audio2landmark_model.test and
         # main_end2end_module2.py:262-272 (timed; its output is not fed on -- random weights do not draw faces -- the
         # synthetic sequence of the same length is)
+        # audio front end on the host, as in the reference: wav -> loudness -> mel (62.5 frames/s) -> 18-frame windows
+        au = audio.clip_audio_features(wav, max_frames=frames)
+        assert au.shape == (frames, 18, 80)
         fl = module1.predict_landmarks_speaker_aware(pose, content, au, spk, fid)
         module1.to_image_landmarks(fl, scale=0.01, shift=(-128.0, -128.0), rng=np.random.RandomState(0))
         return streamer.run(photo, lm0, seq, matte=matte, profile=profile)
@@ -260,8 +263,9 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
                                        'maps, netF pre/post, static drawing @512^2, generator, blend; batch 1'},
             'speedup_vs_cpu': round(cpu_s * frames / wall, 1),
             'note': 'random-init weights; stand-in netF and matte; Module1 = both landmark networks (content + speaker-aware '
-                    'pose branch) and their post-processing on synthetic mel windows / speaker embedding: the AutoVC front end '
-                    'and the checkpoints are absent from the reference tree'}
+                    'pose branch) and their post-processing on the mel windows of the reference\'s example clip '
+                    '(tests/golden/female12.wav; mel stage inside the timed region); synthetic speaker embedding; the AutoVC '
+                    'converter, RAPT f0 and the checkpoints are absent from the reference tree'}
 
 
 def main():

@@ -91,7 +91,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 3
+#define AP_ABI_VERSION 4
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -348,6 +348,17 @@ int ap_kp_to_map(const float* lm, int32_t N, int32_t P, int32_t S, float num, fl
  * flow_out N x 2 x OS x OS, mask_out N x 1 x OS x OS.  Reference values: gain 20, num/den = 8/7, S 224, OS 256. */
 int ap_flow_post(const float* flow, const float* vis, int32_t N, int32_t VC, int32_t S, int32_t OS, float gain, float num,
                  float den, float* flow_out, float* mask_out, ap_stream_t stream);
+/* nn.PixelShuffle(2): x (N, 4 C, H, W) -> y (N, C, 2 H, 2 W), y[n][c][2h+i][2w+j] = x[n][4c+2i+j][h][w]
+ * (decoder upsampling of FlowUnet_v2, Module2/intrinsic_flow_models/networks.py:693-698). */
+int ap_pixel_shuffle2(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float* y, ap_stream_t stream);
+
+/* getlipline (Module2/models/geomgm_ifw_fore_model.py:507-515): out[n] (size x size, {0, 1}) = union over the segments
+ * (seg_a[i], seg_b[i]) of cv2.line(mask, lands[n][a], lands[n][b], 255, thickness) -- OpenCV 4.2 ThickLine (quad through
+ * FillConvexPoly at 16.16 fixed point + a filled circle at both ends), float coordinates truncated to int as the Python
+ * binding does.  lands: device (N, P, 2) as (x, y); seg_a / seg_b: HOST arrays of nseg <= 32 landmark indices;
+ * thickness 2..16.  replaces the numpy + cv2 loop of getlipline (one launch + one memset). */
+int ap_lip_line_mask(const float* lands, int32_t N, int32_t P, const int32_t* seg_a, const int32_t* seg_b, int32_t nseg,
+                     int32_t size, int32_t thickness, float* out, ap_stream_t stream);
 /* draw2(op=0) (Module2/data/umlvdfw_test_dataset.py:34-41): filled cv2.circle(radius) at np.round(lm) for every
  * landmark; out N x 1 x H x W = hi inside / lo outside (the reference: +1 / -1).  The disc is OpenCV's octant-walk
  * fill (drawing.cpp Circle(), opencv-python 4.2 pinned by requirements.txt:2), whose row half-widths

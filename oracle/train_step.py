@@ -19,6 +19,7 @@ The reference model class itself cannot be instantiated here (cv2, .cuda(), abse
 section 8c); the pieces this composition is made of (G, D, GANLoss, masked, sparse_image_warp) are each pinned to
 goldens captured from the reference.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -52,18 +53,12 @@ LIP_SEGMENTS = [(i, i + 1) for i in range(48, 59)] + [(59, 48)] + [(i, i + 1) fo
 
 
 def lipline(lands, size, thickness):
-    """getlipline (:507-515): union of the 20 lip segments drawn with cv2.line(thickness) -- restated as a
-    distance-to-segment test (pixels within thickness/2 + 0.5 of a segment)."""
-    yy = torch.arange(size, dtype=torch.float32).view(1, 1, size, 1)
-    xx = torch.arange(size, dtype=torch.float32).view(1, 1, 1, size)
-    i0 = torch.tensor([a for a, _ in LIP_SEGMENTS])
-    i1 = torch.tensor([b for _, b in LIP_SEGMENTS])
-    p0, p1 = lands[:, i0].float(), lands[:, i1].float()
-    ax, ay = p0[..., 0, None, None], p0[..., 1, None, None]
-    dx, dy = (p1 - p0)[..., 0, None, None], (p1 - p0)[..., 1, None, None]
-    t = (((xx - ax) * dx + (yy - ay) * dy) / (dx * dx + dy * dy).clamp_min(1e-6)).clamp(0, 1)
-    d2 = (xx - ax - t * dx) ** 2 + (yy - ay - t * dy) ** 2
-    return (d2 <= (thickness / 2.0 + 0.5) ** 2).any(dim=1, keepdim=True).float()
+    """getlipline (:507-515): union of the 20 lip segments drawn with cv2.line(thickness), per sample, by OpenCV's
+    ThickLine rule as restated in oracle/cv_raster.py (float landmark coordinates truncated to int)."""
+    from . import cv_raster
+    ln = lands.detach().cpu().double().numpy()
+    m = np.stack([cv_raster.lip_line_mask(size, ln[i], LIP_SEGMENTS, thickness) for i in range(ln.shape[0])])
+    return torch.from_numpy(m).to(lands.dtype if lands.dtype.is_floating_point else torch.float32).unsqueeze(1)
 
 
 def warp_nchw(img, src_xy, dst_xy):

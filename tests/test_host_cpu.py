@@ -164,3 +164,29 @@ def test_ganloss_and_scheduler(golden):
         facs.append(sched.get_last_lr()[0])
         sched.optimizer.step(); sched.step()
     assert facs == pytest.approx(list(ad['lr_factors']))
+
+
+def test_opencv_rule_fixtures_are_what_the_restatements_draw():
+    """tests/golden/opencv_rules.json (literal disc row tables and thick-line rasters; cv2 itself is absent here -- a
+    maintainer checks them against cv2 with tests/golden/check_opencv_rules.py): the oracle restatement
+    (oracle/cv_raster.py, quoting OpenCV 4.2 drawing.cpp), the older disc restatement in oracle/aux_glue.py and the
+    library's host-side table all agree with the committed literals."""
+    import json
+    import numpy as np
+    from oracle import cv_raster as cr, aux_glue as oa
+    from animateportrait_amd import losses
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'opencv_rules.json')))
+    assert d['circle_half_widths']['3'] == [3, 2, 2, 0] and d['circle_half_widths']['4'] == [4, 3, 3, 2, 0]
+    assert d['circle_half_widths']['5'] == [5, 4, 4, 4, 3, 0] and d['circle_half_widths']['1'] == [1, 0]
+    for r, hw in d['circle_half_widths'].items():
+        assert cr.circle_half_widths(int(r)) == hw == oa.cv2_filled_circle_rows(int(r)) == losses.circle_rows(int(r))
+    for ln in d['lines']:
+        img = np.zeros((d['canvas'], d['canvas']), np.uint8)
+        cr.thick_line(img, ln['p0'], ln['p1'], ln['thickness'])
+        want = np.zeros_like(img)
+        for y, a, b in ln['runs']:
+            want[y, a:b + 1] = 255
+        assert np.array_equal(img, want), ln
+    # a horizontal thickness-2 line is three rows tall with one-pixel caps (ThickLine: half width 1 px + r = 1 end circles)
+    h = d['lines'][0]
+    assert h['runs'] == [[7, 5, 30], [8, 4, 31], [9, 5, 30]]

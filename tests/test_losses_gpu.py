@@ -250,3 +250,31 @@ def test_landmark_discs_vs_oracle_rule(dev):
         for i in range(3):
             assert torch.equal(out[i].cpu(), oa.draw2(256, 256, lm[i].numpy(), r)), (r, i)
     assert set(out.unique().tolist()) == {-1.0, 1.0}
+
+
+def test_lip_line_mask_is_opencv_thickline_rule(dev):
+    """ap_lip_line_mask (getlipline, geomgm_ifw_fore_model.py:507-515) against the restatement of OpenCV's ThickLine /
+    FillConvexPoly / Line2 / Circle (oracle/cv_raster.py) -- bit exact: random lip loops incl. points outside the frame,
+    thickness 2 (256 px) and 4 (512 px), and the committed literal rasters of tests/golden/opencv_rules.json."""
+    import json
+    import os
+    from animateportrait_amd import losses
+    from animateportrait_amd.models.geomgm_ifw_fore_model import LIP_SEGMENTS
+    from oracle import cv_raster as cr
+    g = torch.Generator().manual_seed(12)
+    for size, th in ((256, 2), (512, 4), (64, 3)):
+        lands = torch.rand(3, 68, 2, generator=g) * (size * 1.2) - size * 0.1          # some points leave the frame
+        lands[1, 48:68] = lands[1, 48:68].round()                                       # integer coordinates too
+        lands[2, 50] = lands[2, 51]                                                     # a zero-length segment
+        got = losses.lip_line_mask(lands.to(dev), LIP_SEGMENTS, size, th).cpu()
+        for i in range(3):
+            want = cr.lip_line_mask(size, lands[i].double().numpy(), LIP_SEGMENTS, th)
+            assert got.shape == (3, 1, size, size) and np.array_equal(got[i, 0].numpy(), want), (size, th, i, float(np.abs(got[i, 0].numpy() - want).sum()))
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'opencv_rules.json')))
+    for ln in d['lines']:
+        pts = torch.tensor([[ln['p0'], ln['p1']]], dtype=torch.float32) + 0.4          # the binding truncates
+        got = losses.lip_line_mask(pts.to(dev), [(0, 1)], d['canvas'], ln['thickness']).cpu()[0, 0].numpy()
+        want = np.zeros((d['canvas'], d['canvas']), np.float32)
+        for y, a, b in ln['runs']:
+            want[y, a:b + 1] = 1.0
+        assert np.array_equal(got, want), ln
