@@ -88,7 +88,12 @@ class GeomCGTIFWTestModel(BaseModel):
         self._photo_ref = photo                                             # (kept alive so that its id stays unique)
         self.real_A = photo.to(dev)
         self.warp_motion = input['warp_motion'].to(dev)
-        self.real_A_lm = input['A_lm'].to(dev)
+        alm = input['A_lm']
+        self.real_A_lm = alm.to(dev)
+        # the photo's landmark map is constant over a clip (one tensor per batch size, as the photo): its encoding inside
+        # the generator is cached under this identity; a fresh tensor per call (datasets) gets a fresh key every time
+        self.netG_A.land1_cache_key = (id(alm), alm._version, tuple(alm.shape))
+        self._alm_ref = alm
         self.target_B_lm = input['tB_lm'].to(dev)
         for k, attr in (('realA_static_warp', 'realA_static_warp'), ('A_lm_68', 'real_A_lm_68'),
                         ('tB_lm_68', 'target_B_lm_68'), ('winB', 'winB')):

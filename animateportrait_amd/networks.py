@@ -194,6 +194,8 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
                            _7=ConvLayer([ngf], output_nc, 7, 1, 3, PAD_REFLECT))
         self.model_landmark_trans = _seq(_0=ConvLayer([1], 8, 3, 1, 1), _3=ConvLayer([8], con_dim, 3, 2, 1),
                                          _6=ConvLayer([con_dim], con_dim, 3, 2, 1))
+        self.land1_cache_key = None      # set by a streaming caller: identity of the (constant) land1 tensor, see _run
+        self._land1_cache = None
 
     def is_block2(self, i):
         return (i + self.disp) % self.div == 0
@@ -232,12 +234,30 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         x3 = cf(tape, self.model_tri22['0'], x3, norm_act=ACT_RELU)
         x3 = dfw(x3, motion, flow, ifmask, 2, tape, self.model_tri_merge)
         x = cf(tape, self.model_tri_merge, [x1, x2, x3])
-        # land1 / land2 share the encoder weights: one pass over the 2B batch
-        lands = Feat(torch.cat([land1, land2], 0).contiguous())
-        l = cf(tape, self.model_landmark_trans['0'], lands, norm_act=ACT_RELU)
-        l = cf(tape, self.model_landmark_trans['3'], l, norm_act=ACT_RELU)
-        l = cf(tape, self.model_landmark_trans['6'], l, norm_act=ACT_NONE)
-        l1, l2 = batch_split_forward(tape, l, b)
+        lt = self.model_landmark_trans
+        key = self.land1_cache_key
+        if tape is None and key is not None:
+            # streaming inference: land1 is the photo's landmark map, the same for every frame of a clip -- the caller
+            # (GeomCGTIFWTestModel) names it with land1_cache_key and its encoding (networks.py:1331-1332) is reused;
+            # only land2 runs through the encoder.  Never on by default: a cached result must not enter a timed step.
+            full = (key, tuple(land1.shape), tuple(ops.weight_key(lt[k].weight) for k in ('0', '3', '6')))
+            if self._land1_cache is None or self._land1_cache[0] != full:
+                l = cf(None, lt['0'], Feat(land1.contiguous()), norm_act=ACT_RELU)
+                l = cf(None, lt['3'], l, norm_act=ACT_RELU)
+                l = cf(None, lt['6'], l, norm_act=ACT_NONE)
+                l.mean                                           # finalise the statistics once
+                self._land1_cache = (full, l)
+            l1 = self._land1_cache[1]
+            l2 = cf(None, lt['0'], Feat(land2.contiguous()), norm_act=ACT_RELU)
+            l2 = cf(None, lt['3'], l2, norm_act=ACT_RELU)
+            l2 = cf(None, lt['6'], l2, norm_act=ACT_NONE)
+        else:
+            # land1 / land2 share the encoder weights: one pass over the 2B batch
+            lands = Feat(torch.cat([land1, land2], 0).contiguous())
+            l = cf(tape, lt['0'], lands, norm_act=ACT_RELU)
+            l = cf(tape, lt['3'], l, norm_act=ACT_RELU)
+            l = cf(tape, lt['6'], l, norm_act=ACT_NONE)
+            l1, l2 = batch_split_forward(tape, l, b)
         for i in range(self.n_blocks):
             blk = self.model2[str(i)]
             x = blk.run([x, l1, l2], tape) if self.is_block2(i) else blk.run(x, tape)

@@ -184,7 +184,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     through the in-process pipeline (Module1 content LSTM -> landmarks -> motion grids -> landmark maps -> netF pre/post
     -> static drawing (once) -> generator -> blend), wall-clock, next to the reference-style CPU data path (per frame:
     txt round trip, scipy.griddata motion, static drawing at 512^2, generator at batch 1) timed on `cpu_frames` frames of
-    the same clip and extrapolated.  Random-init weights; stand-in netF / matte (no checkpoints in the reference tree)."""
+    the same clip and extrapolated.  Random-init weights; FlowUnet_v2 netF on the HIP kernels, stand-in matte (no checkpoints in the reference tree)."""
     import contextlib
     import io
     import tempfile
@@ -198,7 +198,13 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     with contextlib.redirect_stdout(io.StringIO()):
         torch.manual_seed(1234)
         model = create_model(opt)
-    model.aux['netF'] = standins.StandinFlowNet().to(dev)
+    # netF: FlowUnet_v2 (intrinsic_flow_models/networks.py:647-744) on the HIP conv kernels, BatchNorm folded.  Its
+    # hyper-parameters live in the absent checkpoints/FlowReg_id_flow_faces/train_opt.json: the class defaults (nf 64,
+    # max_nf 256, start_scale 2, 2 residual blocks) with the 4 scales a 224-px input admits (112 -> 56 -> 28 -> 14 -> 7)
+    from animateportrait_amd import flow_unet, flow_unet_hip
+    torch.manual_seed(4321)
+    netF_cpu = flow_unet.FlowUnetV2(136, nf=64, max_nf=256, start_scale=2, num_scales=4, n_residual_blocks=2, norm='batch').eval()
+    model.aux['netF'] = flow_unet_hip.FlowUnetV2Hip(netF_cpu).to(dev)
     content = module1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5).to(dev).eval()      # train_audio2landmark.py:71-73
     pose = module1.Audio2LandmarkPos(drop_out=0.5).to(dev).eval()                                  # :55-59
     spk = torch.randn(256, generator=torch.Generator().manual_seed(7))
@@ -238,7 +244,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     torch.set_num_threads(cores)
     sd_g = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
     sd_s = og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321)
-    netF = standins.StandinFlowNet()
+    netF = netF_cpu                                          # the same FlowUnet_v2 weights as stock PyTorch modules on the host
     a_lm = oa.draw2(256, 256, lm0.numpy(), 3).unsqueeze(0)
 
     def frame(ori, lm):
@@ -262,7 +268,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
                              'sample': 'oracle per-frame path: landmark txt round trip, scipy.griddata motion, cv2-rule landmark '
                                        'maps, netF pre/post, static drawing @512^2, generator, blend; batch 1'},
             'speedup_vs_cpu': round(cpu_s * frames / wall, 1),
-            'note': 'random-init weights; stand-in netF and matte; Module1 = both landmark networks (content + speaker-aware '
+            'note': 'random-init weights; netF = FlowUnet_v2 (nf 64, 4 scales) on the HIP conv kernels, stand-in matte; Module1 = both landmark networks (content + speaker-aware '
                     'pose branch) and their post-processing on the mel windows of the reference\'s example clip '
                     '(tests/golden/female12.wav; mel stage inside the timed region); synthetic speaker embedding; the AutoVC '
                     'converter, RAPT f0 and the checkpoints are absent from the reference tree'}

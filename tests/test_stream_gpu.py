@@ -77,6 +77,13 @@ def test_clip_streamer_vs_oracle_frames():
     # same clip in one batch and without stage synchronisation: identical frames
     out2 = stream.ClipStreamer(model, batch=8).run(photo, lm0, seq, matte=matte).cpu()
     assert linf(out2, out) < 1e-4          # another batch size picks another tile shape: fp32 summation order
+    # the photo's landmark map is encoded once per clip (generator land1 cache): another photo landmark set must not see
+    # the previous clip's encoding
+    lm0b = lm0 + torch.tensor([3.0, -2.0])
+    out3 = stream.ClipStreamer(model, batch=8).run(photo, lm0b, seq, matte=matte).cpu()
+    model.netG_A._land1_cache = None
+    out4 = stream.ClipStreamer(model, batch=8).run(photo, lm0b, seq, matte=matte).cpu()
+    assert torch.equal(out3, out4) and linf(out3, out2) > 1e-4
 
 
 def test_end2end_cli_writes_the_clip(tmp_path, monkeypatch):

@@ -3,7 +3,7 @@ TAG=${1:-r02_gen}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/$TAG
-rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/$TAG -o prof -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact-fp32 --train-steps 0 > $ROOT/gpurun_out/$TAG.json 2> $ROOT/gpurun_out/$TAG.err
+rocprofv3 --kernel-trace --stats -d $ROOT/gpurun_out/$TAG -o prof -- python $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-exact-fp32 --train-steps 0 --no-stream > $ROOT/gpurun_out/$TAG.json 2> $ROOT/gpurun_out/$TAG.err
 DB=$(find $ROOT/gpurun_out/$TAG -name "*results.db" | head -1)
 python $ROOT/tools/rocpd_summary.py stats $DB $ROOT/gpurun_out/${TAG}_kernel_stats.md | head -40
 rm -rf $ROOT/gpurun_out/$TAG

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
   rm -rf $ROOT/gpurun_out/${TAG}_$name
-  rocprofv3 --kernel-trace --pmc "$@" -d $ROOT/gpurun_out/${TAG}_$name -o prof -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-fp32 --train-steps 0 > $ROOT/gpurun_out/${TAG}_$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" -d $ROOT/gpurun_out/${TAG}_$name -o prof -- python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-exact-fp32 --train-steps 0 --no-stream > $ROOT/gpurun_out/${TAG}_$name.log 2>&1
   DB=$(find $ROOT/gpurun_out/${TAG}_$name -name "*results.db" | head -1)
   python $ROOT/tools/rocpd_summary.py pmc $DB $ROOT/gpurun_out/${TAG}_pmc_$name.md $ROOT/gpurun_out/${TAG}_pmc_$name.json > /dev/null
   rm -rf $ROOT/gpurun_out/${TAG}_$name
