@@ -89,6 +89,9 @@ SIGNATURES = {
     'ap_warp_concat_fwd_split': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                                 ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                 ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p]),
+    'ap_warp_concat_fwd_ex': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                             ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_float, ctypes.c_int32, ctypes.c_void_p]),
     'ap_motion_grid': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                       ctypes.c_int32, c_f32p, ctypes.c_void_p]),
     'ap_resize_bilinear': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

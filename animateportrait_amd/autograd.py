@@ -199,7 +199,8 @@ def warp_forward(tape, f, motion, flow, ifmask, level, consumer=None):
     copy itself; in inference (no tape) the fp32 concat is then not written at all."""
     n, _, h, w = f.data.shape
     emit_xs = consumer is not None and ops.takes_split(consumer.spec, n, h, w)
-    out = ops.warp_concat(f, motion, flow, ifmask, level, emit_xs=emit_xs, keep_fp32=tape is not None or not emit_xs)
+    s2d = emit_xs and len(consumer.spec.cin_segments) == 1 and ops.s2d_eligible(consumer.spec, h, w)
+    out = ops.warp_concat(f, motion, flow, ifmask, level, emit_xs=emit_xs, keep_fp32=tape is not None or not emit_xs, s2d=s2d)
     if tape is not None:
         tape.track(out)
 

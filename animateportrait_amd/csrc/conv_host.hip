@@ -828,8 +828,8 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         const dim3 grid((unsigned)((long long)d->N * p.tiles_y * p.tiles_x));
         if (d->stride == 1 && d->Cout == 8) hipLaunchKernelGGL((conv_small_f32<SmallCfg<1, 8>>), grid, dim3(256), 0, (hipStream_t)stream, p);
         else if (d->stride == 1) hipLaunchKernelGGL((conv_small_f32<SmallCfg<1, 16>>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else if (d->Cout == 8) hipLaunchKernelGGL((conv_small_f32<SmallCfg<2, 8>>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((conv_small_f32<SmallCfg<2, 16>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else if (d->Cout == 8) hipLaunchKernelGGL((conv_small_gather_f32<SmallCfg<2, 8>>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((conv_small_gather_f32<SmallCfg<2, 16>>), grid, dim3(256), 0, (hipStream_t)stream, p);
         return check_launch("conv_small_f32");
     }
     if (pl.bf3) {

@@ -87,6 +87,48 @@ __device__ __forceinline__ void store_split_slot(uint4* xs, int n, int CG2, int 
     *reinterpret_cast<wbf16x8*>(xs + ((long long)(n * 2 + 1) * CG2 + cg) * (HW + 1) + pix) = lv;
 }
 
+// The same slot pair in the SPACE-TO-DEPTH split layout a stride-2 3x3 consumer stages (conv_bf16x3.h, split_s2d_kernel):
+//   X'[(ry * 2 + rx) * C2 + c][qy][qx] = pad1(v)[c][2 qy + ry][2 qx + rx]   on an (H/2 + 1) x (W/2 + 1) map,
+// so pixel (y, x) lands in phase ((y + 1) & 1, (x + 1) & 1) at ((y + 1) >> 1, (x + 1) >> 1).  The pixels of the image
+// border also write the all-zero slots of the padding ring next to them (every phase plane has one zero row and column).
+__device__ __forceinline__ void store_split_slot_s2d(uint4* xs, int n, int CG2, int cg, int H, int W, int y, int x,
+                                                     const float (&v)[8]) {
+    const int H2 = H / 2 + 1, W2 = W / 2 + 1, HW2 = H2 * W2;
+    wbf16x8 hv, lv;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const __bf16 h = (__bf16)v[c];
+        hv[c] = h;
+        lv[c] = (__bf16)(v[c] - (float)h);
+    }
+    auto plane = [&](int part, int ry, int rx) { return xs + ((long long)(n * 2 + part) * (4 * CG2) + (ry * 2 + rx) * CG2 + cg) * (HW2 + 1); };
+    const int py = y + 1, px = x + 1;
+    const int ry = py & 1, rx = px & 1, qy = py >> 1, qx = px >> 1;
+    *reinterpret_cast<wbf16x8*>(plane(0, ry, rx) + qy * W2 + qx) = hv;
+    *reinterpret_cast<wbf16x8*>(plane(1, ry, rx) + qy * W2 + qx) = lv;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const bool top = y == 0, bot = y == H - 1, lef = x == 0, rig = x == W - 1;
+    if (top || bot) {           // padded rows 0 / H + 1 at this column
+        const int zy = top ? 0 : H + 1;
+        plane(0, zy & 1, rx)[(zy >> 1) * W2 + qx] = z;
+        plane(1, zy & 1, rx)[(zy >> 1) * W2 + qx] = z;
+    }
+    if (lef || rig) {           // padded columns 0 / W + 1 at this row
+        const int zx = lef ? 0 : W + 1;
+        plane(0, ry, zx & 1)[qy * W2 + (zx >> 1)] = z;
+        plane(1, ry, zx & 1)[qy * W2 + (zx >> 1)] = z;
+    }
+    if ((top || bot) && (lef || rig)) {     // the four corners of the ring
+        const int zy = top ? 0 : H + 1, zx = lef ? 0 : W + 1;
+        plane(0, zy & 1, zx & 1)[(zy >> 1) * W2 + (zx >> 1)] = z;
+        plane(1, zy & 1, zx & 1)[(zy >> 1) * W2 + (zx >> 1)] = z;
+    }
+    if (y == 0 && x == 0) {     // the closing all-zero slot of the four phase planes of this channel group
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { plane(0, r >> 1, r & 1)[HW2] = z; plane(1, r >> 1, r & 1)[HW2] = z; }
+    }
+}
+
 // grid: (ceil(H*W/256), ceil(C/CG), N).  out (fp32 [N, 2C, H, W]) and xs (its split-bf16 copy) are both optional.
 __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
                                                           const float* __restrict__ x_rstd, int x_act,
@@ -94,8 +136,8 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
                                                           const float* __restrict__ flow,
                                                           const float* __restrict__ ifmask, float* __restrict__ out,
                                                           uint4* __restrict__ xs,
-                                                          int C, int H, int W, int S, float flow_scale) {
-    if (xs != nullptr && blockIdx.x == 0 && threadIdx.x < 4) {
+                                                          int C, int H, int W, int S, float flow_scale, int s2d) {
+    if (xs != nullptr && !s2d && blockIdx.x == 0 && threadIdx.x < 4) {
         // the all-zero slot that closes every plane of the split layout (this block's two channel groups x 2 parts)
         const int CG2 = (2 * C) >> 3, HWz = H * W;
         const int part = threadIdx.x & 1, cg = (threadIdx.x >> 1) ? (C >> 3) + blockIdx.y : blockIdx.y;
@@ -183,7 +225,10 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
                 out[((long long)n * 2 * C + C + c0 + c) * HW + pix] = v2[c];
             }
         }
-        if (xs != nullptr) {
+        if (xs != nullptr && s2d) {
+            store_split_slot_s2d(xs, n, (2 * C) >> 3, blockIdx.y, H, W, oy, ox, v1);
+            store_split_slot_s2d(xs, n, (2 * C) >> 3, (C >> 3) + blockIdx.y, H, W, oy, ox, v2);
+        } else if (xs != nullptr) {
             store_split_slot(xs, n, (2 * C) >> 3, blockIdx.y, HW, pix, v1);
             store_split_slot(xs, n, (2 * C) >> 3, (C >> 3) + blockIdx.y, HW, pix, v2);
         }
@@ -696,6 +741,16 @@ extern "C" int ap_warp_concat_fwd_split(const float* x, const float* x_mean, con
                                         const float* motion, const float* flow, const float* ifmask, float* out,
                                         void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                                         float flow_scale, ap_stream_t stream) {
+    return ap_warp_concat_fwd_ex(x, x_mean, x_rstd, x_act, motion, flow, ifmask, out, xs, N, C, H, W, S, flow_scale, 0, stream);
+}
+
+extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                                     const float* motion, const float* flow, const float* ifmask, float* out,
+                                     void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
+                                     float flow_scale, int32_t flags, ap_stream_t stream) {
+    const int s2d = flags & 1;
+    if (s2d && (!xs || (H & 1) || (W & 1) || (C % kWarpCG) != 0))
+        return fail(AP_ERR_INVALID, "warp_concat_fwd: the space-to-depth split output needs xs, an even map and C %% 8 == 0");
     if (!x || !motion || !flow || !ifmask) return fail(AP_ERR_INVALID, "warp_concat_fwd: null pointer");
     if (!out && !xs) return fail(AP_ERR_INVALID, "warp_concat_fwd: neither an fp32 nor a split output");
     if ((x_mean == nullptr) != (x_rstd == nullptr)) return fail(AP_ERR_INVALID, "warp_concat_fwd: mean/rstd mismatch");
@@ -706,7 +761,7 @@ extern "C" int ap_warp_concat_fwd_split(const float* x, const float* x_mean, con
         return fail(AP_ERR_UNSUPPORTED, "warp_concat_fwd: the split output needs C %% 8 == 0 (C=%d)", C);
     dim3 grid((H * W + 255) / 256, (C + kWarpCG - 1) / kWarpCG, N);
     hipLaunchKernelGGL(warp_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
-                       flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale);
+                       flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, s2d);
     return check_launch("warp_concat_kernel");
 }
 

@@ -82,10 +82,11 @@ class ConvLayer(nn.Module):
             # 7x7 stem on <= 4 channels: 1x7 split-bf16 convolution over the row expansion of the input
             spec, packed = self.rows_spec(), self.packed_rows()
             srcs = [ops.presplit_rows(srcs[0], self.spec.k, self.spec.pad, self.spec.pad_mode)]
-        elif not srcs[0].is_split_only and ops.s2d_eligible(spec, *srcs[0].data.shape[2:]):
-            # 4x4 stride-2 PatchGAN layer: 2x2 split-bf16 convolution over the space-to-depth copy of the input
+        elif (srcs[0].s2d is not None or not srcs[0].is_split_only) and ops.s2d_eligible(spec, *srcs[0].data.shape[2:]):
+            # 4x4 stride-2 PatchGAN layer / 3x3 stride-2 encoder layer: 2x2 split-bf16 convolution over the space-to-depth
+            # copy of the input -- made here, or already written by the producer (the warp kernel, ops.warp_concat s2d=True)
             spec, packed = self.s2d_spec(), self.packed_s2d()
-            srcs = [ops.presplit_s2d(srcs[0])]
+            srcs = [srcs[0].s2d if srcs[0].s2d is not None else ops.presplit_s2d(srcs[0])]
         if packed is None:
             packed = self.packed()
         if norm_act is None:

@@ -63,7 +63,7 @@ class Feat:
     A convolution hands its InstanceNorm statistics over as per-tile partial sums (``pending``); they are
     finalised by whichever consumer comes first -- inside the fused norm/residual/split pass when that is the
     consumer (ap_norm_apply_split), by a standalone ap_instnorm_finalize when ``mean`` / ``rstd`` are read."""
-    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows', 'xs_heads_only')
+    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows', 'xs_heads_only', 's2d')
 
     def __init__(self, data, mean=None, rstd=None, act=ACT_NONE, pending=None):
         self.data, self._mean, self._rstd, self.act = data, mean, rstd, act
@@ -71,6 +71,7 @@ class Feat:
         self.xs = None           # split-bf16 copy (ap_split_prepass), made on first use and shared by all consumers
         self.xs_rows = None      # {(k, pad, pad_mode): row expansion for k x k stems (ap_split_prepass_rows)}
         self.xs_heads_only = False   # the split copy was written without its tail planes (package mode plain bf16)
+        self.s2d = None              # space-to-depth split copy (a split-only Feat) made by the producer (warp_concat s2d=True)
 
     @property
     def shape(self):
@@ -86,7 +87,7 @@ class Feat:
 
     @property
     def is_split_only(self):
-        return self.xs is not None and self.data.stride(0) == 0 and self.data.numel() > 1
+        return (self.xs is not None or self.s2d is not None) and self.data.stride(0) == 0 and self.data.numel() > 1
 
     @property
     def virtual(self):
@@ -503,10 +504,12 @@ def materialize(f, residual=None, emit_xs=None):
     return Feat(out)
 
 
-def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True):
+def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True, s2d=False):
     """double_feature_warping (networks.py:1298-1313) on a (possibly virtual) feature map.  emit_xs: the 2C-channel
     concat is going to be staged by a split-bf16 convolution, so the kernel also writes its split copy; with
-    keep_fp32=False (inference) that copy is the only output and the result is a split-only Feat."""
+    keep_fp32=False (inference) that copy is the only output and the result is a split-only Feat.
+    s2d (with emit_xs): the consumer is a stride-2 3x3 layer that runs as a 2x2 layer over the space-to-depth copy
+    (s2d_eligible): the kernel writes THAT layout (zero padding ring included) and the result carries it as ``.s2d``."""
     x = f.data
     n, c, h, w = x.shape
     for t, name in ((x, 'x'), (motion, 'motion'), (flow, 'flow'), (ifmask, 'ifmask')):
@@ -517,15 +520,22 @@ def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True):
     if h != s >> level or w != s >> level:
         raise ValueError('warp_concat: level %d expects %d px features, got %dx%d' % (level, s >> level, h, w))
     emit_xs = bool(emit_xs) and c % 8 == 0
+    s2d = bool(s2d) and emit_xs and h % 2 == 0 and w % 2 == 0
     out = xs = None
     if keep_fp32 or not emit_xs:
         out = torch.empty((n, 2 * c, h, w), dtype=torch.float32, device=x.device)
+    s2d_shape = (n, 8 * c, h // 2 + 1, w // 2 + 1)
     if emit_xs:
-        nbytes = C.check(C.lib().ap_split_prepass_bytes(n, 2 * c, h, w), 'split_prepass_bytes')
+        nbytes = C.check(C.lib().ap_split_prepass_bytes(*(s2d_shape if s2d else (n, 2 * c, h, w))), 'split_prepass_bytes')
         xs = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    C.check(C.lib().ap_warp_concat_fwd_split(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
-                                             _ptr(ifmask), _ptr(out), _ptr(xs), n, c, h, w, s, 1.0 / (1 << level),
-                                             _stream()), 'warp_concat_fwd')
+    C.check(C.lib().ap_warp_concat_fwd_ex(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
+                                          _ptr(ifmask), _ptr(out), _ptr(xs), n, c, h, w, s, 1.0 / (1 << level),
+                                          1 if s2d else 0, _stream()), 'warp_concat_fwd')
+    if s2d:
+        # the plain split copy does not exist: only the stride-2 consumer (through .s2d) or fp32 readers can use this
+        res = Feat(out) if out is not None else Feat(torch.empty(1, dtype=torch.float32, device=x.device).expand((n, 2 * c, h, w)))
+        res.s2d = Feat.split_only(s2d_shape, xs)
+        return res
     if out is None:
         return Feat.split_only((n, 2 * c, h, w), xs)
     res = Feat(out)

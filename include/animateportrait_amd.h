@@ -213,6 +213,13 @@ int ap_warp_concat_fwd_split(const float* x, const float* x_mean, const float* x
                              const float* motion, const float* flow, const float* ifmask,
                              float* out, void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                              float flow_scale, ap_stream_t stream);
+/* ... with flags.  bit 0: xs takes the SPACE-TO-DEPTH split layout of the 2C-channel concat -- what ap_split_prepass_s2d
+ * would make of it: (N, 4 * 2C, H/2 + 1, W/2 + 1) with the zero padding ring written -- for a stride-2 3x3 consumer
+ * (model_tri01 / model_tri12, networks.py:1318-1324) that runs as a 2x2 stride-1 layer (ap_conv_desc.s2d_k = 3); H, W even. */
+int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
+                          const float* motion, const float* flow, const float* ifmask, float* out, void* xs,
+                          int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale, int32_t flags,
+                          ap_stream_t stream);
 
 /* ======================================================================= backward pass
  * What torch.autograd launches for the layers above (loss.backward() at

@@ -949,3 +949,24 @@ def test_degenerate_shapes_are_errors_not_crashes(dev):
     y = G(torch.rand(1, 3, 256, 256, device=dev), -torch.ones(1, 1, 256, 256, device=dev), -torch.ones(1, 1, 256, 256, device=dev),
           z(1, 256, 256, 2), z(1, 2, 256, 256), z(1, 1, 256, 256)).detach()        # the device still works afterwards
     assert bool(torch.isfinite(y).all())
+
+
+def test_warp_writes_space_to_depth_split_layout(dev):
+    """ap_warp_concat_fwd_ex(flags = 1): the split copy of the warped concat in the space-to-depth layout of its stride-2
+    consumer (model_tri01 / model_tri12) == ap_split_prepass_s2d of the fp32 concat, byte for byte, zero ring included."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(21)
+    n, c, s = 2, 16, 64
+    for level in (0, 1):
+        h = s >> level
+        x = torch.randn(n, c, h, h, generator=g).to(dev)
+        yy, xx = torch.meshgrid(torch.linspace(-1, 1, s), torch.linspace(-1, 1, s), indexing='ij')
+        motion = (torch.stack([xx, yy], -1).unsqueeze(0).repeat(n, 1, 1, 1) + 0.05 * torch.randn(n, s, s, 2, generator=g)).to(dev)
+        flow = (3.0 * torch.randn(n, 2, s, s, generator=g)).to(dev)
+        ifmask = (torch.rand(n, 1, s, s, generator=g) > 0.3).float().to(dev)
+        res = ops.warp_concat(ops.Feat(x), motion, flow, ifmask, level, emit_xs=True, keep_fp32=True, s2d=True)
+        assert res.s2d is not None and tuple(res.s2d.shape) == (n, 8 * c, h // 2 + 1, h // 2 + 1)
+        ref = ops.warp_concat(ops.Feat(x), motion, flow, ifmask, level, emit_xs=False)
+        assert torch.equal(res.data, ref.data)
+        want = ops.presplit_s2d(ops.Feat(ref.data))
+        assert torch.equal(res.s2d.xs.cpu(), want.xs.cpu())
