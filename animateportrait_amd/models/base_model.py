@@ -68,7 +68,15 @@ class BaseModel(ABC):
             return
         if os.path.exists(os.path.join(self.FLOW_CHECKPOINT_DIR, model_id, 'train_opt.json')):
             from ..flow_unet import load_flow_network
-            aux['netF'] = load_flow_network(model_id, epoch, self.FLOW_CHECKPOINT_DIR, self.device)
+            net = load_flow_network(model_id, epoch, self.FLOW_CHECKPOINT_DIR, self.device)
+            try:
+                # the frozen regressor runs on the HIP convolution kernels (BatchNorm folded: flow_unet_hip.py) ...
+                from ..flow_unet_hip import FlowUnetV2Hip
+                aux['netF'] = FlowUnetV2Hip(net).to(self.device)
+            except NotImplementedError as e:
+                # ... unless its configuration cannot be folded (norm='instance'): then the stock-PyTorch mirror
+                print('[netF] %s: running FlowUnet_v2 as stock PyTorch modules' % e)
+                aux['netF'] = net
 
     def eval(self):
         for name in self.model_names:

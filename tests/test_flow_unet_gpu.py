@@ -73,3 +73,43 @@ def test_flowunet_hip_wide_vs_torch_mirror(dev, cfg):
     for name, got, ref in (('flow', flow, rf), ('vis', vis, rv), ('pyr_last', pyr[-1], rp[-1]), ('feat', feat, rfeat)):
         assert got.shape == ref.shape, name
         assert float((got.cpu() - ref).abs().max()) <= 5e-4 * float(ref.abs().max()) + 1e-5, (name, float((got.cpu() - ref).abs().max()), float(ref.abs().max()))
+
+
+def test_models_attach_the_hip_flow_network_from_its_checkpoint(dev, tmp_path):
+    """``load_flow_network()`` of both models (geomgm_ifw_fore_model.py:57-68, :386): with the checkpoint directory present,
+    ``BaseModel.attach_flow_network`` puts FlowUnet_v2 on the HIP kernels, and ``flow_network_warp`` (:69-84) through the
+    model's set_input == the oracle's CPU composition with the stock-PyTorch network."""
+    import contextlib
+    import io
+    import json
+    from test_flow_unet_cpu import _seeded_net, CONFIG
+    from animateportrait_amd.flow_unet_hip import FlowUnetV2Hip
+    from animateportrait_amd.options.base_options import TestOptions
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.synthetic import make_landmarks
+    from oracle import aux_glue as oa
+    net, _ = _seeded_net()
+    d = tmp_path / 'FlowReg_id_flow_faces'
+    d.mkdir()
+    json.dump(dict(which_model='unet_v2', input_type1='joint', input_type2='joint', joint_nc=68, seg_nc=7, nf=CONFIG['nf'],
+                   max_nf=CONFIG['max_nf'], start_scale=CONFIG['start_scale'], num_scale=CONFIG['num_scales'],
+                   norm=CONFIG['norm']), open(d / 'train_opt.json', 'w'))
+    torch.save(net.state_dict(), d / 'best_net_netF.pth')
+    opt = TestOptions().parse(['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--dataset_mode',
+                               'synthetic', '--name', 'x', '--output_nc', '1', '--ngf', '8', '--netg_resb_div', '3',
+                               '--netg_resb_disp', '3', '--gpu_ids', '0'])
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(opt)
+    model.FLOW_CHECKPOINT_DIR = str(tmp_path)
+    model.attach_flow_network()
+    assert isinstance(model.aux['netF'], FlowUnetV2Hip)
+    g = torch.Generator().manual_seed(2)
+    lm1, lm2 = make_landmarks(2, g), make_landmarks(2, g)
+    photo = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
+    from animateportrait_amd import losses
+    flow, mask = losses.flow_network_warp(model.aux['netF'], photo.to(dev), lm1.to(dev), lm2.to(dev))
+    rflow, rmask = oa.flow_network_warp(net, photo, lm1, lm2)
+    # the visibility argmax may flip where two logits tie within rounding: compare where the masks agree (nearly everywhere)
+    agree = (mask.cpu() - rmask).abs() < 1e-4
+    assert float(agree.float().mean()) > 0.999
+    assert float(((flow.cpu() - rflow).abs() * agree).max()) <= 2e-4 * float(rflow.abs().max()) + 1e-5
