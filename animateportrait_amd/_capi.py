@@ -35,6 +35,12 @@ class ApConvDesc(ctypes.Structure):
                 ('src', ApSrc * 3)]
 
 
+class ApWeightView(ctypes.Structure):
+    _fields_ = [('w', c_f32p), ('s_co', ctypes.c_int64), ('s_ci', ctypes.c_int64), ('s_ky', ctypes.c_int64),
+                ('s_kx', ctypes.c_int64), ('s2d_c', ctypes.c_int32), ('rows_c', ctypes.c_int32), ('ksrc', ctypes.c_int32),
+                ('reserved', ctypes.c_int32)]
+
+
 class ApOutView(ctypes.Structure):
     _fields_ = [('nstride', ctypes.c_int64), ('cstride', ctypes.c_int64), ('rstride', ctypes.c_int32),
                 ('xstride', ctypes.c_int32), ('y_off', ctypes.c_int32), ('x_off', ctypes.c_int32),
@@ -49,7 +55,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 4      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 5      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -76,6 +82,10 @@ SIGNATURES = {
                                               c_f32p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     'ap_conv2d_kernel_name': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.c_char_p, ctypes.c_int32]),
     'ap_conv2d_pack_weights': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_pack_entry_bytes': (ctypes.c_int32, []),
+    'ap_conv2d_pack_entries': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ApWeightView), c_f32p, ctypes.c_void_p,
+                                              ctypes.c_int32]),
+    'ap_conv2d_pack_run': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     'ap_conv2d_fwd': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_fwd_view': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ApOutView), c_f32p, c_f32p, c_f32p,
                                           ctypes.c_void_p]),

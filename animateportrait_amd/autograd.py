@@ -13,6 +13,27 @@ from . import ops
 from .ops import Feat, ConvSpec, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, PAD_ZERO, PAD_REFLECT, W_OIHW, W_IOHW
 
 
+# ctx.needs_input_grad only mirrors requires_grad: a custom Function cannot see whether THIS backward call wants the
+# parameter gradients (torch.autograd.grad(loss, [input]) runs the same node and drops them).  Writing them straight into
+# the optimiser's flat buffer is therefore opt-in: the train step wraps its ``loss.backward()`` calls in
+# ``direct_param_grads()``; everywhere else the gradients go back through autograd.
+_DIRECT = 0
+
+
+class direct_param_grads:
+    """``with direct_param_grads(): loss.backward()`` -- the caller states that this backward accumulates into ``p.grad`` of
+    every trainable parameter (plain ``.backward()`` of the train step, geomgm_ifw_fore_model.py:586,610,634,780)."""
+
+    def __enter__(self):
+        global _DIRECT
+        _DIRECT += 1
+
+    def __exit__(self, *exc):
+        global _DIRECT
+        _DIRECT -= 1
+        return False
+
+
 class Tape:
     def __init__(self):
         self.steps = []
@@ -29,10 +50,12 @@ class Tape:
         -- instead of one AccumulateGrad add per parameter and call (~200 launches per train step).
 
         This bypasses autograd's own accumulation, so it is taken only when that is exactly what autograd would have
-        done: ``needs`` (ctx.needs_input_grad of the parameter positions) says the caller asked for the gradient of
-        EVERY trainable parameter -- ``torch.autograd.grad(loss, [input])`` / ``backward(inputs=...)`` must not touch
-        the optimiser's buffers -- and every ``p.grad`` still IS its view of the flat gradient buffer (after
+        done: the caller opted in (``direct_param_grads()``: a plain ``loss.backward()`` of the train step --
+        ``torch.autograd.grad(loss, [input])`` / ``backward(inputs=...)`` must not touch the optimiser's buffers), every
+        trainable parameter is wanted (``needs``), and every ``p.grad`` still IS its view of the flat gradient buffer (after
         ``module.zero_grad()`` / ``p.grad = None`` autograd would start from a fresh tensor, not add to stale sums)."""
+        if _DIRECT <= 0:
+            return False
         live = [p for p in params if p.requires_grad]
         if not live or any(getattr(p, '_flat_owner', None) is None for p in live):
             return False
@@ -153,11 +176,11 @@ def conv_backward(tape, layer, srcs, out, norm, act):
             spec, fold_pad = _dgrad_spec(layer, c)
             w = layer.weight.detach()
             if len(srcs) > 1:
-                w = (w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]).contiguous()
+                w = w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]       # a view: the packer takes strides
             packed = layer.packed_dgrad(i, spec, w)
             if fold_pad and ops.dgrad_strip_eligible(spec, gfeat):
                 # 66-column padded gradient: two whole tile columns + a transposed 2-column strip (ops.conv2d_dgrad_strip)
-                packed_t = layer.packed_dgrad((i, 'T'), spec, lambda: w.transpose(2, 3).contiguous())
+                packed_t = layer.packed_dgrad((i, 'T'), spec, w.transpose(2, 3))
                 g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t)
             else:
                 g = ops.conv2d(spec, [gfeat], packed, None).data

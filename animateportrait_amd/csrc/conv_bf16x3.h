@@ -912,6 +912,13 @@ static __global__ __launch_bounds__(256) void split_s2d_kernel(const SplitS2dPar
 }
 
 // ---- weight packer: out = LDS image per (cout tile, chunk): [part][tap][kgroup][CO_TILE][8] bf16
+// The source is addressed through element strides, so that the operand of a data-gradient operator -- a channel slice, a
+// transposed-tap view of the layer's parameter -- or of the derived forms below needs no contiguous temporary:
+//   view == 0: the dense OIHW / IOHW tensor described by layout / Cin / Cout / K (strides derived here);
+//   view == 1: element (co, cin, ky, kx) of the OPERATOR at  w[co * s_co + cin * s_ci + ky * s_ky + kx * s_kx];
+//   s2d_c  > 0: the operator is the 2 x 2 space-to-depth form over 4 * s2d_c channels of a ksrc x ksrc stride-2 layer:
+//               operator (cin = r * s2d_c + c, tap (ty, tx)) = source (c, 2 ty + (r >> 1), 2 tx + (r & 1)), zero beyond ksrc;
+//   rows_c > 0: the operator is the 1 x K row form of a K x K stem over rows_c channels: operator cin = ky * rows_c + c.
 struct PackBf3Params {
     const float* w;
     unsigned short* out;
@@ -920,14 +927,15 @@ struct PackBf3Params {
     int nseg, segC[kMaxSeg], chunk_begin[kMaxSeg];
     int CO_TILE, nchunks, co_tiles;
     int ntaps, tap_ky[kMaxTaps], tap_kx[kMaxTaps];      // source tap of packed tap t (already flipped if needed)
+    int view, s2d_c, rows_c, ksrc;
+    long long s_co, s_ci, s_ky, s_kx;
 };
 
-static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
+__device__ __forceinline__ void pack_bf16x3_body(const PackBf3Params& p, long long first, long long step) {
     const int T = p.ntaps;
     const long long per_block = 2LL * T * 2 * p.CO_TILE * 8;
     const long long total = (long long)p.co_tiles * p.nchunks * per_block;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
+    for (long long idx = first; idx < total; idx += step) {
         long long r = idx % per_block;
         const long long blk = idx / per_block;
         const int chunk = (int)(blk % p.nchunks), cot = (int)(blk / p.nchunks);
@@ -945,17 +953,51 @@ static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
         if (cs < p.segC[s] && co < p.Cout && p.tap_ky[t] >= 0) {   // tap_ky < 0: a window position this phase does not have
             int cin = cs;
             for (int j = 0; j < s; ++j) cin += p.segC[j];
-            const int ky = p.tap_ky[t], kx = p.tap_kx[t];
-            const int KH = p.KH > 0 ? p.KH : p.K;                  // KH != K: a 1 x K row kernel
-            const long long off = p.layout == 0 ? (((long long)co * p.Cin + cin) * KH + ky) * p.K + kx
-                                                : (((long long)cin * p.Cout + co) * KH + ky) * p.K + kx;
-            v = p.w[off];
+            int ky = p.tap_ky[t], kx = p.tap_kx[t];
+            bool ok = true;
+            if (p.s2d_c > 0) {
+                const int rr = cin / p.s2d_c;
+                cin -= rr * p.s2d_c;
+                ky = 2 * ky + (rr >> 1);
+                kx = 2 * kx + (rr & 1);
+                ok = ky < p.ksrc && kx < p.ksrc;
+            } else if (p.rows_c > 0) {
+                ky = cin / p.rows_c;
+                cin -= ky * p.rows_c;
+                ok = ky < p.ksrc;
+            }
+            if (ok) {
+                long long off;
+                if (p.view) {
+                    off = co * p.s_co + cin * p.s_ci + ky * p.s_ky + kx * p.s_kx;
+                } else {
+                    const int KH = p.KH > 0 ? p.KH : p.K;          // KH != K: a 1 x K row kernel
+                    off = p.layout == 0 ? (((long long)co * p.Cin + cin) * KH + ky) * p.K + kx
+                                        : (((long long)cin * p.Cout + co) * KH + ky) * p.K + kx;
+                }
+                v = p.w[off];
+            }
         }
         __bf16 h, l;
         split_bf16(v, h, l);
         const __bf16 o = part == 0 ? h : l;
         p.out[idx] = *reinterpret_cast<const unsigned short*>(&o);
     }
+}
+
+static __global__ void pack_bf16x3_kernel(const PackBf3Params p) {
+    pack_bf16x3_body(p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
+}
+
+// every (layer, variant) of a network in ONE launch: entry blockIdx.y of a device-resident table (built once: the parameters
+// are views of the optimiser's flat buffer and the packed images are persistent, so the pointers do not change)
+static __global__ void pack_bf16x3_table_kernel(const PackBf3Params* __restrict__ table) {
+    __shared__ PackBf3Params p;
+    const int* src = reinterpret_cast<const int*>(table + blockIdx.y);
+    int* dst = reinterpret_cast<int*>(&p);
+    for (int i = threadIdx.x; i < (int)(sizeof(PackBf3Params) / sizeof(int)); i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+    pack_bf16x3_body(p, (long long)blockIdx.x * blockDim.x + threadIdx.x, (long long)gridDim.x * blockDim.x);
 }
 
 }  // namespace apamd

@@ -528,6 +528,28 @@ static int num_cus() {
     return cached[dev];
 }
 
+// the packer's parameters for one launch of a split-bf16 plan; `v` (nullable): the weight as a strided / derived view
+static PackBf3Params bf3_pack_params(const ap_conv_desc* d, const Plan& pl, const Launch& L, const float* weight,
+                                     const ap_weight_view* v, float* packed) {
+    PackBf3Params p;
+    memset(&p, 0, sizeof(p));
+    p.w = v ? v->w : weight;
+    p.out = reinterpret_cast<unsigned short*>(packed + L.wp_off);
+    p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KW; p.layout = d->w_layout; p.flip = 0;
+    p.KH = d->KH != d->KW ? d->KH : 0;
+    p.nseg = d->nsrc;
+    for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
+    p.CO_TILE = pl.bk->CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
+    p.ntaps = (int)L.taps.size();
+    for (int t = 0; t < p.ntaps; ++t) { p.tap_ky[t] = L.taps[t].ky; p.tap_kx[t] = L.taps[t].kx; }
+    if (v) {
+        p.view = 1;
+        p.s_co = v->s_co; p.s_ci = v->s_ci; p.s_ky = v->s_ky; p.s_kx = v->s_kx;
+        p.s2d_c = v->s2d_c; p.rows_c = v->rows_c; p.ksrc = v->ksrc;
+    }
+    return p;
+}
+
 }  // namespace apamd
 
 using namespace apamd;
@@ -714,17 +736,7 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
     }
     if (pl.bf3) {
         for (const auto& L : pl.launches) {
-            PackBf3Params p;
-            memset(&p, 0, sizeof(p));
-            p.w = weight;
-            p.out = reinterpret_cast<unsigned short*>(packed + L.wp_off);
-            p.Cin = pl.Cin; p.Cout = d->Cout; p.K = d->KW; p.layout = d->w_layout; p.flip = 0;
-            p.KH = d->KH != d->KW ? d->KH : 0;
-            p.nseg = d->nsrc;
-            for (int s = 0; s < d->nsrc; ++s) { p.segC[s] = d->src[s].C; p.chunk_begin[s] = pl.chunk_begin[s]; }
-            p.CO_TILE = pl.bk->CO_TILE; p.nchunks = pl.nchunks; p.co_tiles = pl.co_tiles;
-            p.ntaps = (int)L.taps.size();
-            for (int t = 0; t < p.ntaps; ++t) { p.tap_ky[t] = L.taps[t].ky; p.tap_kx[t] = L.taps[t].kx; }
+            const PackBf3Params p = bf3_pack_params(d, pl, L, weight, nullptr, packed);
             hipLaunchKernelGGL(pack_bf16x3_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, p);
             rc = check_launch("pack_bf16x3_kernel");
             if (rc) return rc;
@@ -755,6 +767,29 @@ int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* pa
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "pack (head copy) weights: %s", hipGetErrorString(e));
     }
     return AP_OK;
+}
+
+int32_t ap_conv2d_pack_entry_bytes(void) { return (int32_t)sizeof(PackBf3Params); }
+
+int32_t ap_conv2d_pack_entries(const ap_conv_desc* d, const ap_weight_view* v, float* packed, void* entries, int32_t max_entries) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    if (rc) return rc;
+    if (!v || !v->w || !packed) return fail(AP_ERR_INVALID, "pack_entries: null view / packed pointer");
+    if (!pl.bf3) return 0;                                   // not a split-bf16 plan: use ap_conv2d_pack_weights
+    if ((int)pl.launches.size() > max_entries || !entries) return fail(AP_ERR_INVALID, "pack_entries: room for %d entries, plan has %d", max_entries, (int)pl.launches.size());
+    if ((v->s2d_c > 0 || v->rows_c > 0) && v->ksrc < 1) return fail(AP_ERR_INVALID, "pack_entries: derived views need ksrc");
+    PackBf3Params* out = reinterpret_cast<PackBf3Params*>(entries);
+    int n = 0;
+    for (const auto& L : pl.launches) out[n++] = bf3_pack_params(d, pl, L, nullptr, v, packed);
+    return n;
+}
+
+int ap_conv2d_pack_run(const void* entries_dev, int32_t count, ap_stream_t stream) {
+    if (!entries_dev || count < 1 || count > 65535) return fail(AP_ERR_INVALID, "pack_run: bad table");
+    hipLaunchKernelGGL(pack_bf16x3_table_kernel, dim3(48, count), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackBf3Params*>(entries_dev));
+    return check_launch("pack_bf16x3_table_kernel");
 }
 
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,

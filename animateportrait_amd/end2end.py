@@ -10,8 +10,12 @@ ffmpeg exists) out, through ``stream.ClipStreamer`` in batches.
         --landmark_scale 0.5 --name formal/drawing --epoch 70 --out output/<db> [--audio a.wav]
 
 Landmark sources: ``--landmarks DIR`` (the reference's ``Alm_txt`` layout: ``ori.txt`` + ``%05d.txt``, 512-px coordinates
-for a 256-px photo -> ``--landmark_scale 0.5``) or ``--landmarks_npy FILE`` ((T + 1, 68, 2): row 0 = the photo's).  The
-matte comes from ``--matte PNG`` (white = foreground) unless the model has its matting network.
+for a 256-px photo -> ``--landmark_scale 0.5``), ``--landmarks_npy FILE`` ((T + 1, 68, 2): row 0 = the photo's), or the audio
+itself: ``--wav FILE --photo_landmarks TXT`` runs the audio half of main_end2end_module2.py:181-272 in process -- mel
+windows (audio.py) -> the two Module1 networks (``--load_a2l_G_name`` / ``--load_a2l_C_name`` checkpoints) -> the landmark
+post-processing -> image-pixel landmarks -- with the photo's detected (68, 3) landmarks (``face_alignment`` output, a txt of 68
+rows) and a speaker embedding (``--speaker_emb`` txt of 256 numbers; the resemblyzer / AutoVC front end is not part of this
+build) as inputs.  The matte comes from ``--matte PNG`` (white = foreground) unless the model has its matting network.
 """
 import argparse
 import os
@@ -54,6 +58,22 @@ def load_matte(path, size):
     return torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).view(1, 1, size, size)
 
 
+def landmarks_from_audio(a, device):
+    """The audio half of main_end2end_module2.py:181-272 in process: returns (photo landmarks (68, 2), clip (T, 68, 2)) px."""
+    from . import audio, module1
+    shape = np.loadtxt(a.photo_landmarks).reshape(68, -1)
+    if shape.shape[1] == 2:
+        shape = np.concatenate([shape, np.zeros((68, 1))], 1)
+    std_z = np.loadtxt(a.std_face).reshape(68, 3)[:, 2] if a.std_face else None
+    face_id, scale, shift = module1.adjust_and_norm_input_face(shape, std_z)
+    net_g, net_c = module1.load_module1(a.load_a2l_G_name, a.load_a2l_C_name, device)
+    emb = np.loadtxt(a.speaker_emb).reshape(-1) if a.speaker_emb else np.zeros(256, dtype=np.float32)
+    windows = audio.clip_audio_features(a.wav, max_frames=a.max_frames)
+    fl = module1.predict_landmarks_speaker_aware(net_g, net_c, windows, emb, face_id.reshape(-1))
+    seq = module1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
+    return module1.photo_landmarks_in_pixels(face_id, scale, shift), seq.astype(np.float32)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--photo', required=True)
@@ -64,11 +84,20 @@ def main(argv=None):
     ap.add_argument('--out', required=True)
     ap.add_argument('--fps', type=float, default=62.5)                              # main_end2end_module2.py:343
     ap.add_argument('--audio', default=None)
+    ap.add_argument('--wav', default=None, help='drive the clip from this audio file (needs --photo_landmarks)')
+    ap.add_argument('--photo_landmarks', default=None, help='txt, 68 rows "x y z": the photo\'s detected landmarks in pixels')
+    ap.add_argument('--speaker_emb', default=None, help='txt with the 256-d speaker embedding (default: zeros)')
+    ap.add_argument('--std_face', default=None, help='STD_FACE_LANDMARKS.txt (its depth column replaces the detected one)')
+    ap.add_argument('--load_a2l_G_name', default='Module1/checkpoints/ckpt_speaker_branch.pth')
+    ap.add_argument('--load_a2l_C_name', default='Module1/checkpoints/ckpt_content_branch.pth')
+    ap.add_argument('--max_frames', type=int, default=None)
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--size', type=int, default=256)
     a, rest = ap.parse_known_args(argv)
-    if (a.landmarks is None) == (a.landmarks_npy is None):
-        ap.error('exactly one of --landmarks / --landmarks_npy')
+    if sum(x is not None for x in (a.landmarks, a.landmarks_npy, a.wav)) != 1:
+        ap.error('exactly one of --landmarks / --landmarks_npy / --wav')
+    if a.wav is not None and a.photo_landmarks is None:
+        ap.error('--wav needs --photo_landmarks')
     # the model's own options: the test settings of test_gan_new (:95-104) unless given
     defaults = ['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--netg_resb_div', '3',
                 '--netg_resb_disp', '3', '--output_nc', '1', '--dataset_mode', 'synthetic', '--blendbg', '1', '--gpu_ids', '0']
@@ -77,7 +106,11 @@ def main(argv=None):
     model = create_model(opt)
     model.setup(opt)                    # '<epoch>_net_G_A.pth' + the static drawing generator; missing files are errors
     model.eval()
-    if a.landmarks is not None:
+    if a.wav is not None:
+        lm0, seq = landmarks_from_audio(a, torch.device('cuda', opt.gpu_ids[0]))
+        if a.audio is None:
+            a.audio = a.wav
+    elif a.landmarks is not None:
         lm0, seq = stream.load_landmark_dir(a.landmarks, a.landmark_scale)
     else:
         arr = np.load(a.landmarks_npy).astype(np.float32) * a.landmark_scale

@@ -26,6 +26,7 @@ import itertools
 import torch
 
 from .. import losses, networks, parallel
+from ..autograd import direct_param_grads
 from ..optim import FlatAdam
 from ..util.image_pool import ImagePool
 from .base_model import BaseModel
@@ -249,7 +250,8 @@ class GeomGMIFWForeModel(BaseModel):
             pf = netD(torch.cat([fake1.detach(), fake2.detach()], 0))
             loss = (self.criterionGAN(netD(real), True)
                     + (self.criterionGAN(pf[:b], False) + self.criterionGAN(pf[b:], False)) / 2.0) / 2.0
-        loss.backward()
+        with direct_param_grads():          # a plain .backward() of the train step: accumulate straight into the flat buffers
+            loss.backward()
         return loss.detach()
 
     def backward_D_A(self):
@@ -278,7 +280,8 @@ class GeomGMIFWForeModel(BaseModel):
             b = real.shape[0]
             pf = D(torch.cat([fake, other], 0))
             loss = (crit(D(real), True) + crit(pf[:b], False) + crit(pf[b:], False)) / 3.0
-        loss.backward()
+        with direct_param_grads():          # a plain .backward() of the train step: accumulate straight into the flat buffers
+            loss.backward()
         self.loss_D_A_coh = loss.detach()
 
     # ------------------------------------------------------------------ G loss
@@ -346,7 +349,8 @@ class GeomGMIFWForeModel(BaseModel):
         elif o.identity_loss:
             self._notice('faceloss', 'no face-recognition network: identity loss (lambda_face) is skipped')
         self.loss_G = loss
-        loss.backward()
+        with direct_param_grads():          # a plain .backward() of the train step: accumulate straight into the flat buffers
+            loss.backward()
 
     # ------------------------------------------------------------------ step
     def optimize_parameters(self):

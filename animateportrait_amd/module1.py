@@ -357,3 +357,46 @@ def predict_landmarks(net, au_windows, face_id, scale=1.0, shift=(0.0, 0.0), seg
         outs.append(dis + f)
     fl = torch.cat(outs, 0).cpu().numpy()
     return to_image_landmarks(fl, scale, shift, eyes=False, smooth=smooth)[:, :, :2]
+
+
+# ------------------------------------------------------------------------------------------------ clip driver pieces
+def load_module1(speaker_ckpt, content_ckpt, device=None):
+    """The two checkpoints ``Audio2landmark_model.__init__`` loads (train_audio2landmark.py:55-79):
+    ``ckpt_speaker_branch.pth`` -> ``G`` (key 'G', minus the ``comb_mlp`` entries) and ``ckpt_content_branch.pth`` -> ``C``
+    (key 'model_g_face_id'); both in eval mode on ``device``.  Returns (net_g, net_c)."""
+    net_g = Audio2LandmarkPos(drop_out=0.5)                                          # :55-59
+    ck = torch.load(speaker_ckpt, map_location='cpu')
+    sd = net_g.state_dict()
+    sd.update({k: v for k, v in ck['G'].items() if k.split('.')[0] not in ['comb_mlp']})   # :64-66
+    net_g.load_state_dict(sd)
+    net_c = Audio2LandmarkContent(use_prior_net=True, drop_out=0.5)                  # :71-73
+    net_c.load_state_dict(torch.load(content_ckpt, map_location='cpu')['model_g_face_id'])   # :76-77
+    for n in (net_g, net_c):
+        n.eval()
+        for q in n.parameters():
+            q.requires_grad_(False)
+    return (net_g.to(device), net_c.to(device)) if device is not None else (net_g, net_c)
+
+
+def adjust_and_norm_input_face(shape_3d, std_face_z=None):
+    """main_end2end_module2.py:196-204 + util/utils.py:348-359 on the photo's (68, 3) landmarks (pixels): the manual lip /
+    eye adjustment, then the normalisation to Module1's frame.  Returns (face_id (68, 3), scale, shift (2,)); ``std_face_z``
+    is column z of STD_FACE_LANDMARKS.txt (the reference replaces the detected depth by it x 0.1; zeros when absent)."""
+    f = np.array(shape_3d, dtype=np.float64, copy=True).reshape(68, 3)
+    f[49:54, 1] += 1.
+    f[55:60, 1] -= 1.
+    f[[37, 38, 43, 44], 1] -= 2
+    f[[40, 41, 46, 47], 1] += 2
+    scale = 1.6 / (f[0, 0] - f[16, 0])
+    shift = -0.5 * (f[0, 0:2] + f[16, 0:2])
+    f[:, 0:2] = (f[:, 0:2] + shift) * scale
+    f[:, 2] = 0.0 if std_face_z is None else np.asarray(std_face_z, dtype=np.float64).reshape(68) * 0.1
+    f[:, 0:2] = -f[:, 0:2]
+    return f, float(scale), shift
+
+
+def photo_landmarks_in_pixels(face_id, scale, shift):
+    """main_end2end_module2.py:311-315 ('save ori'): the normalised face back in image pixels, (68, 2)."""
+    f = np.array(face_id, dtype=np.float64, copy=True).reshape(68, 3)
+    f[:, 0:2] = -f[:, 0:2] / scale - np.asarray(shift, dtype=np.float64)
+    return f[:, :2].astype(np.float32)

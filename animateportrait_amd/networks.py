@@ -46,30 +46,22 @@ class ConvLayer(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout, dtype=torch.float32))
         self.spec = ConvSpec(cin_segments, cout, k, stride, pad, pad_mode, transposed, output_padding,
                              W_IOHW if transposed else W_OIHW)
-        self._packed = None
-        self._packed_key = None
-        self._packed_dgrad = {}
+        self._slots = {}                   # operator variant -> ops.PackedSlot (forward, row / space-to-depth forms, data gradients)
         self._rows_spec = None
-        self._packed_rows = None
         self._s2d_spec = None
-        self._packed_s2d = None
 
-    def packed_dgrad(self, seg, spec, w):
-        """Packed weights of the data-gradient operator for input segment ``seg`` (cached per weight version)."""
-        key = ops.weight_key(self.weight)
-        hit = self._packed_dgrad.get(seg)
-        if hit is None or hit[0] != key:
-            hit = (key, ops.pack_weights(spec, w() if callable(w) else w))     # callable: built on a miss only
-            self._packed_dgrad[seg] = hit
-        return hit[1]
+    def _packed(self, slot_id, spec, view):
+        slot = ops.packed_slot(spec, self.weight, view, self._slots.get(slot_id))
+        self._slots[slot_id] = slot
+        return slot.buf
+
+    def packed_dgrad(self, seg, spec, view):
+        """Packed weights of the data-gradient operator for input segment ``seg``; ``view``: the operand as a (strided)
+        view of this layer's parameter (a channel slice, transposed taps): no contiguous copy is made for the batched packer."""
+        return self._packed(('dgrad', seg), spec, ops.WeightView(view))
 
     def packed(self):
-        w = self.weight
-        key = ops.weight_key(w)
-        if self._packed is None or self._packed_key != key:
-            self._packed = ops.pack_weights(self.spec, w.detach())
-            self._packed_key = key
-        return self._packed
+        return self._packed('fwd', self.spec, ops.WeightView(self.weight.detach()))
 
     def run(self, srcs, norm_act=None, act=ACT_NONE):
         """norm_act=None: plain conv + bias + act.  norm_act=ACT_*: conv followed by InstanceNorm
@@ -99,11 +91,7 @@ class ConvLayer(nn.Module):
         return self._s2d_spec
 
     def packed_s2d(self):
-        w = self.weight
-        key = ops.weight_key(w)
-        if self._packed_s2d is None or self._packed_s2d[0] != key:
-            self._packed_s2d = (key, ops.pack_weights(self.s2d_spec(), ops.s2d_weight(w.detach())))
-        return self._packed_s2d[1]
+        return self._packed('s2d', self.s2d_spec(), ops.WeightView(self.weight.detach(), s2d_c=self.spec.cin_segments[0]))
 
     def rows_spec(self):
         if self._rows_spec is None:
@@ -111,11 +99,7 @@ class ConvLayer(nn.Module):
         return self._rows_spec
 
     def packed_rows(self):
-        w = self.weight
-        key = ops.weight_key(w)
-        if self._packed_rows is None or self._packed_rows[0] != key:
-            self._packed_rows = (key, ops.pack_weights(self.rows_spec(), ops.stem_rows_weight(w.detach())))
-        return self._packed_rows[1]
+        return self._packed('rows', self.rows_spec(), ops.WeightView(self.weight.detach(), rows_c=self.spec.cin_segments[0]))
 
 
 def _seq(**children):

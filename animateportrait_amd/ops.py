@@ -198,6 +198,103 @@ def pack_weights(spec, weight):
     return packed
 
 
+class WeightView:
+    """A packer operand: ``t`` = a (possibly non-contiguous) 4-D view of a layer's parameter, plus the derived forms
+    (``s2d_c``: space-to-depth form over 4 * s2d_c channels; ``rows_c``: 1 x K row form over rows_c channels)."""
+    __slots__ = ('t', 's2d_c', 'rows_c')
+
+    def __init__(self, t, s2d_c=0, rows_c=0):
+        self.t, self.s2d_c, self.rows_c = t, s2d_c, rows_c
+
+    def dense(self):
+        """The operand as the contiguous tensor ap_conv2d_pack_weights takes (the unbatched path)."""
+        if self.s2d_c:
+            return s2d_weight(self.t)
+        if self.rows_c:
+            return stem_rows_weight(self.t)
+        return self.t.contiguous()
+
+    def c_view(self, spec):
+        v = C.ApWeightView()
+        t = self.t
+        v.w = t.data_ptr()
+        derived = bool(self.s2d_c or self.rows_c)
+        oihw = derived or spec.w_layout == W_OIHW            # the derived forms index the layer's own OIHW parameter
+        v.s_co, v.s_ci = (t.stride(0), t.stride(1)) if oihw else (t.stride(1), t.stride(0))
+        v.s_ky, v.s_kx = t.stride(2), t.stride(3)
+        v.s2d_c, v.rows_c, v.ksrc = self.s2d_c, self.rows_c, t.shape[2]
+        return v
+
+
+class PackedSlot:
+    __slots__ = ('buf', 'key', 'batched')
+
+    def __init__(self, buf, batched):
+        self.buf, self.key, self.batched = buf, None, batched
+
+
+class PackSet:
+    """Every split-bf16 packed image of the layers whose parameters ONE optimiser (optim.FlatAdam) owns, as a device-resident
+    table of packer entries: after an optimiser step all of them are stale at once and are rebuilt by ONE launch
+    (ap_conv2d_pack_run) instead of one per (layer, operator) -- 185 launches per train step before.  The pointers in the
+    table are stable: parameters are views of the optimiser's flat buffer, the packed images are allocated once."""
+
+    def __init__(self):
+        self.host = bytearray()
+        self.count = 0
+        self.table = None            # device copy of ``host``; None: to be uploaded
+        self.members = []            # (PackedSlot, weight Parameter)
+
+    def register(self, slot, weight, entry_bytes, n):
+        self.host += entry_bytes
+        self.count += n
+        self.table = None
+        self.members.append((slot, weight))
+
+    def refresh(self, device):
+        if self.table is None:
+            import numpy as np
+            self.table = torch.from_numpy(np.frombuffer(bytes(self.host), dtype=np.uint8).copy()).to(device)
+        C.check(C.lib().ap_conv2d_pack_run(_ptr(self.table), self.count, _stream()), 'pack_run')
+        for slot, w in self.members:
+            slot.key = weight_key(w)
+
+
+def packed_slot(spec, weight, view, slot):
+    """The packed image of operator ``spec`` over ``view`` of parameter ``weight``, current for the weight's present value.
+    slot: the PackedSlot of an earlier call or None.  Parameters owned by a FlatAdam are packed through its PackSet."""
+    key = weight_key(weight)
+    if slot is not None and slot.key == key:
+        return slot
+    owner = getattr(weight, '_flat_owner', None)
+    lib = C.lib()
+    if slot is None:
+        d = spec.desc(1, 64, 64)
+        n = C.check(lib.ap_conv2d_packed_floats(ctypes.byref(d)), 'conv2d_packed_floats')
+        buf = torch.empty(n, dtype=torch.float32, device=weight.device)
+        slot = PackedSlot(buf, False)
+        if owner is not None and weight.is_cuda:
+            eb = lib.ap_conv2d_pack_entry_bytes()
+            room = (ctypes.c_ubyte * (4 * eb))()
+            cv = view.c_view(spec)
+            cnt = C.check(lib.ap_conv2d_pack_entries(ctypes.byref(d), ctypes.byref(cv), _ptr(buf), room, 4), 'pack_entries')
+            if cnt > 0:
+                ps = getattr(owner, '_packset', None)
+                if ps is None:
+                    ps = owner._packset = PackSet()
+                ps.register(slot, weight, bytes(room)[:cnt * eb], cnt)
+                slot.batched = True
+    if slot.batched:
+        owner._packset.refresh(weight.device)
+    else:
+        d = spec.desc(1, 64, 64)
+        dense = view.dense()
+        _require_device(dense, 'weight')
+        C.check(lib.ap_conv2d_pack_weights(ctypes.byref(d), _ptr(dense), _ptr(slot.buf), _stream()), 'pack_weights')
+        slot.key = key
+    return slot
+
+
 def presplit(f, precision=None):
     """Split-bf16 copy of a (virtual) feature: XS[n][head|tail][C/8][H*W][8 x bf16] with the producer's
     InstanceNorm + activation applied (ap_split_prepass).  Cached on the Feat: one pass serves every consumer.

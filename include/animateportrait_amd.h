@@ -91,7 +91,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 4
+#define AP_ABI_VERSION 5
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -109,6 +109,29 @@ int64_t ap_conv2d_packed_floats(const ap_conv_desc* d);
 int32_t ap_conv2d_stat_tiles(const ap_conv_desc* d);
 /* re-lay the weight (layout d->w_layout, Cout/Cin/KH/KW from d) for the kernel's LDS image */
 int ap_conv2d_pack_weights(const ap_conv_desc* d, const float* weight, float* packed, ap_stream_t stream);
+
+/* ---- batched packing (training: every optimiser step invalidates every packed image of a network).
+ * A weight operand as a strided / derived view of a parameter, in OPERATOR terms: element (cout, cin, ky, kx) of the
+ * operator described by the conv descriptor sits at w[cout * s_co + cin * s_ci + ky * s_ky + kx * s_kx] -- a channel slice
+ * or a transposed-tap view of the layer's parameter for its data-gradient operators needs no contiguous copy.
+ *   s2d_c  > 0: the operator is the 2x2 space-to-depth form (4 * s2d_c input channels) of a ksrc x ksrc stride-2 layer whose
+ *               (cout, c, ky, kx) element the strides address;
+ *   rows_c > 0: the operator is the 1xK row form (ap_split_prepass_rows) of a ksrc x ksrc stem over rows_c channels. */
+typedef struct ap_weight_view {
+    const float* w;
+    int64_t s_co, s_ci, s_ky, s_kx;
+    int32_t s2d_c, rows_c, ksrc, reserved;
+} ap_weight_view;
+/* bytes of one packer entry */
+int32_t ap_conv2d_pack_entry_bytes(void);
+/* Fill `entries` (HOST memory, max_entries * ap_conv2d_pack_entry_bytes()) with the packer entries of this operator: what
+ * ap_conv2d_pack_weights would launch, with `v` as the source and `packed` as the destination.  Returns the number of entries
+ * written, 0 when the plan is not a split-bf16 plan (then use ap_conv2d_pack_weights), negative on error.  The caller
+ * concatenates the entries of all layers of a network, uploads the table once and calls ap_conv2d_pack_run after every
+ * optimiser step: one launch instead of one per (layer, operator). */
+int32_t ap_conv2d_pack_entries(const ap_conv_desc* d, const ap_weight_view* v, float* packed, void* entries, int32_t max_entries);
+/* run `count` entries of a DEVICE-resident table */
+int ap_conv2d_pack_run(const void* entries_dev, int32_t count, ap_stream_t stream);
 /* y = act(conv(src...) + bias); bias may be NULL; stat_partials may be NULL.
  * When stat_partials != NULL the epilogue also writes per-tile sum / sum of squares of the
  * pre-activation output for every (n, cout) (InstanceNorm2d statistics, networks.py:33-34). */

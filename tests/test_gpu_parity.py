@@ -970,3 +970,54 @@ def test_warp_writes_space_to_depth_split_layout(dev):
         assert torch.equal(res.data, ref.data)
         want = ops.presplit_s2d(ops.Feat(ref.data))
         assert torch.equal(res.s2d.xs.cpu(), want.xs.cpu())
+
+
+def test_batched_packer_equals_per_layer_packer(dev):
+    """ap_conv2d_pack_entries / ap_conv2d_pack_run (one launch per optimiser for all layers) write the same packed images as
+    ap_conv2d_pack_weights on contiguous operands: forward, data-gradient operands as strided views of the parameter (channel
+    slice, transposed taps), the space-to-depth and row forms, transposed layers (four fused phases)."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    from animateportrait_amd.optim import FlatAdam
+    from animateportrait_amd.autograd import _dgrad_spec
+    torch.manual_seed(5)
+    layers = [ConvLayer([64, 16, 16], 64, 3, 1, 1, ops.PAD_REFLECT), ConvLayer([64], 128, 3, 2, 1), ConvLayer([3], 64, 7, 1, 3, ops.PAD_REFLECT),
+              ConvLayer([64], 128, 4, 2, 1), ConvLayer([128], 64, 3, 2, 1, transposed=True, output_padding=1), ConvLayer([64], 64, 4, 1, 1)]
+    for l in layers:
+        l.to(dev)
+        torch.nn.init.normal_(l.weight, 0.0, 0.05)
+    opt = FlatAdam([p for l in layers for p in l.parameters()], lr=1e-3)
+    checks = []
+    l0, l1, l2, l3, l4, l5 = layers
+    checks.append((l0.packed(), l0.spec, l0.weight.detach()))
+    c0 = 0
+    for i, c in enumerate(l0.spec.cin_segments):                       # data gradients per input segment + the strip form
+        spec, _ = _dgrad_spec(l0, c)
+        w = l0.weight.detach()[:, c0:c0 + c]
+        checks.append((l0.packed_dgrad(i, spec, w), spec, w.contiguous()))
+        checks.append((l0.packed_dgrad((i, 'T'), spec, w.transpose(2, 3)), spec, w.transpose(2, 3).contiguous()))
+        c0 += c
+    checks.append((l1.packed_s2d(), l1.s2d_spec(), ops.s2d_weight(l1.weight.detach())))
+    checks.append((l3.packed_s2d(), l3.s2d_spec(), ops.s2d_weight(l3.weight.detach())))
+    checks.append((l2.packed_rows(), l2.rows_spec(), ops.stem_rows_weight(l2.weight.detach())))
+    checks.append((l4.packed(), l4.spec, l4.weight.detach()))
+    spec4, _ = _dgrad_spec(l4, 128)
+    checks.append((l4.packed_dgrad(0, spec4, l4.weight.detach()), spec4, l4.weight.detach()))
+    spec1, _ = _dgrad_spec(l1, 64)
+    checks.append((l1.packed_dgrad(0, spec1, l1.weight.detach()), spec1, l1.weight.detach()))
+    checks.append((l5.packed(), l5.spec, l5.weight.detach()))
+    # the wide operators go through the table (narrow ones -- the data gradient towards a 16-channel segment -- are planned on
+    # the fp32 kernels and keep their own packer)
+    assert opt._packset.count >= 12
+    assert all(l._slots[k].batched for l, k in ((l0, 'fwd'), (l0, ('dgrad', 0)), (l0, ('dgrad', (0, 'T'))), (l1, 's2d'),
+                                                 (l3, 's2d'), (l2, 'rows'), (l4, 'fwd'), (l5, 'fwd')))
+    for got, spec, dense in checks:
+        assert torch.equal(got, ops.pack_weights(spec, dense.contiguous()))
+    # an optimiser step invalidates every image; the next access rebuilds all of them with one launch
+    before = l0.packed().clone()
+    for p in opt._params:
+        p.grad.normal_()
+    opt.step()
+    after = l0.packed()
+    assert not torch.equal(before, after) and torch.equal(after, ops.pack_weights(l0.spec, l0.weight.detach()))
+    assert torch.equal(l1.packed_s2d(), ops.pack_weights(l1.s2d_spec(), ops.s2d_weight(l1.weight.detach())))

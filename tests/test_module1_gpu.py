@@ -99,3 +99,45 @@ def test_example_clip_from_samples_to_frames(dev, golden):
     assert frames.shape == (24, 1, 256, 256) and bool(torch.isfinite(frames).all()) and float(frames.std()) > 1e-3
     frames_cpu = stream.ClipStreamer(model, batch=16).run(photo, lm0, seq_cpu[:24], matte=matte)
     assert float((frames - frames_cpu).abs().mean()) < 1e-3
+
+
+def test_end2end_cli_from_wav(dev, golden, tmp_path, monkeypatch):
+    """``python -m animateportrait_amd.end2end --wav ... --photo_landmarks ...``: the whole of main_end2end_module2.py:181-343
+    in one process -- Module1 checkpoints loaded by path (the reference's key layout), mel windows from the wav, landmarks,
+    frames written (64 frames: the reference's add_naive_eye needs more than 45)."""
+    from PIL import Image
+    from animateportrait_amd import audio, end2end, module1 as m1, stream
+    from animateportrait_amd.synthetic import make_landmarks
+    from oracle import generator as og, static_generator as osg
+    gd = golden('module1.npz')
+    netc, netg = _nets(gd, torch.device('cpu'))
+    monkeypatch.chdir(tmp_path)
+    os.makedirs('checkpoints/e2e'); os.makedirs('checkpoints/static'); os.makedirs('m1')
+    torch.save({'G': netg.state_dict()}, 'm1/g.pth')
+    torch.save({'model_g_face_id': netc.state_dict()}, 'm1/c.pth')
+    torch.save(og.init_params(og.generator_param_shapes(3, 1, 8, 9, 3, 3), seed=1234), 'checkpoints/e2e/7_net_G_A.pth')
+    torch.save(og.init_params(osg.static_param_shapes(3, 1, 64), seed=4321), 'checkpoints/static/drawing.pth')
+    yy, xx = np.meshgrid(np.linspace(-1, 1, 256), np.linspace(-1, 1, 256), indexing='ij')
+    Image.fromarray(((np.stack([np.sin(3 * xx + yy), np.cos(2 * yy - xx), xx * yy], -1) + 1) * 127.5).astype(np.uint8)).save('photo.png')
+    Image.fromarray(((((yy / 0.8) ** 2 + (xx / 0.6) ** 2) < 1) * 255).astype(np.uint8)).save('matte.png')
+    lm0 = make_landmarks(1, torch.Generator().manual_seed(9))[0].numpy()
+    lm0[0, 0], lm0[16, 0] = 190.0, 70.0              # jaw ends set the normalisation scale (util/utils.py:349)
+    np.savetxt('photo_lm.txt', np.concatenate([lm0, np.zeros((68, 1))], 1))
+    np.savetxt('spk.txt', np.random.RandomState(3).randn(256))
+    wav = os.path.join(GOLDEN, 'female12.wav')
+    argv = ['--photo', 'photo.png', '--matte', 'matte.png', '--wav', wav, '--photo_landmarks', 'photo_lm.txt',
+            '--speaker_emb', 'spk.txt', '--load_a2l_G_name', 'm1/g.pth', '--load_a2l_C_name', 'm1/c.pth', '--max_frames', '64',
+            '--out', 'out', '--batch', '8', '--name', 'e2e', '--epoch', '7', '--ngf', '8', '--checkpoints_dir', 'checkpoints']
+    np.random.seed(0)
+    assert end2end.main(argv) == 0
+    files = sorted(os.listdir('out/frames'))
+    assert files == ['%05d.png' % k for k in range(64)]
+    got = np.stack([np.asarray(Image.open(os.path.join('out/frames', f))) for f in files])
+    assert got.shape == (64, 256, 256, 3) and got.std() > 1.0
+    # the landmark sequence the CLI derived: finite, inside a sane range around the photo's landmarks
+    fid, scale, shift = m1.adjust_and_norm_input_face(np.loadtxt('photo_lm.txt'))
+    g2, c2 = m1.load_module1('m1/g.pth', 'm1/c.pth', dev)
+    fl = m1.predict_landmarks_speaker_aware(g2, c2, audio.clip_audio_features(wav, max_frames=64), np.loadtxt('spk.txt'), fid.reshape(-1))
+    np.random.seed(0)
+    seq = m1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
+    assert np.isfinite(seq).all() and np.abs(seq.mean(0) - m1.photo_landmarks_in_pixels(fid, scale, shift)).max() < 400

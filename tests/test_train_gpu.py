@@ -176,8 +176,9 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
     # and take the other branch in ANY two evaluations (the oracle's own fp32 pass against its fp64 pass shows ~1e-2
     # L-inf on the generator for that reason; measured on D_A_coh: one flipped pixel in one 31x31 plane moves that
     # output channel's weight-gradient row by 3e-2 of the tensor maximum, every other row by 2e-6, and the layers below
-    # it by a diffuse 5e-4).  The L-inf bar gets a flip allowance there; the per-output-channel MEDIAN of the row errors
-    # (insensitive to the directly hit rows) gets half of it.
+    # it by a diffuse 5e-4; round 3 saw 6e-2 on one row of D_A_ll's 128 -> 256 layer, median row error 3e-6).  Tensors with
+    # >= 32 output-channel rows are therefore checked ROW BY ROW: all rows but 1 % (>= 1) hold HALF the flip allowance (the
+    # diffuse part), the exempt rows stay below 0.15, and so does the per-row median.  Small tensors keep the L-inf allowance.
     flip = 2e-2 if width == 64 else 0.0
 
     def rowmed(a, b64):
@@ -195,7 +196,15 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
         me, mnoise = rowmed(mine, g64), rowmed(g32, g64)
         all_.append((tag, k, round(e, 6), round(noise, 6), round(me, 6), round(mnoise, 6)))
         fl = floor if tag == 'G' else floor_d
-        if e > 3.0 * noise + fl + flip or me > 3.0 * mnoise + fl + 0.5 * flip:
+        if flip and mine.dim() >= 2 and mine.shape[0] >= 32:
+            # full width, a tensor with many output-channel rows: a flipped (leaky) ReLU pixel hits the rows of the planes it
+            # sits in and nothing else -- so instead of loosening L-inf for the whole tensor, every row must hold the
+            # no-flip bar except at most 1 % of them (>= 1), and those stay below the size of a few flips
+            d = (mine.detach().cpu().double() - g64.double()).abs().flatten(1).amax(1) / g64.double().abs().max().clamp_min(1e-30)
+            over = d > 3.0 * noise + fl + 0.5 * flip
+            if int(over.sum()) > max(1, mine.shape[0] // 100) or float(d.max()) > 0.15 or me > 3.0 * mnoise + fl + 0.5 * flip:
+                bad.append((tag, k, e, noise, me, mnoise, int(over.sum())))
+        elif e > 3.0 * noise + fl + flip or me > 3.0 * mnoise + fl + 0.5 * flip:
             bad.append((tag, k, e, noise, me, mnoise))
     for k in sdG:
         check('G', k, gG[k], r32['gG'][k], r64['gG'][k])
@@ -403,3 +412,50 @@ def test_autograd_guards_and_generator_input_gradient(dev):
     # (d)
     with pytest.raises(NotImplementedError, match='flow'):
         G(args[0], args[1], args[2], args[3], args[4].clone().requires_grad_(True), args[5])
+
+
+def test_gradient_block_path_respects_autograd_contract(dev):
+    """the direct path of _NetFn.backward (parameter gradients written into the optimiser's flat buffer) is taken
+    only when autograd asked for every trainable parameter AND every p.grad still is its flat view.
+    * torch.autograd.grad(loss, [input]) must not touch the optimiser's gradient buffer;
+    * torch.autograd.grad(loss, params) returns real tensors;
+    * after module.zero_grad() (p.grad = None) stale sums in the flat buffer must not be added to."""
+    from animateportrait_amd import networks
+    from animateportrait_amd.optim import FlatAdam
+    torch.manual_seed(2)
+    D = networks.define_D(1, 8, 'basic', 3, 'instance', 'normal', 0.02, [0])
+    opt = FlatAdam(D.parameters(), lr=1e-3)
+    x = torch.randn(2, 1, 64, 64, device=dev, requires_grad=True)
+    # reference gradients through the train step's flow (the model wraps its .backward() calls the same way)
+    from animateportrait_amd.autograd import direct_param_grads
+    opt.zero_grad()
+    with direct_param_grads():
+        D(x).square().mean().backward()
+    ref = opt.flat_grad.clone()
+    # ... and without the opt-in the same numbers arrive through autograd's own accumulation
+    opt.zero_grad()
+    x.grad = None
+    D(x).square().mean().backward()
+    assert torch.allclose(opt.flat_grad, ref, rtol=1e-5, atol=1e-7 * float(ref.abs().max()))
+    ref_x = x.grad.clone()
+    assert float(ref.abs().max()) > 0
+    # (1) gradient w.r.t. the input only: the flat buffer stays as it is
+    opt.zero_grad()
+    (gx,) = torch.autograd.grad(D(x).square().mean(), [x])
+    assert float(opt.flat_grad.abs().max()) == 0.0 and torch.allclose(gx, ref_x, rtol=1e-5, atol=1e-8)
+    # (2) gradients w.r.t. the parameters as returned tensors
+    params = [p for p in D.parameters()]
+    gs = torch.autograd.grad(D(x).square().mean(), params)
+    assert all(g is not None for g in gs) and float(opt.flat_grad.abs().max()) == 0.0
+    flat = torch.cat([g.reshape(-1) for g in gs])
+    assert torch.allclose(flat, ref, rtol=1e-4, atol=1e-7 * float(ref.abs().max()))
+    # (3) module.zero_grad() drops the views; stale contents of the flat buffer must not leak into the next backward
+    opt.flat_grad.fill_(7.0)
+    D.zero_grad()                                         # set_to_none
+    assert all(p.grad is None for p in D.parameters())
+    with direct_param_grads():                            # even when opted in: p.grad is no longer the flat view
+        D(x).square().mean().backward()
+    got = torch.cat([p.grad.reshape(-1) for p in D.parameters()])
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-7 * float(ref.abs().max()))
+    opt.step()                                            # _rebind copies the fresh gradients into the flat buffer
+    assert all(p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * p._flat_off for p in D.parameters())
