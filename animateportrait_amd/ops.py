@@ -284,9 +284,10 @@ def packed_slot(spec, weight, view, slot):
                     ps = owner._packset = PackSet()
                 ps.register(slot, weight, bytes(room)[:cnt * eb], cnt)
                 slot.batched = True
-    if slot.batched:
-        owner._packset.refresh(weight.device)
+    if slot.batched and slot.key is not None:
+        owner._packset.refresh(weight.device)             # stale by an optimiser step: every image of the set in one launch
     else:
+        # the unbatched packer -- also for the first image of a table member (the table run would rebuild all the others)
         d = spec.desc(1, 64, 64)
         dense = view.dense()
         _require_device(dense, 'weight')

@@ -11,8 +11,9 @@ Pinning: the first three groups are pinned to outputs of the reference's own fun
 stand-ins of ``animateportrait_amd/standins.py`` because their checkpoints are not in the reference tree).
 ``draw2`` needs OpenCV, which is absent from this image: ``cv2_filled_circle_rows`` restates the octant walk of
 ``Circle()`` in OpenCV's modules/imgproc/src/drawing.cpp (opencv-python==4.2.0.34, requirements.txt:2) -- PARITY
-UNPINNED for that one function (no cv2 here to run it against); the r=1 plus and r=2 diamond it yields are OpenCV's
-well-known small discs.
+UNPINNED against cv2 for that one function (no cv2 here to run it against); the row tables it yields (r = 3: 3/2/2/0,
+r = 4: 4/3/3/2/0, ...) are committed as literals in tests/golden/opencv_rules.json next to the thick-line rasters of
+oracle/cv_raster.py, and tests/golden/check_opencv_rules.py is the one-minute check for a maintainer with cv2.
 """
 import numpy as np
 import torch

@@ -11,8 +11,8 @@ python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 bash tools/gen_prof.sh ${TAG}_gen > gpurun_out/${TAG}_gen_prof.log 2>&1
 mv gpurun_out/${TAG}_gen_kernel_stats.md gpurun_out/${TAG}_gen_kernel_stats.md 2>/dev/null
 bash tools/pmc_prof.sh ${TAG} > gpurun_out/${TAG}_pmc.log 2>&1
-python tools/hbm_table.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_gen_gen_kernel_stats.md gpurun_out/${TAG}_hbm_per_kernel.md 20 > /dev/null 2>&1 || \
-python tools/hbm_table.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_gen_kernel_stats.md gpurun_out/${TAG}_hbm_per_kernel.md 20 > /dev/null 2>&1
+python tools/hbm_table.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_gen_gen_kernel_stats.md gpurun_out/${TAG}_hbm_per_kernel.md 30 > /dev/null 2>&1 || \
+python tools/hbm_table.py gpurun_out/${TAG}_pmc_fetch.json gpurun_out/${TAG}_pmc_write.json gpurun_out/${TAG}_gen_kernel_stats.md gpurun_out/${TAG}_hbm_per_kernel.md 30 > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 for MODE in bf16x3 bf16; do
   rm -rf $ROOT/gpurun_out/${TAG}_tr_$MODE
