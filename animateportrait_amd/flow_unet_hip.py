@@ -108,11 +108,56 @@ class FlowUnetV2Hip(nn.Module):
             self.dec_res.append(nn.ModuleList([_ResBlock(getattr(net, 'dec_%d_res_%d' % (l, k))) for k in range(self.n_res)]))
             self.pred_flow.append(_layer(getattr(net, 'pred_flow_%d' % l)[1], None))
         self.pred_vis = _layer(net.pred_vis[1], None)
+        # flow_network_warp (geomgm_ifw_fore_model.py:69-84) uses flow_out and vis_out only: with ``heads_only`` the
+        # lower pyramid heads are skipped and the two full-resolution heads (c -> 2, c -> 3) run as ONE 5-output layer
+        # (a 2- or 3-output layer fills 1/16 of a 32-cout MFMA tile either way)
+        self.heads_only = False
+        self.use_graph = False             # replay the forward pass as a hipGraph (set by the streaming callers)
+        self._graphs = {}
+        f0, vs = net.pred_flow_0[1], net.pred_vis[1]
+        self.pred_both = ConvLayer([f0.in_channels], 5, 3, 1, 1, PAD_ZERO)
+        with torch.no_grad():
+            self.pred_both.weight.copy_(torch.cat([f0.weight.detach().float(), vs.weight.detach().float()], 0))
+            self.pred_both.bias.copy_(torch.cat([f0.bias.detach().float(), vs.bias.detach().float()], 0))
+        for q in self.pred_both.parameters():
+            q.requires_grad_(False)
 
     @torch.no_grad()
     def forward(self, x):
         if not x.is_cuda:
             raise RuntimeError('FlowUnetV2Hip runs on the MI355X only (the stock-PyTorch mirror is flow_unet.FlowUnetV2)')
+        if self.use_graph and not torch.cuda.is_current_stream_capturing():
+            return self._replay(x)
+        return self._forward(x)
+
+    def _replay(self, x):
+        """The ~150 launches of a forward pass as ONE hipGraph launch per input shape.  The network is frozen and its layers
+        are small at the deep scales, so a clip spends more host time issuing these launches than the GPU spends running them
+        (profiles/r03z_stream_kernel_stats.md: 6.5 ms of host work per batch of 16 against ~3 ms of kernels).  Capture goes
+        through torch.cuda.graph (its private pool owns the intermediate buffers); the C-ABI launches land on the capturing
+        stream because every call passes torch's current stream."""
+        key = (tuple(x.shape), x.device.index)
+        ent = self._graphs.get(key)
+        if ent is None:
+            static_in = torch.empty_like(x, dtype=torch.float32).contiguous()
+            static_in.copy_(x)
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                      # warm-up: kernel attributes, packed weights, allocator
+                for _ in range(2):
+                    self._forward(static_in)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self._forward(static_in)
+            ent = self._graphs[key] = (graph, static_in, outs)
+        graph, static_in, outs = ent
+        static_in.copy_(x)
+        graph.replay()
+        # the graph's output buffers are overwritten by the next replay: hand out copies (a few MB)
+        return tuple(o.clone() if torch.is_tensor(o) else ([t.clone() for t in o] if o is not None else None) for o in outs)
+
+    def _forward(self, x):
         f = self.pre0.run([Feat(x.float().contiguous())])
         for res, down in zip(self.pre_res, self.pre_down):
             f = down.run([_relu(res.run(f))])
@@ -126,10 +171,14 @@ class FlowUnetV2Hip(nn.Module):
             f = Feat(ops.pixel_shuffle2(self.dec_up[l].run([_relu(f)]).data))
             for k in range(self.n_res - 1, -1, -1):
                 f = self.dec_res[l][k].run(f, hiddens.pop())
-            flow_pyr.insert(0, self.pred_flow[l].run([_relu(f)]).data)
-        vis = self.pred_vis.run([_relu(f)]).data
+            if not self.heads_only:
+                flow_pyr.insert(0, self.pred_flow[l].run([_relu(f)]).data)
         s = self.start_scale
 
         def up(t):
             return ops.resize_bilinear(t, (t.shape[2] * s, t.shape[3] * s))
+        if self.heads_only:
+            both = up(self.pred_both.run([_relu(f)]).data)               # bilinear up-sampling is per channel
+            return both[:, 0:2].contiguous(), both[:, 2:5].contiguous(), None, f.data
+        vis = self.pred_vis.run([_relu(f)]).data
         return up(flow_pyr[0]), up(vis), flow_pyr, f.data

@@ -73,6 +73,8 @@ class BaseModel(ABC):
                 # the frozen regressor runs on the HIP convolution kernels (BatchNorm folded: flow_unet_hip.py) ...
                 from ..flow_unet_hip import FlowUnetV2Hip
                 aux['netF'] = FlowUnetV2Hip(net).to(self.device)
+                aux['netF'].heads_only = True          # flow_network_warp reads flow_out / vis_out only
+                aux['netF'].use_graph = True           # one hipGraph launch per call instead of ~150 small launches
             except NotImplementedError as e:
                 # ... unless its configuration cannot be folded (norm='instance'): then the stock-PyTorch mirror
                 print('[netF] %s: running FlowUnet_v2 as stock PyTorch modules' % e)

@@ -205,6 +205,8 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     torch.manual_seed(4321)
     netF_cpu = flow_unet.FlowUnetV2(136, nf=64, max_nf=256, start_scale=2, num_scales=4, n_residual_blocks=2, norm='batch').eval()
     model.aux['netF'] = flow_unet_hip.FlowUnetV2Hip(netF_cpu).to(dev)
+    model.aux['netF'].heads_only = True        # as BaseModel.attach_flow_network sets it: flow_out / vis_out only
+    model.aux['netF'].use_graph = True         # ... and one hipGraph launch per call
     content = module1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5).to(dev).eval()      # train_audio2landmark.py:71-73
     pose = module1.Audio2LandmarkPos(drop_out=0.5).to(dev).eval()                                  # :55-59
     spk = torch.randn(256, generator=torch.Generator().manual_seed(7))

@@ -102,7 +102,7 @@ def test_models_attach_the_hip_flow_network_from_its_checkpoint(dev, tmp_path):
         model = create_model(opt)
     model.FLOW_CHECKPOINT_DIR = str(tmp_path)
     model.attach_flow_network()
-    assert isinstance(model.aux['netF'], FlowUnetV2Hip)
+    assert isinstance(model.aux['netF'], FlowUnetV2Hip) and model.aux['netF'].heads_only and model.aux['netF'].use_graph
     g = torch.Generator().manual_seed(2)
     lm1, lm2 = make_landmarks(2, g), make_landmarks(2, g)
     photo = torch.rand(2, 3, 256, 256, generator=g) * 2 - 1
@@ -113,3 +113,13 @@ def test_models_attach_the_hip_flow_network_from_its_checkpoint(dev, tmp_path):
     agree = (mask.cpu() - rmask).abs() < 1e-4
     assert float(agree.float().mean()) > 0.999
     assert float(((flow.cpu() - rflow).abs() * agree).max()) <= 2e-4 * float(rflow.abs().max()) + 1e-5
+    # the merged 5-output head == the two separate heads of the full forward
+    x = (torch.rand(2, 136, 64, 64, generator=g) > 0.97).float().to(dev)
+    fa, va, _, _ = model.aux['netF'](x)
+    fa2, va2, _, _ = model.aux['netF'](x * 0 + (torch.rand(x.shape, device=dev) > 0.9).float())   # a replay on other data
+    fa3, va3, _, _ = model.aux['netF'](x)                         # and back: the graph is a function of its input only
+    assert torch.equal(fa, fa3) and torch.equal(va, va3) and not torch.equal(fa, fa2)
+    model.aux['netF'].heads_only = False
+    model.aux['netF'].use_graph = False
+    fb, vb, pyr, _ = model.aux['netF'](x)
+    assert len(pyr) == CONFIG['num_scales'] and torch.allclose(fa, fb, atol=1e-6) and torch.allclose(va, vb, atol=1e-6)
