@@ -628,6 +628,8 @@ struct NormSplitParams {
     float* y;                 // fp32 output or null
     uint4* xs;                // split output or null
     int heads_only;           // 1: only the head planes of xs are written (consumers in AP_PRECISION_BF16 never read tails)
+    int xs_relu;              // 1: the split copy holds relu(v) while y holds v -- the next layer's `activation -> conv` of a
+                              // pre-activation residual stream (FlowUnet_v2's ResidualBlock) without a second pass
     int N, C, HW;
 };
 
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             __bf16 h, l;
-            split_bf16(v[c][0], h, l);
+            split_bf16(p.xs_relu ? fmaxf(v[c][0], 0.f) : v[c][0], h, l);
             hv[c] = h;
             lv[c] = l;
         }
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 __bf16 h, l;
-                split_bf16(live ? v[c][j] : 0.f, h, l);
+                split_bf16(live ? (p.xs_relu ? fmaxf(v[c][j], 0.f) : v[c][j]) : 0.f, h, l);
                 hv[c] = h;
                 lv[c] = l;
             }

@@ -626,6 +626,7 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
     if (residual) { p.res = residual->data; p.res_mean = residual->mean; p.res_rstd = residual->rstd; }
     p.y = y; p.xs = reinterpret_cast<uint4*>(xs);
     p.heads_only = (flags & 1) ? 1 : 0;
+    p.xs_relu = (flags & 2) ? 1 : 0;
     p.N = N; p.C = src->C; p.HW = H * W;
     if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
         dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);

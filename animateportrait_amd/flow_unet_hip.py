@@ -50,18 +50,39 @@ def _layer(conv, bn, segs=None, shuffle=1):
     return layer
 
 
-def _relu(f):
-    """activation(f) as a consumer-side activation (f is a materialised tensor)."""
-    return Feat(f.data, act=ACT_RELU)
+class _Act:
+    """A materialised pre-activation feature and, lazily, its ``activation(f)`` view for the conv loaders: ONE Feat per
+    feature, so the split-bf16 copy of relu(f) is made once however many layers read it (an encoder feature feeds the next
+    block, the down-sampling layer and -- as ``hiddens`` -- the decoder's channel_mapping)."""
+    __slots__ = ('f', '_relu')
+
+    def __init__(self, f, relu_xs=None):
+        self.f = f
+        self._relu = None
+        if relu_xs is not None:
+            self._relu = Feat(f.data, act=ACT_RELU)
+            self._relu.xs = relu_xs                     # (the loader of a split-bf16 layer takes the copy as it is)
+            self._relu.xs_heads_only = ops.DEFAULT_PRECISION == ops.PRECISION_BF16
+
+    @property
+    def data(self):
+        return self.f.data
+
+    def relu(self):
+        if self._relu is None:
+            self._relu = Feat(self.f.data, act=ACT_RELU)
+        return self._relu
 
 
 def _add(y, x):
-    """x + y for plain features, in the pass that also makes the split-bf16 copy the next wide convolution reads."""
+    """x + y for plain features; the same pass writes the split-bf16 copy of relu(x + y) that the next ``activation -> conv``
+    stages (ap_norm_apply_split_ex, flag bit 1)."""
     n, c, h, w = y.data.shape
     if c % 8:
-        return Feat(y.data + x.data)                                   # (never the case for nf % 8 == 0)
-    out, xs = ops._norm_apply_split(Feat(y.data), Feat(x.data), want_y=True, want_xs=False)
-    return Feat(out)
+        return _Act(Feat(y.data + x.data))                             # (never the case for nf % 8 == 0)
+    want_xs = ops.wants_split(c)
+    out, xs = ops._norm_apply_split(Feat(y.data), Feat(x.data), want_y=True, want_xs=want_xs, xs_relu=True)
+    return _Act(Feat(out), xs)
 
 
 class _ResBlock(nn.Module):
@@ -76,11 +97,12 @@ class _ResBlock(nn.Module):
             self.conv = _layer(blk.conv[0], blk.conv[1])
 
     def run(self, x, a=None):
+        """x, a: _Act; returns _Act"""
         if self.has_a:
-            ya = self.conv_a.run([_relu(a)])
-            y = self.conv.run([_relu(x), _relu(ya)])
+            ya = _Act(self.conv_a.run([a.relu()]))
+            y = self.conv.run([x.relu(), ya.relu()])
         else:
-            y = self.conv.run([_relu(x)])
+            y = self.conv.run([x.relu()])
         return _add(y, x)
 
 
@@ -158,27 +180,27 @@ class FlowUnetV2Hip(nn.Module):
         return tuple(o.clone() if torch.is_tensor(o) else ([t.clone() for t in o] if o is not None else None) for o in outs)
 
     def _forward(self, x):
-        f = self.pre0.run([Feat(x.float().contiguous())])
+        f = _Act(self.pre0.run([Feat(x.float().contiguous())]))
         for res, down in zip(self.pre_res, self.pre_down):
-            f = down.run([_relu(res.run(f))])
+            f = _Act(down.run([res.run(f).relu()]))
         hiddens, flow_pyr = [], []
         for l in range(self.num_scales):
             for blk in self.enc_res[l]:
                 f = blk.run(f)
                 hiddens.append(f)
-            f = self.enc_down[l].run([_relu(f)])
+            f = _Act(self.enc_down[l].run([f.relu()]))
         for l in range(self.num_scales - 1, -1, -1):
-            f = Feat(ops.pixel_shuffle2(self.dec_up[l].run([_relu(f)]).data))
+            f = _Act(Feat(ops.pixel_shuffle2(self.dec_up[l].run([f.relu()]).data)))
             for k in range(self.n_res - 1, -1, -1):
                 f = self.dec_res[l][k].run(f, hiddens.pop())
             if not self.heads_only:
-                flow_pyr.insert(0, self.pred_flow[l].run([_relu(f)]).data)
+                flow_pyr.insert(0, self.pred_flow[l].run([f.relu()]).data)
         s = self.start_scale
 
         def up(t):
             return ops.resize_bilinear(t, (t.shape[2] * s, t.shape[3] * s))
         if self.heads_only:
-            both = up(self.pred_both.run([_relu(f)]).data)               # bilinear up-sampling is per channel
+            both = up(self.pred_both.run([f.relu()]).data)               # bilinear up-sampling is per channel
             return both[:, 0:2].contiguous(), both[:, 2:5].contiguous(), None, f.data
-        vis = self.pred_vis.run([_relu(f)]).data
+        vis = self.pred_vis.run([f.relu()]).data
         return up(flow_pyr[0]), up(vis), flow_pyr, f.data

@@ -412,7 +412,7 @@ def _alloc_xs(x):
     return torch.empty(nbytes, dtype=torch.uint8, device=x.device)
 
 
-def _norm_apply_split(f, residual, want_y, want_xs):
+def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
     """One ap_norm_apply_split pass over ``f``: finalises pending statistics on the way, returns the fp32
     tensor ``act(IN(f)) [+ IN(residual)]`` (want_y) and / or its split-bf16 copy (want_xs).  Without a residual the
     split copy is f's own and is cached on it."""
@@ -442,7 +442,7 @@ def _norm_apply_split(f, residual, want_y, want_xs):
     xs = _alloc_xs(x) if want_xs else None
     # plain-bf16 mode: no kernel reads tail planes, so they are not written (the package-wide mode decides: split
     # copies are shared by every consumer of a feature)
-    flags = 1 if DEFAULT_PRECISION == PRECISION_BF16 else 0
+    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0)
     C.check(C.lib().ap_norm_apply_split_ex(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
                                            ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
                                            flags, _stream()), 'norm_apply_split')
