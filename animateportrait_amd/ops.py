@@ -227,10 +227,10 @@ class WeightView:
 
 
 class PackedSlot:
-    __slots__ = ('buf', 'key', 'batched')
+    __slots__ = ('buf', 'key', 'batched', 'owner')
 
     def __init__(self, buf, batched):
-        self.buf, self.key, self.batched = buf, None, batched
+        self.buf, self.key, self.batched, self.owner = buf, None, batched, None
 
 
 class PackSet:
@@ -266,6 +266,9 @@ def packed_slot(spec, weight, view, slot):
     key = weight_key(weight)
     if slot is not None and slot.key == key:
         return slot
+    if slot is not None and (slot.buf.device != weight.device or
+                             (slot.batched and slot.owner is not getattr(weight, '_flat_owner', None))):
+        slot = None                      # the module moved to another device / to another optimiser: start over
     owner = getattr(weight, '_flat_owner', None)
     lib = C.lib()
     if slot is None:
@@ -283,7 +286,7 @@ def packed_slot(spec, weight, view, slot):
                 if ps is None:
                     ps = owner._packset = PackSet()
                 ps.register(slot, weight, bytes(room)[:cnt * eb], cnt)
-                slot.batched = True
+                slot.batched, slot.owner = True, owner
     if slot.batched and slot.key is not None:
         owner._packset.refresh(weight.device)             # stale by an optimiser step: every image of the set in one launch
     else:
