@@ -9,6 +9,7 @@ so reference checkpoints (``<epoch>_net_G_A.pth`` ...) load with ``strict=True``
 The modules own their parameters as ordinary ``nn.Parameter``s; ``forward`` never touches a
 torch operator for the math -- every layer is a call into libapamd.so (HIP, gfx950).
 """
+import os
 import functools
 
 import torch
@@ -181,6 +182,15 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
                                          _6=ConvLayer([con_dim], con_dim, 3, 2, 1))
         self.land1_cache_key = None      # set by a streaming caller: identity of the (constant) land1 tensor, see _run
         self._land1_cache = None
+        self.branch_streams = os.environ.get('APAMD_BRANCH_STREAMS', '1') != '0'   # inference: encoder branches on their own HIP streams (see _run)
+        self._streams = {}
+        self._packed_for = None
+
+    def _side_streams(self, device):
+        st = self._streams.get(device.index)
+        if st is None:
+            st = self._streams[device.index] = [torch.cuda.Stream(device=device) for _ in range(4)]
+        return st
 
     def is_block2(self, i):
         return (i + self.disp) % self.div == 0
@@ -206,43 +216,80 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         self._last_input_feat = inp if tape is not None else None
         motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
         cf, dfw = conv_forward, self.double_feature_warping
-        x1 = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)
-        x1 = dfw(x1, motion, flow, ifmask, 0, tape, self.model_tri01['0'])
-        x1 = cf(tape, self.model_tri01['0'], x1, norm_act=ACT_RELU)
-        x1 = cf(tape, self.model_tri02['0'], x1, norm_act=ACT_RELU)
-        x2 = cf(tape, self.model_tri10['1'], inp, norm_act=ACT_RELU)
-        x2 = cf(tape, self.model_tri11['0'], x2, norm_act=ACT_RELU)
-        x2 = dfw(x2, motion, flow, ifmask, 1, tape, self.model_tri12['0'])
-        x2 = cf(tape, self.model_tri12['0'], x2, norm_act=ACT_RELU)
-        x3 = cf(tape, self.model_tri20['1'], inp, norm_act=ACT_RELU)
-        x3 = cf(tape, self.model_tri21['0'], x3, norm_act=ACT_RELU)
-        x3 = cf(tape, self.model_tri22['0'], x3, norm_act=ACT_RELU)
-        x3 = dfw(x3, motion, flow, ifmask, 2, tape, self.model_tri_merge)
-        x = cf(tape, self.model_tri_merge, [x1, x2, x3])
-        lt = self.model_landmark_trans
-        key = self.land1_cache_key
-        if tape is None and key is not None:
-            # streaming inference: land1 is the photo's landmark map, the same for every frame of a clip -- the caller
-            # (GeomCGTIFWTestModel) names it with land1_cache_key and its encoding (networks.py:1331-1332) is reused;
-            # only land2 runs through the encoder.  Never on by default: a cached result must not enter a timed step.
-            full = (key, tuple(land1.shape), tuple(ops.weight_key(lt[k].weight) for k in ('0', '3', '6')))
-            if self._land1_cache is None or self._land1_cache[0] != full:
-                l = cf(None, lt['0'], Feat(land1.contiguous()), norm_act=ACT_RELU)
-                l = cf(None, lt['3'], l, norm_act=ACT_RELU)
-                l = cf(None, lt['6'], l, norm_act=ACT_NONE)
-                l.mean                                           # finalise the statistics once
-                self._land1_cache = (full, l)
-            l1 = self._land1_cache[1]
-            l2 = cf(None, lt['0'], Feat(land2.contiguous()), norm_act=ACT_RELU)
-            l2 = cf(None, lt['3'], l2, norm_act=ACT_RELU)
-            l2 = cf(None, lt['6'], l2, norm_act=ACT_NONE)
-        else:
+
+        def branch1():
+            x = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)
+            x = dfw(x, motion, flow, ifmask, 0, tape, self.model_tri01['0'])
+            x = cf(tape, self.model_tri01['0'], x, norm_act=ACT_RELU)
+            return cf(tape, self.model_tri02['0'], x, norm_act=ACT_RELU)
+
+        def branch2():
+            x = cf(tape, self.model_tri10['1'], inp, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri11['0'], x, norm_act=ACT_RELU)
+            x = dfw(x, motion, flow, ifmask, 1, tape, self.model_tri12['0'])
+            return cf(tape, self.model_tri12['0'], x, norm_act=ACT_RELU)
+
+        def branch3():
+            x = cf(tape, self.model_tri20['1'], inp, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri21['0'], x, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri22['0'], x, norm_act=ACT_RELU)
+            return dfw(x, motion, flow, ifmask, 2, tape, self.model_tri_merge)
+
+        def landmarks():
+            lt = self.model_landmark_trans
+            key = self.land1_cache_key
+            if tape is None and key is not None:
+                # streaming inference: land1 is the photo's landmark map, the same for every frame of a clip -- the caller
+                # (GeomCGTIFWTestModel) names it with land1_cache_key and its encoding (networks.py:1331-1332) is reused;
+                # only land2 runs through the encoder.  Never on by default: a cached result must not enter a timed step.
+                full = (key, tuple(land1.shape), tuple(ops.weight_key(lt[k].weight) for k in ('0', '3', '6')))
+                if self._land1_cache is None or self._land1_cache[0] != full:
+                    l = cf(None, lt['0'], Feat(land1.contiguous()), norm_act=ACT_RELU)
+                    l = cf(None, lt['3'], l, norm_act=ACT_RELU)
+                    l = cf(None, lt['6'], l, norm_act=ACT_NONE)
+                    l.mean                                           # finalise the statistics once
+                    self._land1_cache = (full, l)
+                la = self._land1_cache[1]
+                lb = cf(None, lt['0'], Feat(land2.contiguous()), norm_act=ACT_RELU)
+                lb = cf(None, lt['3'], lb, norm_act=ACT_RELU)
+                lb = cf(None, lt['6'], lb, norm_act=ACT_NONE)
+                return la, lb
             # land1 / land2 share the encoder weights: one pass over the 2B batch
             lands = Feat(torch.cat([land1, land2], 0).contiguous())
             l = cf(tape, lt['0'], lands, norm_act=ACT_RELU)
             l = cf(tape, lt['3'], l, norm_act=ACT_RELU)
             l = cf(tape, lt['6'], l, norm_act=ACT_NONE)
-            l1, l2 = batch_split_forward(tape, l, b)
+            return batch_split_forward(tape, l, b)
+
+        # (the first forward after a weight update stays on one stream: it repacks weights, possibly every image of an
+        # optimiser's table in one launch, and the other branches must not read theirs before that launch)
+        wkey = ops.weight_key(self.model_tri_merge.weight)
+        fork = tape is None and self.branch_streams and input.is_cuda and self._packed_for == wkey
+        self._packed_for = wkey
+        if fork:
+            # Inference: the three encoder branches and the landmark encoder are independent until the merge convolution
+            # (networks.py:1317-1333) and mix matrix-bound launches (stride-2 / stem convolutions) with HBM-bound ones (warp,
+            # split / space-to-depth passes, stem epilogues): each runs on its own HIP stream so that the one kind fills
+            # the other's idle pipe.  Fork / join by stream waits; tensors that cross to the main stream are recorded on it
+            # for the caching allocator.
+            main = torch.cuda.current_stream()
+            side = self._side_streams(input.device)
+            if ops.stem_rows_eligible(self.model_tri10['1'].spec):
+                ops.presplit_rows(inp, 7, 3, PAD_REFLECT)         # the row expansion the three stems share: before the fork
+            outs = []
+            for st, fn in zip(side, (branch1, branch2, branch3, landmarks)):
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    outs.append(fn())
+            for st in side:
+                main.wait_stream(st)
+            x1, x2, x3, (l1, l2) = outs
+            for f in (x1, x2, x3, l1, l2):
+                ops.record_feat_stream(f, main)
+        else:
+            x1, x2, x3 = branch1(), branch2(), branch3()
+            l1, l2 = landmarks()
+        x = cf(tape, self.model_tri_merge, [x1, x2, x3])
         for i in range(self.n_blocks):
             blk = self.model2[str(i)]
             x = blk.run([x, l1, l2], tape) if self.is_block2(i) else blk.run(x, tape)

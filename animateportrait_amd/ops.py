@@ -123,6 +123,18 @@ class Feat:
                     None if self.rstd is None else self.rstd[lo * c:hi * c], self.act)
 
 
+def record_feat_stream(f, stream):
+    """Tell the caching allocator that every tensor of Feat ``f`` (made on another stream) is also used on ``stream``."""
+    seen = [f.data, f._mean, f._rstd, f.xs]
+    if f.pending is not None:
+        seen.append(f.pending[0])
+    if f.s2d is not None:
+        seen += [f.s2d.xs]
+    for t in seen:
+        if torch.is_tensor(t) and t.is_cuda and t.untyped_storage().size() > 0:
+            t.record_stream(stream)
+
+
 class ConvSpec:
     """Static part of one convolution-like operator (everything except N, H, W and pointers)."""
 
@@ -175,13 +187,24 @@ class LaunchProfiler:
         self.records = []   # (kernel name, flops, start event, end event)
 
     def summary(self):
+        """Per kernel instantiation: launches, total ms, FLOPs.  A bracket far above its group's median (same kernel, same
+        FLOPs) is a scheduling hiccup between the two events (seen: one 22 ms bracket around a 0.2 ms launch), not kernel
+        time: it is replaced by the group's median and counted in ``outliers``."""
         torch.cuda.synchronize()
-        agg = {}
+        groups = {}
         for name, flops, e0, e1 in self.records:
-            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0))
-            a['launches'] += 1
-            a['ms'] += e0.elapsed_time(e1)
-            a['flops'] += flops
+            groups.setdefault((name, flops), []).append(e0.elapsed_time(e1))
+        agg = {}
+        for (name, flops), ts in groups.items():
+            med = sorted(ts)[len(ts) // 2]
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, outliers=0))
+            for t in ts:
+                if t > 4.0 * med:
+                    a['outliers'] += 1
+                    t = med
+                a['ms'] += t
+            a['launches'] += len(ts)
+            a['flops'] += flops * len(ts)
         return agg
 
 

@@ -378,15 +378,17 @@ def main():
     prof = ops.LaunchProfiler()
     ops.PROFILER = prof
     psteps = min(a.steps, 5)
-    for _ in range(psteps):
+    forked, G.branch_streams = G.branch_streams, False   # attribution pass on ONE stream: a launch's event bracket must not
+    for _ in range(psteps):                              # hold another branch's concurrent kernels
         step()
     ops.PROFILER = None
+    G.branch_streams = forked
     agg = prof.summary()
     if rank == 0 and os.environ.get('APAMD_BENCH_VERBOSE'):
         for name, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):
             print('  %-34s launches/step %3d  ms/step %7.3f  TFLOP/s %6.1f' % (
                 name, v['launches'] // psteps, v['ms'] / psteps, v['flops'] / (v['ms'] * 1e-3) / 1e12),
-                file=sys.stderr)
+                'outliers %d' % v['outliers'] if v['outliers'] else '', file=sys.stderr)
     dom = max(agg.items(), key=lambda kv: kv[1]['ms'])
     dname, dk = dom
     alg = dk['flops'] / (dk['ms'] * 1e-3) / 1e12          # algorithmic TFLOP/s (2 * MACs of the convolution)
@@ -407,6 +409,7 @@ def main():
                 'avg_launch_us': round(dk['ms'] * 1e3 / dk['launches'], 2),
                 'gflop_per_launch': round(dk['flops'] / dk['launches'] / 1e9, 3),
                 'conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / psteps, 3),
+                'bracket_outliers_replaced': sum(v['outliers'] for v in agg.values()),
                 'traffic': None}
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     if os.path.exists(tpath):
