@@ -361,13 +361,15 @@ class GeomGMIFWForeModel(BaseModel):
         self.set_requires_grad(nets_D, False)
         self.optimizer_G.zero_grad()
         self.backward_G()
-        # G's gradients travel (one RCCL all-reduce over xGMI) while the D backward passes run: those read only the
-        # frames generated in forward() and the D weights, so deferring G's update behind them changes no value
+        # G's gradients are exchanged right away (one RCCL all-reduce over xGMI); its update is deferred behind the D
+        # backward passes, which read only the frames generated in forward() and the D weights.  With
+        # parallel.OVERLAP_COLLECTIVES the exchange stays in flight under those passes; by default the compute stream
+        # waits for it at once (kernels of another stream must not share the device with the matrix kernels, parallel.py)
         g_work = parallel.allreduce_optimizer_grads(self.optimizer_G, async_op=True)
         self.set_requires_grad(nets_D, True)
         self.optimizer_D.zero_grad()
-        # every discriminator's gradients start travelling as soon as its backward pass is enqueued (one collective per
-        # D over its slice of the flat gradient buffer), under the backward passes of the discriminators that follow
+        # every discriminator's gradients are exchanged as soon as its backward pass is enqueued (one collective per D
+        # over its slice of the flat gradient buffer)
         d_works, d_whole = [], False
 
         def exchange(net):

@@ -9,7 +9,6 @@ so reference checkpoints (``<epoch>_net_G_A.pth`` ...) load with ``strict=True``
 The modules own their parameters as ordinary ``nn.Parameter``s; ``forward`` never touches a
 torch operator for the math -- every layer is a call into libapamd.so (HIP, gfx950).
 """
-import os
 import functools
 
 import torch
@@ -182,15 +181,6 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
                                          _6=ConvLayer([con_dim], con_dim, 3, 2, 1))
         self.land1_cache_key = None      # set by a streaming caller: identity of the (constant) land1 tensor, see _run
         self._land1_cache = None
-        self.branch_streams = os.environ.get('APAMD_BRANCH_STREAMS', '1') != '0'   # inference: encoder branches on their own HIP streams (see _run)
-        self._streams = {}
-        self._packed_for = None
-
-    def _side_streams(self, device):
-        st = self._streams.get(device.index)
-        if st is None:
-            st = self._streams[device.index] = [torch.cuda.Stream(device=device) for _ in range(4)]
-        return st
 
     def is_block2(self, i):
         return (i + self.disp) % self.div == 0
@@ -261,34 +251,11 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
             l = cf(tape, lt['6'], l, norm_act=ACT_NONE)
             return batch_split_forward(tape, l, b)
 
-        # (the first forward after a weight update stays on one stream: it repacks weights, possibly every image of an
-        # optimiser's table in one launch, and the other branches must not read theirs before that launch)
-        wkey = ops.weight_key(self.model_tri_merge.weight)
-        fork = tape is None and self.branch_streams and input.is_cuda and self._packed_for == wkey
-        self._packed_for = wkey
-        if fork:
-            # Inference: the three encoder branches and the landmark encoder are independent until the merge convolution
-            # (networks.py:1317-1333) and mix matrix-bound launches (stride-2 / stem convolutions) with HBM-bound ones (warp,
-            # split / space-to-depth passes, stem epilogues): each runs on its own HIP stream so that the one kind fills
-            # the other's idle pipe.  Fork / join by stream waits; tensors that cross to the main stream are recorded on it
-            # for the caching allocator.
-            main = torch.cuda.current_stream()
-            side = self._side_streams(input.device)
-            if ops.stem_rows_eligible(self.model_tri10['1'].spec):
-                ops.presplit_rows(inp, 7, 3, PAD_REFLECT)         # the row expansion the three stems share: before the fork
-            outs = []
-            for st, fn in zip(side, (branch1, branch2, branch3, landmarks)):
-                st.wait_stream(main)
-                with torch.cuda.stream(st):
-                    outs.append(fn())
-            for st in side:
-                main.wait_stream(st)
-            x1, x2, x3, (l1, l2) = outs
-            for f in (x1, x2, x3, l1, l2):
-                ops.record_feat_stream(f, main)
-        else:
-            x1, x2, x3 = branch1(), branch2(), branch3()
-            l1, l2 = landmarks()
+        # ONE stream: the three branches and the landmark encoder are independent until the merge convolution, but they
+        # must not run on side streams -- measured in round 3 (tools/conc_warp.py): a warp kernel that
+        # shares compute units with one of the matrix kernels of another stream reads wrong data in lanes 48-63.
+        x1, x2, x3 = branch1(), branch2(), branch3()
+        l1, l2 = landmarks()
         x = cf(tape, self.model_tri_merge, [x1, x2, x3])
         for i in range(self.n_blocks):
             blk = self.model2[str(i)]

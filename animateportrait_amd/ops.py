@@ -123,18 +123,6 @@ class Feat:
                     None if self.rstd is None else self.rstd[lo * c:hi * c], self.act)
 
 
-def record_feat_stream(f, stream):
-    """Tell the caching allocator that every tensor of Feat ``f`` (made on another stream) is also used on ``stream``."""
-    seen = [f.data, f._mean, f._rstd, f.xs]
-    if f.pending is not None:
-        seen.append(f.pending[0])
-    if f.s2d is not None:
-        seen += [f.s2d.xs]
-    for t in seen:
-        if torch.is_tensor(t) and t.is_cuda and t.untyped_storage().size() > 0:
-            t.record_stream(stream)
-
-
 class ConvSpec:
     """Static part of one convolution-like operator (everything except N, H, W and pointers)."""
 

@@ -57,13 +57,27 @@ def shard_batch(batch, rank, world):
     return out
 
 
+# RCCL runs its kernels on its own HIP stream.  Measured on MI355X (tools/conc_warp.py): while one
+# of this library's large matrix kernels (LDS-DMA + MFMA, > 256 registers per lane) shares compute units with a kernel
+# of ANOTHER stream, that kernel can read wrong data in lanes 48-63 -- the library's own warp kernel did, in 60 % of its
+# launches, and a compiler-only reproducer exists (tools/xcdvis/aggr_lib.hip).  A collective must therefore never be
+# in flight next to the backward pass: the compute stream is ordered behind every collective at once (``work.wait()``
+# is a stream wait on RCCL, no host block), which costs ~1-2 ms of exposed exchange per train step on one node.
+# APAMD_OVERLAP_COLLECTIVES=1 restores the overlapped form (collectives travel under the following backward passes).
+OVERLAP_COLLECTIVES = os.environ.get('APAMD_OVERLAP_COLLECTIVES', '0') == '1'
+
+
 def allreduce_flat_(flat, async_op=False):
-    """In-place mean of one flat gradient buffer over all ranks."""
+    """In-place mean of one flat gradient buffer over all ranks.  async_op=True returns the work handle; on the GPU the
+    compute stream has already been ordered behind it unless OVERLAP_COLLECTIVES (see above)."""
     w = world_size()
     if w == 1:
         return None
     flat.div_(w)
-    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+    work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
+    if async_op and flat.is_cuda and not OVERLAP_COLLECTIVES:
+        work.wait()
+    return work
 
 
 def allreduce_gradients(params, bucket_bytes=32 << 20):

@@ -378,11 +378,9 @@ def main():
     prof = ops.LaunchProfiler()
     ops.PROFILER = prof
     psteps = min(a.steps, 5)
-    forked, G.branch_streams = G.branch_streams, False   # attribution pass on ONE stream: a launch's event bracket must not
-    for _ in range(psteps):                              # hold another branch's concurrent kernels
+    for _ in range(psteps):
         step()
     ops.PROFILER = None
-    G.branch_streams = forked
     agg = prof.summary()
     if rank == 0 and os.environ.get('APAMD_BENCH_VERBOSE'):
         for name, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms']):

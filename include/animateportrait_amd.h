@@ -18,7 +18,12 @@
  *   - return value: 0 = ok, negative = error (message: ap_last_error(),
  *     thread-local); no C++ exception crosses the boundary;
  *   - no global mutable state apart from one-time kernel attribute setup,
- *     so calls on distinct streams are thread-safe.
+ *     so the HOST side of calls on distinct streams is thread-safe;
+ *   - but keep all work of this library on ONE stream per device at a time (and
+ *     let no other kernel share the device with it): a kernel that shares
+ *     compute units with the library's matrix kernels was measured to read
+ *     wrong data in lanes 48-63 on MI355X ("Concurrent
+ *     streams"; tools/conc_warp.py reproduces it).
  */
 #ifndef ANIMATEPORTRAIT_AMD_H
 #define ANIMATEPORTRAIT_AMD_H

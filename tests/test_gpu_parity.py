@@ -215,33 +215,6 @@ def test_generator_ngf64_headline_tolerance(dev, golden):
     assert torch.equal(y1, y[:1]), 'samples must be independent (InstanceNorm): B=1 == B=2[0] bitwise'
 
 
-def test_generator_branch_streams_are_bitwise_serial(dev):
-    """Inference runs the three encoder branches and the landmark encoder on their own HIP streams (networks._run): the
-    same launches in another order, so the output is the serial one bit for bit -- across repeated frames, and again
-    after a weight change (that forward stays on one stream to repack)."""
-    from animateportrait_amd import networks as N
-    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
-    G = N.define_G(3, 1, 16, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
-    args = [[a.to(dev) for a in generator_args(make_generator_inputs(4, seed=s))] for s in (1, 2, 3)]
-    with torch.no_grad():
-        G.branch_streams = False
-        want = [G(*a).clone() for a in args]
-        G.branch_streams = True
-        for rep in range(3):
-            got = [G(*a) for a in args]
-            torch.cuda.synchronize()
-            assert G._packed_for is not None
-            for g, w in zip(got, want):
-                assert torch.equal(g, w)
-        G.model_tri_merge.weight.mul_(0.5)
-        G.branch_streams = False
-        want2 = G(*args[0]).clone()
-        G.branch_streams = True
-        G.model_tri_merge.weight.mul_(2.0).mul_(0.5)
-        assert torch.equal(G(*args[0]), want2) and torch.equal(G(*args[0]), want2)
-        assert not torch.equal(want2, want[0])
-
-
 def test_static_generator(dev, golden):
     """resnet_style2_9blocks (networks.py:573-637) on the HIP path against the reference's
     outputs; cat[f1, style] is a two-segment source of model.0, never a tensor."""
