@@ -933,57 +933,70 @@ struct PackBf3Params {
     long long s_co, s_ci, s_ky, s_kx;
 };
 
+// One 16-byte slot (8 input channels of one cout, tap and k-group) per thread and step, head and tail images together:
+// the source value is read once for both parts and leaves as two 16-byte stores (a thread per bf16 element measured 424 us
+// for the generator's table, 0.45 TB/s).
 __device__ __forceinline__ void pack_bf16x3_body(const PackBf3Params& p, long long first, long long step) {
     const int T = p.ntaps;
-    const long long per_block = 2LL * T * 2 * p.CO_TILE * 8;
-    const long long total = (long long)p.co_tiles * p.nchunks * per_block;
-    for (long long idx = first; idx < total; idx += step) {
-        long long r = idx % per_block;
-        const long long blk = idx / per_block;
-        const int chunk = (int)(blk % p.nchunks), cot = (int)(blk / p.nchunks);
-        const int c = (int)(r % 8); r /= 8;
-        const int col = (int)(r % p.CO_TILE); r /= p.CO_TILE;
-        const int kg = (int)(r % 2); r /= 2;
-        const int t = (int)(r % T);
-        const int part = (int)(r / T);
+    const unsigned slots_blk = (unsigned)T * 2u * (unsigned)p.CO_TILE;          // slots of one part of a (cout tile, chunk) block
+    const long long total = (long long)p.co_tiles * p.nchunks * slots_blk;
+    const int KH = p.KH > 0 ? p.KH : p.K;                                       // KH != K: a 1 x K row kernel
+    for (long long sidx = first; sidx < total; sidx += step) {
+        const unsigned blk = (unsigned)(sidx / slots_blk);
+        unsigned r = (unsigned)(sidx - (long long)blk * slots_blk);
+        const int chunk = (int)(blk % (unsigned)p.nchunks), cot = (int)(blk / (unsigned)p.nchunks);
+        const int col = (int)(r % (unsigned)p.CO_TILE); r /= (unsigned)p.CO_TILE;
+        const int kg = (int)(r & 1u);
+        const int t = (int)(r >> 1);
         const int co = cot * p.CO_TILE + col;
         int s = 0;
         if (p.nseg > 1 && chunk >= p.chunk_begin[1]) s = 1;
         if (p.nseg > 2 && chunk >= p.chunk_begin[2]) s = 2;
-        const int cs = (chunk - p.chunk_begin[s]) * 16 + kg * 8 + c;
-        float v = 0.f;
-        if (cs < p.segC[s] && co < p.Cout && p.tap_ky[t] >= 0) {   // tap_ky < 0: a window position this phase does not have
-            int cin = cs;
-            for (int j = 0; j < s; ++j) cin += p.segC[j];
-            int ky = p.tap_ky[t], kx = p.tap_kx[t];
-            bool ok = true;
-            if (p.s2d_c > 0) {
-                const int rr = cin / p.s2d_c;
-                cin -= rr * p.s2d_c;
-                ky = 2 * ky + (rr >> 1);
-                kx = 2 * kx + (rr & 1);
-                ok = ky < p.ksrc && kx < p.ksrc;
-            } else if (p.rows_c > 0) {
-                ky = cin / p.rows_c;
-                cin -= ky * p.rows_c;
-                ok = ky < p.ksrc;
-            }
-            if (ok) {
-                long long off;
-                if (p.view) {
-                    off = co * p.s_co + cin * p.s_ci + ky * p.s_ky + kx * p.s_kx;
-                } else {
-                    const int KH = p.KH > 0 ? p.KH : p.K;          // KH != K: a 1 x K row kernel
-                    off = p.layout == 0 ? (((long long)co * p.Cin + cin) * KH + ky) * p.K + kx
-                                        : (((long long)cin * p.Cout + co) * KH + ky) * p.K + kx;
+        int seg0 = 0;
+        for (int j = 0; j < s; ++j) seg0 += p.segC[j];
+        const int cs0 = (chunk - p.chunk_begin[s]) * 16 + kg * 8;
+        const bool row_ok = co < p.Cout && p.tap_ky[t] >= 0;       // tap_ky < 0: a window position this phase does not have
+        bf16x8 hv, lv;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int cs = cs0 + c;
+            float v = 0.f;
+            if (row_ok && cs < p.segC[s]) {
+                int cin = cs + seg0;
+                int ky = p.tap_ky[t], kx = p.tap_kx[t];
+                bool ok = true;
+                if (p.s2d_c > 0) {
+                    const int rr = cin / p.s2d_c;
+                    cin -= rr * p.s2d_c;
+                    ky = 2 * ky + (rr >> 1);
+                    kx = 2 * kx + (rr & 1);
+                    ok = ky < p.ksrc && kx < p.ksrc;
+                } else if (p.rows_c > 0) {
+                    ky = cin / p.rows_c;
+                    cin -= ky * p.rows_c;
+                    ok = ky < p.ksrc;
                 }
-                v = p.w[off];
+                if (ok) {
+                    long long off;
+                    if (p.view) {
+                        off = co * p.s_co + cin * p.s_ci + ky * p.s_ky + kx * p.s_kx;
+                    } else {
+                        off = p.layout == 0 ? (((long long)co * p.Cin + cin) * KH + ky) * p.K + kx
+                                            : (((long long)cin * p.Cout + co) * KH + ky) * p.K + kx;
+                    }
+                    v = p.w[off];
+                }
             }
+            __bf16 h, l;
+            split_bf16(v, h, l);
+            hv[c] = h;
+            lv[c] = l;
         }
-        __bf16 h, l;
-        split_bf16(v, h, l);
-        const __bf16 o = part == 0 ? h : l;
-        p.out[idx] = *reinterpret_cast<const unsigned short*>(&o);
+        // image of the block: [part][tap][kgroup][CO_TILE] slots
+        bf16x8* const img = reinterpret_cast<bf16x8*>(p.out) + (long long)blk * 2 * slots_blk;
+        const unsigned slot = ((unsigned)t * 2u + (unsigned)kg) * (unsigned)p.CO_TILE + (unsigned)col;
+        img[slot] = hv;
+        img[slots_blk + slot] = lv;
     }
 }
 
