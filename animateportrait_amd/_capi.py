@@ -55,7 +55,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 5      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 6      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -91,6 +91,10 @@ SIGNATURES = {
                                           ctypes.c_void_p]),
     'ap_instnorm_finalize': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_float,
                                             c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_instnorm_finalize_octet': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                                  ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_octet_ok': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_fwd_octet': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     'ap_warp_concat_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,

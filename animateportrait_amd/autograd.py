@@ -188,10 +188,10 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         c0 += c
 
 
-def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE):
+def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE, out_octet=False):
     if not isinstance(srcs, (list, tuple)):
         srcs = [srcs]
-    out = layer.run(srcs, norm_act=norm_act, act=act)
+    out = layer.run(srcs, norm_act=norm_act, act=act, out_octet=out_octet and tape is None)
     if tape is not None:
         tape.track(out)
         norm = norm_act is not None

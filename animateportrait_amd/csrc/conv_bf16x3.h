@@ -492,6 +492,79 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
             const bool full = vec_ok && ox0 + 32 <= p.OW;                      // whole 32-pixel rows: no per-element edge tests
             const int prow = lane >> 3, pcol = (lane & 7) * 4;
             const int oxv = ox0 + pcol;
+            bool octet = false;
+            if constexpr (C::K == 0 || C::ROW) {
+                // ---- channel-octet output y[n][Cout/8][OH*OW][8] (ap_conv2d_fwd_octet; the run-time-tap and row families
+                // only: the producers of the warp kernel's input).  The MFMA layout already holds 4 consecutive couts of
+                // one pixel per lane and register quad (row = (r & 3) + 8 (r >> 2) + 4 half), and the two halves of a wave
+                // hold the two halves of an octet: 16-byte stores straight from the accumulators, a wave covers 32 pixels
+                // x 32 bytes = 1 KiB contiguous; no LDS patch.  Row sums by a 5-step butterfly per accumulator register.
+                octet = p.o_octet != 0;
+                if (octet) {
+                    const int ox = ox0 + l32;
+                    const long long ohw = (long long)p.OH * p.OW;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float s16[16], q16[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { s16[r] = 0.f; q16[r] = 0.f; }
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int co = co_base + m * 32 + g * 8 + 4 * half;          // 4 consecutive couts (Cout % 8 == 0)
+                            const bool cok = co < p.Cout;
+                            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (p.bias != nullptr && cok) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) bv[j] = p.bias[co + j];
+                            }
+                            float* const obase = p.y + (long long)n * p.o_nstride + (long long)(co >> 3) * ohw * 8 + (co & 7);
+#pragma unroll
+                            for (int q = 0; q < NT; ++q) {
+                                const int oy = oy0 + wpx * NT + q;
+                                if (cok && oy < p.OH && ox < p.OW) {
+                                    float vv[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        vv[j] = acc[m][q][g * 4 + j] + bv[j];
+                                        s16[g * 4 + j] += vv[j];
+                                        q16[g * 4 + j] += vv[j] * vv[j];
+                                    }
+                                    *reinterpret_cast<float4*>(obase + ((long long)oy * p.OW + ox) * 8) =
+                                        make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
+                                }
+                            }
+                        }
+                        if (want_stats) {
+                            // 16 row sums over the 32 lanes of a half-wave as a transpose-reduce: at every step a lane
+                            // hands half of its rows to the partner and keeps the sums of the other half (8 + 4 + 2 + 1
+                            // exchanges, then one plain step) -- 16 shuffles per quantity instead of 16 x 5
+                            auto fold = [&](float (&v)[16]) {
+                                const bool b16 = l32 & 16, b8 = l32 & 8, b4 = l32 & 4, b2 = l32 & 2;
+                                float w8[8], w4[4], w2[2];
+#pragma unroll
+                                for (int i = 0; i < 8; ++i)
+                                    w8[i] = (b16 ? v[i + 8] : v[i]) + __shfl_xor(b16 ? v[i] : v[i + 8], 16, 64);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i)
+                                    w4[i] = (b8 ? w8[i + 4] : w8[i]) + __shfl_xor(b8 ? w8[i] : w8[i + 4], 8, 64);
+#pragma unroll
+                                for (int i = 0; i < 2; ++i)
+                                    w2[i] = (b4 ? w4[i + 2] : w4[i]) + __shfl_xor(b4 ? w4[i] : w4[i + 2], 4, 64);
+                                float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 2, 64);
+                                return w1 + __shfl_xor(w1, 1, 64);
+                            };
+                            const float s = fold(s16), q2 = fold(q16);
+                            if ((l32 & 1) == 0) {
+                                const int r = ((l32 >> 4) & 1) * 8 + ((l32 >> 3) & 1) * 4 + ((l32 >> 2) & 1) * 2 + ((l32 >> 1) & 1);
+                                float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * 2;
+                                d[0] = s;
+                                d[1] = q2;
+                            }
+                        }
+                    }
+                }
+            }
+            if (!octet) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -562,6 +635,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                     }
                 }
             }
+            }   // !octet
             if (want_stats) {
                 __syncthreads();
                 if (tid < CO_TILE) {

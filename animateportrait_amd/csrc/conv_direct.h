@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int ty = tid >> 4, tx = tid & 15;
-    int b = blockIdx.x;
+    int b = (int)xcd_logical_block(gridDim.x, blockIdx.x);   // neighbouring tiles (shared halo rows) on one XCD's L2
     const int tix = b % p.tiles_x; b /= p.tiles_x;
     const int tiy = b % p.tiles_y;
     const int n = b / p.tiles_y;

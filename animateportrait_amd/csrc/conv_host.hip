@@ -794,7 +794,7 @@ int ap_conv2d_pack_run(const void* entries_dev, int32_t count, ap_stream_t strea
 }
 
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream);
+                           float* stat_partials, ap_stream_t stream, bool octet = false);
 
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream) {
@@ -807,12 +807,33 @@ int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const flo
     return conv2d_fwd_impl(d, view, packed, bias, y, nullptr, stream);
 }
 
+// the channel-octet output form exists in the run-time-tap and row families of the split-bf16 kernel (conv_bf16x3.h epilogue)
+static bool octet_plan_ok(const ap_conv_desc* d, const Plan& pl) {
+    if (!pl.bf3 || pl.fused_phases || pl.ph4 || pl.launches.size() != 1 || (d->Cout & 7)) return false;
+    const Bf3Kernel* kern = bf3_for_taps(pl.bk, (int)pl.launches[0].taps.size());
+    return kern && (kern->K == 0 || kern->ROW);
+}
+
+int32_t ap_conv2d_octet_ok(const ap_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, pl)) return 0;
+    return octet_plan_ok(d, pl) ? 1 : 0;
+}
+
+int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float* bias, float* y, float* stat_partials,
+                        ap_stream_t stream) {
+    return conv2d_fwd_impl(d, nullptr, packed, bias, y, stat_partials, stream, true);
+}
+
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream) {
+                           float* stat_partials, ap_stream_t stream, bool octet) {
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc) return rc;
     if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
+    if (octet && !octet_plan_ok(d, pl))
+        return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_octet: only single-launch split-bf16 layers of the run-time-tap / row kernel "
+                                        "families with Cout %% 8 == 0 write the channel-octet layout (ap_conv2d_octet_ok)");
     if (view) {
         if (!pl.bf3 || pl.fused_phases || pl.launches.size() != 1)
             return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_view: only single-launch split-bf16 plans take an output window");
@@ -903,6 +924,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         p.ablate = env_int("APAMD_ABLATE", 0);
 #endif
 #endif
+            p.o_octet = octet ? 1 : 0;
             if (view) {
                 // output window: a sub-grid of the output, stored with the caller's strides (ap_out_view)
                 p.OH = view->OH; p.OW = view->OW;

@@ -76,6 +76,7 @@ struct ConvKParams {
     unsigned s2d_mask[4];     // whose existing taps are s2d_mask[phase] (run-time-tap split-bf16 kernels skip the others)
     unsigned ph_tapmask[4];   // bit t: tap t of the 2 x 2 window exists in that phase (split-bf16 run-time-tap kernels skip
                               // the MFMAs of the others -- their weights are zero: 7 of the 16 taps of a fused 3x3 up-convolution)
+    int o_octet;              // conv_bf16x3 run-time-tap / row families: output as y[n][Cout/8][OH*OW][8] (ap_conv2d_fwd_octet)
 };
 
 // K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void conv_small_gather_f32(const SmallKParams 
     __shared__ __attribute__((aligned(16))) float wl[C::MAXCIN * 9 * COUT];
     __shared__ float red[8][COUT][2];
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
-    int b = blockIdx.x;
+    int b = (int)xcd_logical_block(gridDim.x, blockIdx.x);   // neighbouring tiles (shared halo rows) on one XCD's L2
     const int tix = b % p.tiles_x; b /= p.tiles_x;
     const int tiy = b % p.tiles_y;
     const int n = b / p.tiles_y;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_small_f32(const SmallKParams p) {
     __shared__ float xt[CC * IH * IWP];
     __shared__ float red[8][COUT][2];
     const int tid = threadIdx.x, lx = tid & 31, ly = tid >> 5;
-    int b = blockIdx.x;
+    int b = (int)xcd_logical_block(gridDim.x, blockIdx.x);   // neighbouring tiles (shared halo rows) on one XCD's L2
     const int tix = b % p.tiles_x; b /= p.tiles_x;
     const int tiy = b % p.tiles_y;
     const int n = b / p.tiles_y;

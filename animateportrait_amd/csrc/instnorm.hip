@@ -18,7 +18,7 @@ namespace apamd {
 __global__ __launch_bounds__(64) void instnorm_finalize_kernel(const float* __restrict__ partials,
                                                                const float* __restrict__ y, int tiles, int HW,
                                                                float eps, float* __restrict__ mean,
-                                                               float* __restrict__ rstd) {
+                                                               float* __restrict__ rstd, int oct_C) {
     const int i = blockIdx.x, lane = threadIdx.x;
     const double inv_count = 1.0 / (double)HW;
     double s = 0.0, q = 0.0;
@@ -38,10 +38,18 @@ __global__ __launch_bounds__(64) void instnorm_finalize_kernel(const float* __re
     var = var > 0.0 ? var : 0.0;
     if (y != nullptr && m * m > (double)kInstNormRefineRatio * var) {       // wave-uniform
         const float m0 = (float)m;
+        // oct_C > 0: y is the channel-octet layout [n][C/8][HW][8] (ap_conv2d_fwd_octet): plane (n, c) starts at octet
+        // c / 8 of image n, its elements are 8 floats apart
         const float* py = y + (long long)i * HW;
+        int ys = 1;
+        if (oct_C > 0) {
+            const int n = i / oct_C, c = i - n * oct_C;
+            py = y + ((long long)n * (oct_C >> 3) + (c >> 3)) * HW * 8 + (c & 7);
+            ys = 8;
+        }
         double ds = 0.0, dq = 0.0;
         for (int k = lane; k < HW; k += 64) {
-            const float d = py[k] - m0;
+            const float d = py[(long long)k * ys] - m0;
             ds += (double)d;
             dq += (double)d * (double)d;
         }
@@ -109,7 +117,16 @@ int ap_instnorm_finalize(const float* stat_partials, const float* y, int32_t NC,
     if (!stat_partials || !mean || !rstd) return fail(AP_ERR_INVALID, "instnorm_finalize: null pointer");
     if (NC < 1 || tiles < 1 || count < 1) return fail(AP_ERR_INVALID, "instnorm_finalize: bad sizes");
     hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(NC), dim3(64), 0, (hipStream_t)stream, stat_partials, y, tiles, count,
-                       eps, mean, rstd);
+                       eps, mean, rstd, 0);
+    return check_launch("instnorm_finalize_kernel");
+}
+
+int ap_instnorm_finalize_octet(const float* stat_partials, const float* y, int32_t N, int32_t C, int32_t tiles, int32_t count,
+                               float eps, float* mean, float* rstd, ap_stream_t stream) {
+    if (!stat_partials || !mean || !rstd) return fail(AP_ERR_INVALID, "instnorm_finalize_octet: null pointer");
+    if (N < 1 || C < 8 || (C & 7) || tiles < 1 || count < 1) return fail(AP_ERR_INVALID, "instnorm_finalize_octet: bad sizes");
+    hipLaunchKernelGGL(instnorm_finalize_kernel, dim3(N * C), dim3(64), 0, (hipStream_t)stream, stat_partials, y, tiles, count,
+                       eps, mean, rstd, C);
     return check_launch("instnorm_finalize_kernel");
 }
 

@@ -63,10 +63,10 @@ class ConvLayer(nn.Module):
     def packed(self):
         return self._packed('fwd', self.spec, ops.WeightView(self.weight.detach()))
 
-    def run(self, srcs, norm_act=None, act=ACT_NONE):
+    def run(self, srcs, norm_act=None, act=ACT_NONE, out_octet=False):
         """norm_act=None: plain conv + bias + act.  norm_act=ACT_*: conv followed by InstanceNorm
         (bias skipped -- it cancels exactly under the mean subtraction) and that activation,
-        both deferred to the consumer."""
+        both deferred to the consumer.  out_octet: see ops.conv2d (the output is read by the warp kernel only)."""
         if not isinstance(srcs, (list, tuple)):
             srcs = [srcs]
         spec, packed = self.spec, None
@@ -82,8 +82,8 @@ class ConvLayer(nn.Module):
         if packed is None:
             packed = self.packed()
         if norm_act is None:
-            return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act)
-        return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act)
+            return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act, out_octet=out_octet)
+        return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act, out_octet=out_octet)
 
     def s2d_spec(self):
         if self._s2d_spec is None:
@@ -206,23 +206,26 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         self._last_input_feat = inp if tape is not None else None
         motion, flow, ifmask = motion.contiguous(), flow.contiguous(), ifmask.contiguous()
         cf, dfw = conv_forward, self.double_feature_warping
+        # inference: the encoder layers in front of the three warps write the channel-octet layout the warp kernel gathers
+        # best (ops.conv2d out_octet); with a tape their outputs stay NCHW for the backward kernels
+        oct = tape is None
 
         def branch1():
-            x = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri00['1'], inp, norm_act=ACT_RELU, out_octet=oct)
             x = dfw(x, motion, flow, ifmask, 0, tape, self.model_tri01['0'])
             x = cf(tape, self.model_tri01['0'], x, norm_act=ACT_RELU)
             return cf(tape, self.model_tri02['0'], x, norm_act=ACT_RELU)
 
         def branch2():
             x = cf(tape, self.model_tri10['1'], inp, norm_act=ACT_RELU)
-            x = cf(tape, self.model_tri11['0'], x, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri11['0'], x, norm_act=ACT_RELU, out_octet=oct)
             x = dfw(x, motion, flow, ifmask, 1, tape, self.model_tri12['0'])
             return cf(tape, self.model_tri12['0'], x, norm_act=ACT_RELU)
 
         def branch3():
             x = cf(tape, self.model_tri20['1'], inp, norm_act=ACT_RELU)
             x = cf(tape, self.model_tri21['0'], x, norm_act=ACT_RELU)
-            x = cf(tape, self.model_tri22['0'], x, norm_act=ACT_RELU)
+            x = cf(tape, self.model_tri22['0'], x, norm_act=ACT_RELU, out_octet=oct)
             return dfw(x, motion, flow, ifmask, 2, tape, self.model_tri_merge)
 
         def landmarks():

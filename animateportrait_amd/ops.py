@@ -63,7 +63,7 @@ class Feat:
     A convolution hands its InstanceNorm statistics over as per-tile partial sums (``pending``); they are
     finalised by whichever consumer comes first -- inside the fused norm/residual/split pass when that is the
     consumer (ap_norm_apply_split), by a standalone ap_instnorm_finalize when ``mean`` / ``rstd`` are read."""
-    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows', 'xs_heads_only', 's2d')
+    __slots__ = ('data', '_mean', '_rstd', 'act', 'xs', 'pending', 'xs_rows', 'xs_heads_only', 's2d', 'oct')
 
     def __init__(self, data, mean=None, rstd=None, act=ACT_NONE, pending=None):
         self.data, self._mean, self._rstd, self.act = data, mean, rstd, act
@@ -72,6 +72,8 @@ class Feat:
         self.xs_rows = None      # {(k, pad, pad_mode): row expansion for k x k stems (ap_split_prepass_rows)}
         self.xs_heads_only = False   # the split copy was written without its tail planes (package mode plain bf16)
         self.s2d = None              # space-to-depth split copy (a split-only Feat) made by the producer (warp_concat s2d=True)
+        self.oct = None              # the fp32 values in the channel-octet layout [N, C/8, H*W, 8] (conv2d out_octet=True);
+                                     # ``data`` is then a storage-less stand-in: only warp_concat reads such a feature
 
     @property
     def shape(self):
@@ -98,6 +100,11 @@ class Feat:
             partial, tiles = self.pending
             n, c, h, w = self.data.shape
             self._alloc_stats()
+            if self.oct is not None:
+                C.check(C.lib().ap_instnorm_finalize_octet(_ptr(partial), _ptr(self.oct), n, c, tiles, h * w, EPS,
+                                                           _ptr(self._mean), _ptr(self._rstd), _stream()), 'instnorm_finalize_octet')
+                self.pending = None
+                return
             C.check(C.lib().ap_instnorm_finalize(_ptr(partial), _ptr(self.data), n * c, tiles, h * w, EPS, _ptr(self._mean),
                                                  _ptr(self._rstd), _stream()), 'instnorm_finalize')
             self.pending = None
@@ -118,6 +125,8 @@ class Feat:
         return self._rstd
 
     def batch_slice(self, lo, hi):
+        if self.oct is not None:
+            raise RuntimeError('a channel-octet feature is read by warp_concat only')
         c = self.data.shape[1]
         return Feat(self.data[lo:hi], None if self.mean is None else self.mean[lo * c:hi * c],
                     None if self.rstd is None else self.rstd[lo * c:hi * c], self.act)
@@ -482,11 +491,13 @@ def takes_split(spec, n, h, w):
     return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
 
 
-def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE):
+def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE, out_octet=False):
     """Run one convolution.  Returns a Feat:
     * want_stats=False: materialised ``act(conv + bias)``;
     * want_stats=True : raw conv output with its InstanceNorm statistics, to be consumed as
-      ``out_act(IN(raw))`` by the next layer."""
+      ``out_act(IN(raw))`` by the next layer.
+    out_octet: the only reader is warp_concat (inference) -- where the layer's kernel can (ap_conv2d_octet_ok), the output
+    is written in the channel-octet layout [N, C/8, H*W, 8] and returned as ``.oct`` of a Feat without an NCHW tensor."""
     x0 = srcs[0].data
     n, _, h, w = x0.shape
     for f, c in zip(srcs, spec.cin_segments):
@@ -513,7 +524,11 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
         spec.fill_sources(d, srcs)
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
-    y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)
+    out_octet = bool(out_octet) and d.presplit == 1 and lib.ap_conv2d_octet_ok(ctypes.byref(d)) == 1
+    if out_octet:
+        y = torch.empty((n, spec.cout // 8, ho.value * wo.value, 8), dtype=torch.float32, device=x0.device)
+    else:
+        y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)
     partial = None
     if want_stats:
         tiles = C.check(lib.ap_conv2d_stat_tiles(ctypes.byref(d)), 'conv2d_stat_tiles')
@@ -523,14 +538,19 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
         C.check(lib.ap_conv2d_kernel_name(ctypes.byref(d), buf, 96), 'conv2d_kernel_name')
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    C.check(lib.ap_conv2d_fwd(ctypes.byref(d), _ptr(packed), _ptr(bias), _ptr(y), _ptr(partial), _stream()),
-            'conv2d_fwd')
+    C.check((lib.ap_conv2d_fwd_octet if out_octet else lib.ap_conv2d_fwd)(ctypes.byref(d), _ptr(packed), _ptr(bias), _ptr(y),
+                                                                          _ptr(partial), _stream()), 'conv2d_fwd')
     if PROFILER is not None:
         e1.record()
         # algorithmic FLOPs = 2 * MACs of the dense operator (transposed: every input pixel x k*k taps)
         px = h * w if spec.transposed else ho.value * wo.value
         macs = getattr(spec, 'alg_macs', None) or sum(spec.cin_segments) * spec.k ** 2
         PROFILER.records.append((buf.value.decode(), 2.0 * n * px * spec.cout * macs, e0, e1))
+    if out_octet:
+        res = Feat(torch.empty(1, dtype=torch.float32, device=x0.device).expand((n, spec.cout, ho.value, wo.value)),
+                   act=out_act if want_stats else ACT_NONE, pending=(partial, tiles) if want_stats else None)
+        res.oct = y
+        return res
     if not want_stats:
         return Feat(y)
     return Feat(y, act=out_act, pending=(partial, tiles))
@@ -624,6 +644,8 @@ def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True, s
     (s2d_eligible): the kernel writes THAT layout (zero padding ring included) and the result carries it as ``.s2d``."""
     x = f.data
     n, c, h, w = x.shape
+    if f.oct is not None:
+        x = f.oct                    # channel-octet layout (conv2d out_octet=True): flags bit 1
     for t, name in ((x, 'x'), (motion, 'motion'), (flow, 'flow'), (ifmask, 'ifmask')):
         _require_device(t, name)
     s = motion.shape[1]
@@ -642,7 +664,7 @@ def warp_concat(f, motion, flow, ifmask, level, emit_xs=False, keep_fp32=True, s
         xs = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     C.check(C.lib().ap_warp_concat_fwd_ex(_ptr(x), _ptr(f.mean), _ptr(f.rstd), f.act, _ptr(motion), _ptr(flow),
                                           _ptr(ifmask), _ptr(out), _ptr(xs), n, c, h, w, s, 1.0 / (1 << level),
-                                          1 if s2d else 0, _stream()), 'warp_concat_fwd')
+                                          (1 if s2d else 0) | (2 if f.oct is not None else 0), _stream()), 'warp_concat_fwd')
     if s2d:
         # the plain split copy does not exist: only the stride-2 consumer (through .s2d) or fp32 readers can use this
         res = Feat(out) if out is not None else Feat(torch.empty(1, dtype=torch.float32, device=x.device).expand((n, 2 * c, h, w)))

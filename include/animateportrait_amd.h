@@ -96,7 +96,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 5
+#define AP_ABI_VERSION 6
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -155,6 +155,15 @@ typedef struct ap_out_view {
 } ap_out_view;
 int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
                        ap_stream_t stream);
+/* ap_conv2d_fwd with the output in the CHANNEL-OCTET layout y[n][Cout/8][Hout*Wout][8] (8 consecutive channels of a pixel
+ * are 32 contiguous bytes) -- what the warp kernel gathers best (ap_warp_concat_fwd_ex flags bit 1): the three encoder
+ * layers in front of double_feature_warping (networks.py:1317-1328: model_tri00, model_tri11, model_tri22) write it in
+ * inference, so that a bilinear tap of 8 channels is one 32-byte read instead of 8 reads from 8 planes.  Statistics as
+ * ap_conv2d_fwd (finalise with ap_instnorm_finalize_octet).  Only where ap_conv2d_octet_ok(d) == 1: single-launch
+ * split-bf16 layers of the run-time-tap (2x2 space-to-depth) and row (7x7 stem) kernel families, Cout % 8 == 0. */
+int32_t ap_conv2d_octet_ok(const ap_conv_desc* d);
+int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float* bias, float* y, float* stat_partials,
+                        ap_stream_t stream);
 
 /* Split-bf16 path (precision = AP_PRECISION_BF16X3, wide 3x3 layers): the convolution consumes its sources as
  * split tensors XS[n][head|tail][C/8][H*W + 1][8 x bf16] (the last 16-byte slot of every plane is all-zero and
@@ -203,6 +212,9 @@ int ap_conv2d_kernel_name(const ap_conv_desc* d, char* buf, int32_t buflen);
  * E[x^2] - E[x]^2 of fp32 sums is rounding noise -- are recomputed from it with the shifted two-pass formula. */
 int ap_instnorm_finalize(const float* stat_partials, const float* y, int32_t NC, int32_t tiles, int32_t count,
                          float eps, float* mean, float* rstd, ap_stream_t stream);
+/* ... for y in the channel-octet layout of ap_conv2d_fwd_octet ([N][C/8][count][8]); mean / rstd stay [N*C]. */
+int ap_instnorm_finalize_octet(const float* stat_partials, const float* y, int32_t N, int32_t C, int32_t tiles, int32_t count,
+                               float eps, float* mean, float* rstd, ap_stream_t stream);
 /* out = act((x - mean) * rstd) + residual, where residual is
  *   NULL, a plain tensor (res_mean == NULL), or itself normalised: (res - res_mean) * res_rstd.
  * Covers `x + conv_block(x)` (networks.py:2358-2360) and `shortcut(x) + conv_block(x)` (:2418-2420).
@@ -244,7 +256,9 @@ int ap_warp_concat_fwd_split(const float* x, const float* x_mean, const float* x
                              float flow_scale, ap_stream_t stream);
 /* ... with flags.  bit 0: xs takes the SPACE-TO-DEPTH split layout of the 2C-channel concat -- what ap_split_prepass_s2d
  * would make of it: (N, 4 * 2C, H/2 + 1, W/2 + 1) with the zero padding ring written -- for a stride-2 3x3 consumer
- * (model_tri01 / model_tri12, networks.py:1318-1324) that runs as a 2x2 stride-1 layer (ap_conv_desc.s2d_k = 3); H, W even. */
+ * (model_tri01 / model_tri12, networks.py:1318-1324) that runs as a 2x2 stride-1 layer (ap_conv_desc.s2d_k = 3); H, W even.
+ * bit 1: x is in the channel-octet layout [N][C/8][H*W][8] written by ap_conv2d_fwd_octet (C % 8 == 0); x_mean / x_rstd
+ * stay [N*C]. */
 int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act,
                           const float* motion, const float* flow, const float* ifmask, float* out, void* xs,
                           int32_t N, int32_t C, int32_t H, int32_t W, int32_t S, float flow_scale, int32_t flags,

@@ -1021,3 +1021,104 @@ def test_batched_packer_equals_per_layer_packer(dev):
     after = l0.packed()
     assert not torch.equal(before, after) and torch.equal(after, ops.pack_weights(l0.spec, l0.weight.detach()))
     assert torch.equal(l1.packed_s2d(), ops.pack_weights(l1.s2d_spec(), ops.s2d_weight(l1.weight.detach())))
+
+
+def _octet_to_nchw(t, c, h, w):
+    """[N, C/8, H*W, 8] (ap_conv2d_fwd_octet) -> NCHW."""
+    n = t.shape[0]
+    return t.view(n, c // 8, h, w, 8).permute(0, 1, 4, 2, 3).reshape(n, c, h, w)
+
+
+@pytest.mark.parametrize('case', ['s2d_3x3', 'stem_rows', 's2d_ragged'])
+def test_conv_channel_octet_output(dev, case):
+    """ap_conv2d_fwd_octet: the layers in front of the three warps (3x3 stride-2 on the space-to-depth route, 7x7 stem in the
+    row form) write y[n][C/8][H*W][8]; the values are the NCHW launch's accumulators bit for bit, the InstanceNorm statistics
+    (summed in another order) agree to rounding, and ap_instnorm_finalize_octet's data pass reads the strided planes."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(31)
+    if case == 'stem_rows':
+        n, cin, cout, h, k, stride, pad, pm = 2, 3, 32, 64, 7, 1, 3, ops.PAD_REFLECT
+    elif case == 's2d_ragged':
+        n, cin, cout, h, k, stride, pad, pm = 1, 32, 72, 44, 3, 2, 1, ops.PAD_ZERO
+    else:
+        n, cin, cout, h, k, stride, pad, pm = 2, 64, 128, 64, 3, 2, 1, ops.PAD_ZERO
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    l = _layer(dev, w, None, stride=stride, pad=pad, pad_mode=pm)
+    x = (torch.randn(n, cin, h, h, generator=g) + 0.5).to(dev)
+    ref = l.run([ops.Feat(x)], norm_act=ops.ACT_RELU)
+    got = l.run([ops.Feat(x)], norm_act=ops.ACT_RELU, out_octet=True)
+    assert got.oct is not None and got.data.stride(0) == 0 and tuple(got.shape) == tuple(ref.shape)
+    ho = ref.shape[2]
+    assert torch.equal(_octet_to_nchw(got.oct, cout, ho, ho), ref.data)
+    assert float(((got.mean - ref.mean).abs() / (ref.mean.abs() + 1e-3)).max()) < 1e-5
+    assert float(((got.rstd - ref.rstd).abs() / ref.rstd).max()) < 1e-5
+    # the data pass of the finaliser (ill-conditioned planes): a large common offset makes every plane take it
+    xb = (torch.randn(n, cin, h, h, generator=g) * 0.01 + 40.0).to(dev)
+    wpos = w.abs()
+    lp = _layer(dev, wpos, None, stride=stride, pad=pad, pad_mode=ops.PAD_REFLECT if k == 7 else ops.PAD_ZERO)
+    refb = lp.run([ops.Feat(xb)], norm_act=ops.ACT_RELU)
+    gotb = lp.run([ops.Feat(xb)], norm_act=ops.ACT_RELU, out_octet=True)
+    assert float(((gotb.rstd - refb.rstd).abs() / refb.rstd).max()) < 1e-5
+    # plain conv + bias + activation form
+    l2 = _layer(dev, w, torch.randn(cout, generator=g), stride=stride, pad=pad, pad_mode=pm)
+    r2 = l2.run([ops.Feat(x)], act=ops.ACT_LRELU)
+    g2 = l2.run([ops.Feat(x)], act=ops.ACT_LRELU, out_octet=True)
+    assert torch.equal(_octet_to_nchw(g2.oct, cout, ho, ho), r2.data)
+    # a channel-octet feature has no NCHW tensor: every other reader refuses it
+    with pytest.raises(RuntimeError):
+        ops.materialize(got)
+
+
+def test_conv_octet_falls_back_to_nchw_where_unsupported(dev):
+    """out_octet is a request: a layer whose kernel has no octet epilogue (3x3 stride-1, fp32 plans) returns NCHW."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(32)
+    l = _layer(dev, torch.randn(64, 64, 3, 3, generator=g) * 0.05, None, stride=1, pad=1, pad_mode=ops.PAD_REFLECT)
+    x = torch.randn(1, 64, 32, 32, generator=g).to(dev)
+    out = l.run([ops.Feat(x)], norm_act=ops.ACT_RELU, out_octet=True)
+    assert out.oct is None and out.data.is_contiguous()
+
+
+@pytest.mark.parametrize('level', [0, 1, 2])
+def test_warp_reads_channel_octet_input(dev, level):
+    """ap_warp_concat_fwd_ex(flags bit 1): the quad-cooperative gather from the channel-octet layout gives the NCHW launch's
+    output -- fp32, split-only and space-to-depth split forms, with the producer's IN + ReLU applied per tap -- up to the
+    order of the four tap products (the two tap columns are summed in different lanes: a few ulp)."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.synthetic import make_generator_inputs
+    d = make_generator_inputs(2, seed=11)
+    mo, fl, mk = d['motion'].to(dev), d['flow'].to(dev), d['ifmask'].to(dev)
+    s = mo.shape[1]
+    h = s >> level
+    c = 16
+    x = (torch.randn(2, c, h, h, generator=torch.Generator().manual_seed(4)) * 3 + 1).to(dev)
+    m = x.mean((2, 3)).reshape(-1)
+    r = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+
+    def feat(octet):
+        f = ops.Feat(x, m, r, ops.ACT_RELU)
+        if octet:
+            f = ops.Feat(torch.empty(1, device=dev).expand(x.shape), m, r, ops.ACT_RELU)
+            f.oct = x.view(2, c // 8, 8, h * h).permute(0, 1, 3, 2).contiguous()
+        return f
+    for kw in ({}, dict(emit_xs=True, keep_fp32=False), dict(emit_xs=True, keep_fp32=True, s2d=True)):
+        a = ops.warp_concat(feat(False), mo, fl, mk, level, **kw)
+        b = ops.warp_concat(feat(True), mo, fl, mk, level, **kw)
+        def close(u, v):
+            return float(((u - v).abs() - 2e-6 * (1.0 + u.abs())).max()) <= 0.0
+        if not a.is_split_only:
+            assert close(a.data, b.data) and torch.equal(a.data == -1.0, b.data == -1.0)
+        if a.xs is not None:
+            (va, za), (vb, zb) = _decode_split(a.xs, 2, 2 * c, h, h), _decode_split(b.xs, 2, 2 * c, h, h)
+            assert close(va, vb) and float(zb.abs().max()) == 0.0
+        if a.s2d is not None:
+            sh = tuple(a.s2d.shape)
+            (va, za), (vb, zb) = _decode_split(a.s2d.xs, *sh), _decode_split(b.s2d.xs, *sh)
+            assert close(va, vb) and float(zb.abs().max()) == 0.0 and torch.equal(va == 0, vb == 0)
+    # a map whose size is not a multiple of 4 takes the one-lane-per-pixel octet path: bit-identical to NCHW
+    x3 = torch.randn(1, 8, 3, 3, generator=torch.Generator().manual_seed(5)).to(dev)
+    mo3 = (torch.rand(1, 3, 3, 2, generator=torch.Generator().manual_seed(6)) * 2 - 1).to(dev)
+    fl3, mk3 = torch.zeros(1, 2, 3, 3, device=dev), torch.ones(1, 1, 3, 3, device=dev)
+    fo = ops.Feat(torch.empty(1, device=dev).expand(x3.shape))
+    fo.oct = x3.view(1, 1, 8, 9).permute(0, 1, 3, 2).contiguous()
+    assert torch.equal(ops.warp_concat(ops.Feat(x3), mo3, fl3, mk3, 0).data, ops.warp_concat(fo, mo3, fl3, mk3, 0).data)
