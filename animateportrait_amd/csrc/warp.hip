@@ -12,7 +12,7 @@
 // per channel are coalesced 256-B rows); sample coordinates and the 2x4 tap offsets/weights are
 // computed once per pixel and reused for CG channels.
 #include "common.h"
-#include <type_traits>
+#include <cstdlib>
 
 namespace apamd {
 
@@ -72,16 +72,6 @@ __device__ __forceinline__ float tap_val(const float* plane, int off, float m, f
 }
 
 constexpr int kWarpCG = 8;   // channels per thread = one 16-byte slot of the split-bf16 layout
-
-// DPP quad permutations (the four lanes of a quad exchange registers without LDS): CTRL = perm[0] | perm[1] << 2 | ...
-template <int CTRL>
-__device__ __forceinline__ float quad_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
-}
-template <int CTRL>
-__device__ __forceinline__ int quad_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
-}
 
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 
@@ -147,7 +137,8 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
                                                           const float* __restrict__ flow,
                                                           const float* __restrict__ ifmask, float* __restrict__ out,
                                                           uint4* __restrict__ xs,
-                                                          int C, int H, int W, int S, float flow_scale, int flags) {
+                                                          int C, int H, int W, int S, float flow_scale, int flags,
+                                                          int tw_shift) {
     const int s2d = flags & 1;
     const int xoct = flags & 2;      // x is the channel-octet layout [N][C/8][H*W][8] (ap_conv2d_fwd_octet)
     // logical block (pixel block fastest, then channel group, then image): contiguous per XCD (common.h) -- the gathers of
@@ -168,10 +159,23 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
         const int part = threadIdx.x & 1, cg = (threadIdx.x >> 1) ? (C >> 3) + by : by;
         xs[((long long)(bz * 2 + part) * CG2 + cg) * (HWz + 1) + HWz] = make_uint4(0u, 0u, 0u, 0u);
     }
-    const int pix = bx * 256 + threadIdx.x;
-    if (pix >= H * W) return;
+    // a workgroup covers a tw x (256 / tw) pixel tile when the map divides into such tiles (tw_shift > 0), else 256
+    // consecutive pixels: the taps of a compact tile fall into a window the CU's L1 holds, those of a 256-pixel row
+    // segment (16 noisy rows high) do not -- the gathers are then served line by line from the L2
+    int pix, oy, ox;
+    if (tw_shift > 0) {
+        const int tiles_x = W >> tw_shift;
+        const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+        oy = ty * (256 >> tw_shift) + ((int)threadIdx.x >> tw_shift);
+        ox = (tx << tw_shift) + ((int)threadIdx.x & ((1 << tw_shift) - 1));
+        pix = oy * W + ox;
+    } else {
+        pix = bx * 256 + threadIdx.x;
+        if (pix >= H * W) return;
+        oy = pix / W;
+        ox = pix - oy * W;
+    }
     const int n = bz;
-    const int oy = pix / W, ox = pix - oy * W;
     const long long SS = (long long)S * S;
 
     float gx, gy, fx, fy, mk;
@@ -219,83 +223,6 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
             wf[k] = tf.off[k] < 0 ? 0.f : tf.w[k];
         }
         float v1[8], v2[8];
-        if (xoct && ((H * W) & 3) == 0) {
-            // ---- quad-cooperative gather.  In the octet layout a tap PAIR (x0, x0 + 1) of the 8 channels is 64 contiguous
-            // bytes, but a lane can load 16: with one lane per pixel the L1 sees a separate request per lane and tap (the
-            // sampling maps are noisy: no two lanes share a line), and the kernel is bound by that request rate.  Here the
-            // four lanes of a quad fetch ONE pixel's tap pair together -- lane q takes tap (q >> 1), channel half (q & 1),
-            // i.e. bytes 16 q .. 16 q + 15 of the pair: one 64-byte request per quad -- for the quad's four pixels in turn
-            // (offsets and weights of pixel p come from lane p by DPP), accumulates its piece for all four pixels, and the
-            // pieces are summed / handed back to the owning lanes by DPP.  16 loads per lane as before, a quarter of the
-            // L1 requests.  (Out-of-range taps carry offset 0 / weight 0, so a pair need not be contiguous: any two taps work.)
-            const int q = threadIdx.x & 3, hsel = q & 1;
-            const bool xs1 = q >> 1;
-            const float4* og = reinterpret_cast<const float4*>(x + ((long long)n * (C >> 3) + by) * HW * 8);
-            float mh[4], rh[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                mh[j] = 0.f; rh[j] = 1.f;
-                if (x_mean != nullptr) { mh[j] = x_mean[n * C + c0 + hsel * 4 + j]; rh[j] = x_rstd[n * C + c0 + hsel * 4 + j]; }
-            }
-            float4 val[4][2][2];
-            float wv[4][2][2];
-            auto fetch = [&](auto ptag) __attribute__((always_inline)) {
-                constexpr int P = decltype(ptag)::value, BC = P * 0x55;        // quad_perm: broadcast lane P
-#pragma unroll
-                for (int row = 0; row < 2; ++row) {
-                    const int om0 = quad_i<BC>(om[row * 2]), om1 = quad_i<BC>(om[row * 2 + 1]);
-                    const int of0 = quad_i<BC>(of[row * 2]), of1 = quad_i<BC>(of[row * 2 + 1]);
-                    const float wm0 = quad_f<BC>(wm[row * 2]), wm1 = quad_f<BC>(wm[row * 2 + 1]);
-                    const float wf0 = quad_f<BC>(wf[row * 2]), wf1 = quad_f<BC>(wf[row * 2 + 1]);
-                    val[P][0][row] = og[(xs1 ? om1 : om0) * 2 + hsel];
-                    val[P][1][row] = og[(xs1 ? of1 : of0) * 2 + hsel];
-                    wv[P][0][row] = xs1 ? wm1 : wm0;
-                    wv[P][1][row] = xs1 ? wf1 : wf0;
-                }
-            };
-            fetch(std::integral_constant<int, 0>{});
-            fetch(std::integral_constant<int, 1>{});
-            fetch(std::integral_constant<int, 2>{});
-            fetch(std::integral_constant<int, 3>{});
-            float acc[2][4][4];                      // [branch][pixel of the quad][channel of this lane's half]
-#pragma unroll
-            for (int P = 0; P < 4; ++P)
-#pragma unroll
-                for (int br = 0; br < 2; ++br) {
-                    const float vr[2][4] = {{val[P][br][0].x, val[P][br][0].y, val[P][br][0].z, val[P][br][0].w},
-                                            {val[P][br][1].x, val[P][br][1].y, val[P][br][1].z, val[P][br][1].w}};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float sum = 0.f;
-#pragma unroll
-                        for (int row = 0; row < 2; ++row) {
-                            float t = (vr[row][j] - mh[j]) * rh[j];
-                            t = x_act == 1 ? (t > 0.f ? t : 0.f) : (x_act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-                            sum += t * wv[P][br][row];
-                        }
-                        sum += quad_f<0x4E>(sum);                    // + the other tap column (lanes q ^ 2)
-                        acc[br][P][j] = sum;
-                    }
-                }
-            // hand the sums to the owning lanes: lane P takes pixel P's channels 0..3 from lane 0 and 4..7 from lane 1
-            auto collect = [&](auto ptag) __attribute__((always_inline)) {
-                constexpr int P = decltype(ptag)::value;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float a0 = quad_f<0x00>(acc[0][P][j]), a1 = quad_f<0x55>(acc[0][P][j]);
-                    const float b0 = quad_f<0x00>(acc[1][P][j]), b1 = quad_f<0x55>(acc[1][P][j]);
-                    if (q == P) { v1[j] = a0; v1[4 + j] = a1; v2[j] = b0; v2[4 + j] = b1; }
-                }
-            };
-            collect(std::integral_constant<int, 0>{});
-            collect(std::integral_constant<int, 1>{});
-            collect(std::integral_constant<int, 2>{});
-            collect(std::integral_constant<int, 3>{});
-            if (!keep) {
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v2[c] = -1.f;
-            }
-        } else {
         float a[8][4], b[8][4], m[8], r[8];
         if (xoct) {
             // a tap is the 32 contiguous bytes of the group's 8 channels: two 16-byte loads instead of 8 dword gathers
@@ -340,7 +267,6 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
             v1[c] = s1;
             v2[c] = keep ? s2 : -1.f;
         }
-        }   // one lane per pixel
         if (out != nullptr) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -885,8 +811,12 @@ extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const 
     if ((C % kWarpCG) != 0 && (xs || !out))
         return fail(AP_ERR_UNSUPPORTED, "warp_concat_fwd: the split output needs C %% 8 == 0 (C=%d)", C);
     dim3 grid((H * W + 255) / 256, (C + kWarpCG - 1) / kWarpCG, N);
+    // tile width (log2): 32 x 8 pixels when the map divides into them (APAMD_WARP_TILE = 0 / 4 / 5 / 6 for A/B runs)
+    static const int tile_env = getenv("APAMD_WARP_TILE") ? atoi(getenv("APAMD_WARP_TILE")) : 5;
+    int tw_shift = tile_env;
+    if (tw_shift < 4 || tw_shift > 6 || (W & ((1 << tw_shift) - 1)) || (H & ((256 >> tw_shift) - 1))) tw_shift = 0;
     hipLaunchKernelGGL(warp_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
-                       flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, flags & 3);
+                       flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, flags & 3, tw_shift);
     return check_launch("warp_concat_kernel");
 }
 
