@@ -131,6 +131,9 @@ __device__ __forceinline__ void store_split_slot_s2d(uint4* xs, int n, int CG2, 
 }
 
 // grid: (ceil(H*W/256), ceil(C/CG), N).  out (fp32 [N, 2C, H, W]) and xs (its split-bf16 copy) are both optional.
+// ACT (= x_act) is a template parameter: with a run-time activation the compiler evaluated ReLU AND LeakyReLU for every
+// one of the 64 gathered values and selected (12 vector instructions per value; the kernel is as much VALU- as memory-bound).
+template <int ACT>
 __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
                                                           const float* __restrict__ x_rstd, int x_act,
                                                           const float* __restrict__ motion,
@@ -252,17 +255,16 @@ __global__ __launch_bounds__(256) void warp_concat_kernel(const float* __restric
             for (int k = 0; k < 4; ++k) { a[c][k] = plane[om[k]]; b[c][k] = plane[of[k]]; }
         }
         }
+        // (an out-of-range tap reads element 0 with weight 0: the same sum as skipping it, no select per value)
+        auto actf = [](float t) { return ACT == 1 ? fmaxf(t, 0.f) : (ACT == 2 ? (t > 0.f ? t : 0.2f * t) : t); };
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            float s1 = 0.f, s2 = 0.f;
+            float s1 = actf((a[c][0] - m[c]) * r[c]) * wm[0];
+            float s2 = actf((b[c][0] - m[c]) * r[c]) * wf[0];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float t = (a[c][k] - m[c]) * r[c];
-                t = x_act == 1 ? (t > 0.f ? t : 0.f) : (x_act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-                s1 += (tm.off[k] < 0 ? 0.f : t) * wm[k];
-                float u = (b[c][k] - m[c]) * r[c];
-                u = x_act == 1 ? (u > 0.f ? u : 0.f) : (x_act == 2 ? (u > 0.f ? u : 0.2f * u) : u);
-                s2 += (tf.off[k] < 0 ? 0.f : u) * wf[k];
+            for (int k = 1; k < 4; ++k) {
+                s1 += actf((a[c][k] - m[c]) * r[c]) * wm[k];
+                s2 += actf((b[c][k] - m[c]) * r[c]) * wf[k];
             }
             v1[c] = s1;
             v2[c] = keep ? s2 : -1.f;
@@ -815,7 +817,8 @@ extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const 
     static const int tile_env = getenv("APAMD_WARP_TILE") ? atoi(getenv("APAMD_WARP_TILE")) : 5;
     int tw_shift = tile_env;
     if (tw_shift < 4 || tw_shift > 6 || (W & ((1 << tw_shift) - 1)) || (H & ((256 >> tw_shift) - 1))) tw_shift = 0;
-    hipLaunchKernelGGL(warp_concat_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
+    auto* kern = x_act == 1 ? warp_concat_kernel<1> : (x_act == 2 ? warp_concat_kernel<2> : warp_concat_kernel<0>);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
                        flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, flags & 3, tw_shift);
     return check_launch("warp_concat_kernel");
 }
