@@ -28,6 +28,34 @@ struct SmallCfg {
     static constexpr int S = S_, COUT = COUT_, TH = 8, TW = 32, MAXCIN = 16;
 };
 
+// Sums of V values per lane over the 32 lanes of a half-wave (lane bits 4..0) by halving: at every step a lane keeps half
+// of its values and receives the partner's sums of those, so V = 16 costs 8 + 4 + 2 + 1 + 1 exchanges instead of 16 x 5.
+// Returns the total of value index `idx_out` (set per lane); valid in every lane.
+template <int V>
+__device__ __forceinline__ float halfwave_sums(float (&v)[V], int l32, int& idx_out) {
+    int idx = 0, cnt = V;
+#pragma unroll
+    for (int bit = 16; bit >= 1; bit >>= 1) {
+        if (cnt > 1) {
+            const int h = cnt >> 1;
+            const bool up = (l32 & bit) != 0;
+#pragma unroll
+            for (int j = 0; j < V / 2; ++j) {
+                if (j < h) {
+                    const float keep = up ? v[h + j] : v[j], give = up ? v[j] : v[h + j];
+                    v[j] = keep + __shfl_xor(give, bit, 64);
+                }
+            }
+            idx += up ? h : 0;
+            cnt = h;
+        } else {
+            v[0] += __shfl_xor(v[0], bit, 64);
+        }
+    }
+    idx_out = idx;
+    return v[0];
+}
+
 // The gather form (one lane per output pixel, taps straight from global memory): kept for the stride-2 layers, where the
 // LDS-staged form below measured slower (84 vs 68 us on the 8 -> 16 layer at B = 32: eight short tiles per CU leave the
 // staging latency exposed; profiles/r03b_gen_kernel_stats.md).
@@ -66,16 +94,28 @@ __global__ __launch_bounds__(256) void conv_small_gather_f32(const SmallKParams 
     float acc[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+    // the nine taps of channel ci + 1 are in flight while channel ci multiplies (the loop is a run-time loop: left alone,
+    // every channel waited for its own gathers)
+    float raw[9];
+    {
+        const float* plane0 = p.src.data + (long long)n * Cin * HW;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) raw[t] = plane0[off[t] >= 0 ? off[t] : 0];
+    }
     for (int ci = 0; ci < Cin; ++ci) {
-        const float* plane = p.src.data + ((long long)n * Cin + ci) * HW;
         float m = 0.f, r = 1.f;
         if (p.src.mean != nullptr) { m = p.src.mean[n * Cin + ci]; r = p.src.rstd[n * Cin + ci]; }
         float x[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            float v = off[t] >= 0 ? (plane[off[t]] - m) * r : 0.f;
-            if (off[t] >= 0) v = p.src.act == 1 ? fmaxf(v, 0.f) : (p.src.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-            x[t] = v;
+            float v = (raw[t] - m) * r;
+            v = p.src.act == 1 ? fmaxf(v, 0.f) : (p.src.act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
+            x[t] = off[t] >= 0 ? v : 0.f;
+        }
+        if (ci + 1 < Cin) {
+            const float* plane = p.src.data + ((long long)n * Cin + ci + 1) * HW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) raw[t] = plane[off[t] >= 0 ? off[t] : 0];
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -91,62 +131,34 @@ __global__ __launch_bounds__(256) void conv_small_gather_f32(const SmallKParams 
         }
     }
     const bool want_stats = p.stats != nullptr;
+    float sv[COUT], qv[COUT];
 #pragma unroll
     for (int co = 0; co < COUT; ++co) {
-        float v = acc[co] + ((p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f);
+        const float v = acc[co] + ((p.bias != nullptr && co < p.Cout) ? p.bias[co] : 0.f);
         if (live && co < p.Cout)
             p.y[((long long)n * p.Cout + co) * p.OH * p.OW + oy * p.OW + ox] = apply_act(v, p.act);
-        if (want_stats) {
-            float s = live ? v : 0.f, q = live ? v * v : 0.f;
-#pragma unroll
-            for (int sh = 1; sh < 32; sh <<= 1) {
-                s += __shfl_xor(s, sh, 64);
-                q += __shfl_xor(q, sh, 64);
-            }
-            if (lx == 0) { red[ly][co][0] = s; red[ly][co][1] = q; }
-        }
+        sv[co] = live ? v : 0.f;
+        qv[co] = live ? v * v : 0.f;
     }
     if (want_stats) {
+        // row sums by halving (16 + 16 exchanges instead of 16 x 5 x 2 butterfly steps)
+        int co_s, co_q;
+        const float s = halfwave_sums<COUT>(sv, lx, co_s);
+        const float q = halfwave_sums<COUT>(qv, lx, co_q);
+        constexpr int GROUP = 32 / COUT < 1 ? 1 : 32 / COUT;       // lanes per output channel
+        if ((lx & (GROUP - 1)) == 0) { red[ly][co_s][0] = s; red[ly][co_q][1] = q; }
         __syncthreads();
         if (tid < COUT && tid < p.Cout) {
-            float s = 0.f, q = 0.f;
+            float s2 = 0.f, q2 = 0.f;
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) { s += red[r8][tid][0]; q += red[r8][tid][1]; }
+            for (int r8 = 0; r8 < 8; ++r8) { s2 += red[r8][tid][0]; q2 += red[r8][tid][1]; }
             float* d = p.stats + (((long long)n * p.Cout + tid) * p.stat_tiles + tiy * p.tiles_x + tix) * 2;
-            d[0] = s;
-            d[1] = q;
+            d[0] = s2;
+            d[1] = q2;
         }
     }
 }
 
-
-// Sums of V values per lane over the 32 lanes of a half-wave (lane bits 4..0) by halving: at every step a lane keeps half
-// of its values and receives the partner's sums of those, so V = 16 costs 8 + 4 + 2 + 1 + 1 exchanges instead of 16 x 5.
-// Returns the total of value index `idx_out` (set per lane); valid in every lane.
-template <int V>
-__device__ __forceinline__ float halfwave_sums(float (&v)[V], int l32, int& idx_out) {
-    int idx = 0, cnt = V;
-#pragma unroll
-    for (int bit = 16; bit >= 1; bit >>= 1) {
-        if (cnt > 1) {
-            const int h = cnt >> 1;
-            const bool up = (l32 & bit) != 0;
-#pragma unroll
-            for (int j = 0; j < V / 2; ++j) {
-                if (j < h) {
-                    const float keep = up ? v[h + j] : v[j], give = up ? v[j] : v[h + j];
-                    v[j] = keep + __shfl_xor(give, bit, 64);
-                }
-            }
-            idx += up ? h : 0;
-            cnt = h;
-        } else {
-            v[0] += __shfl_xor(v[0], bit, 64);
-        }
-    }
-    idx_out = idx;
-    return v[0];
-}
 
 // The input tile (with halo) of CC channels at a time goes through LDS: coalesced row loads, the producer's InstanceNorm +
 // activation and the padding rule applied ONCE per element (the first form gathered every tap of every lane from global
