@@ -77,54 +77,53 @@ __global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
     }
     __syncthreads();
 
-    // loader geometry, identical for every chunk: element e of [CI][IH][IWS]; column c <-> x = ox0 - pad - LPAD + c
-    constexpr int NE = (XE + 255) / 256;
+    // loader geometry, identical for every chunk.  Wave w stages channel w of the chunk (CI = 4 waves): the plane pointer,
+    // the InstanceNorm constants and the activation are then wave-uniform, and an element costs a load, four vector
+    // instructions and an LDS store.  (Round 2 spread the [CI][IH][IWS] elements over the 256 threads: channel, validity,
+    // norm and activation were decided per element with run-time branches -- ~25 instructions per staged element, more
+    // than the 98 packed FMAs per channel the kernel exists for.)  Column c <-> x = ox0 - pad - LPAD + c.
+    static_assert(CI == 4, "one staging wave per channel of the chunk");
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int NE = (PLANE + 63) / 64;
     int goff[NE];
 #pragma unroll
     for (int k = 0; k < NE; ++k) {
-        const int e = tid + k * 256;
-        const int ci = e / PLANE;
-        const int r = e - ci * PLANE;
-        const int ly = r / IWS, lx = r - ly * IWS;
+        const int e = lane + k * 64;
+        const int ly = e / IWS, lx = e - ly * IWS;
         int gy = oy0 - p.pad + ly, gx = ox0 - p.pad - C::LPAD + lx;
-        bool ok = e < XE;
+        bool ok = e < PLANE;
         if (p.pad_mode == 1) {
             gy = reflect_clamp(gy, H);
             gx = reflect_clamp(gx, W);
         } else {
             ok = ok && gy >= 0 && gy < H && gx >= 0 && gx < W;
         }
-        goff[k] = ok ? ci * HW + gy * W + gx : -1;
+        goff[k] = ok ? gy * W + gx : -1;
     }
     float xr[NE];
     auto issue = [&](int chunk) {
         const int s = seg_of(chunk);
         const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
-        const int cleft = p.seg[s].C - cbase;
-        const float* base = p.seg[s].data + ((long long)n * p.seg[s].C + cbase) * HW;
+        if (cbase + wave < p.seg[s].C) {                       // wave-uniform
+            const float* base = p.seg[s].data + ((long long)n * p.seg[s].C + cbase + wave) * HW;
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int ci = (tid + k * 256) / PLANE;
-            // unconditional load from a clamped (always legal) address: no branch, no per-element wait
-            const bool ok = goff[k] >= 0 && ci < cleft;
-            xr[k] = base[ok ? goff[k] : 0];
+            for (int k = 0; k < NE; ++k) xr[k] = base[goff[k] >= 0 ? goff[k] : 0];   // clamped (always legal) address
         }
     };
     auto commit = [&](int chunk, float* dst) {
         const int s = seg_of(chunk);
         const int cbase = (chunk - p.seg[s].chunk_begin) * CI;
-        const int cleft = p.seg[s].C - cbase;
-        const bool norm = p.seg[s].mean != nullptr;
+        const bool on = cbase + wave < p.seg[s].C;
         const int act = p.seg[s].act;
+        const float slope = act == 1 ? 0.f : (act == 2 ? 0.2f : 1.f);      // act(t) = max(t, slope * t)
+        const float m = s_mean[chunk * CI + wave], r = s_rstd[chunk * CI + wave];   // (0, 1) for a plain segment
+        float* const d = dst + wave * PLANE + lane;
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
-            const int e = tid + k * 256;
-            const int ci = e / PLANE;
-            float v = xr[k];
-            if (norm) v = (v - s_mean[chunk * CI + ci]) * s_rstd[chunk * CI + ci];
-            v = act == 1 ? fmaxf(v, 0.f) : (act == 2 ? (v > 0.f ? v : 0.2f * v) : v);
-            v = (goff[k] >= 0 && ci < cleft) ? v : 0.f;
-            if (e < XE) dst[e] = v;
+            const float t = (xr[k] - m) * r;
+            float v = fmaxf(t, slope * t);
+            v = (on && goff[k] >= 0) ? v : 0.f;
+            if (k + 1 < NE || lane + k * 64 < PLANE) d[k * 64] = v;
         }
     };
 
