@@ -910,23 +910,33 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const SplitRowsParams p
     float v[32];
 #pragma unroll
     for (int i = 0; i < 32; ++i) v[i] = 0.f;
+    // branch-free (see split_s2d_kernel): constants, then all K * CIN reads in flight from clamped addresses, then the math
+    float m[CIN], rs[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        m[c] = 0.f; rs[c] = 1.f;
+        if (p.mean != nullptr) { m[c] = p.mean[n * CIN + c]; rs[c] = p.rstd[n * CIN + c]; }
+    }
+    const float slope = p.act == 1 ? 0.f : (p.act == 2 ? 0.2f : 1.f);
+    bool okr[K];
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         int sy = y + ky - p.pad;
-        bool ok = true;
+        okr[ky] = true;
         if (p.pad_mode == 1) sy = reflect_clamp(sy, p.H);
-        else ok = sy >= 0 && sy < p.H;
+        else okr[ky] = sy >= 0 && sy < p.H;
+        const float* row = p.x + (long long)n * CIN * HW + (okr[ky] ? sy * p.W + x : 0);
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) v[ky * CIN + c] = row[(long long)c * HW];
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky)
 #pragma unroll
         for (int c = 0; c < CIN; ++c) {
-            float t = 0.f;
-            if (ok) {
-                t = p.x[((long long)n * CIN + c) * HW + sy * p.W + x];
-                if (p.mean != nullptr) t = (t - p.mean[n * CIN + c]) * p.rstd[n * CIN + c];
-                t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-            }
-            v[ky * CIN + c] = t;
+            float t = (v[ky * CIN + c] - m[c]) * rs[c];
+            t = fmaxf(t, slope * t);
+            v[ky * CIN + c] = okr[ky] ? t : 0.f;
         }
-    }
 #pragma unroll
     for (int cg = 0; cg < 4; ++cg) {
         bf16x8 hv, lv;

@@ -29,6 +29,7 @@ template <int K_, int COP_>
 struct DirectCfg {
     static constexpr int K = K_, COP = COP_;
     static constexpr int CI = 4;
+    static constexpr int WPE = COP_ == 1 ? 3 : 2;        // waves per SIMD the register budget is set for (three 53 KB tiles fit a CU)
     static constexpr int TH = 16, TW = 64;
     static constexpr int R = K / 2;                      // halo (pad == R is required: 'same' convolution)
     static constexpr int LPAD = (4 - R % 4) % 4;         // left padding so every strip window is 16-B aligned
@@ -41,7 +42,7 @@ struct DirectCfg {
 };
 
 template <class C>
-__global__ __launch_bounds__(256) void conv_direct_f32(const DirectKParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C::WPE, C::WPE))) void conv_direct_f32(const DirectKParams p) {
     constexpr int K = C::K, COP = C::COP, CI = C::CI, IWS = C::IWS, PLANE = C::PLANE, XE = C::XE, NV = C::NV;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
