@@ -387,8 +387,7 @@ int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H,
     int rc = check_launch("wgrad_final_kernel");
     if (rc) return rc;
     const long long n = (long long)src->C * 49;
-    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, P, n, dw);
+    launch_wgrad_reduce(stream, workspace, P, n, dw);
     return check_launch("wgrad_reduce_kernel");
 }
 
@@ -430,8 +429,7 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         rc = check_launch("wgrad_narrow_kernel");
         if (rc) return rc;
         const long long n = (long long)d->M * pl.Q;
-        int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.P, n, dw);
+        launch_wgrad_reduce(stream, workspace, pl.P, n, dw);
         return check_launch("wgrad_reduce_kernel");
     }
     if (pl.bf3) {
@@ -511,8 +509,7 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
     hipError_t e = hipLaunchKernel(pl.k->fn, dim3(nblk), dim3(256), args, pl.k->lds_bytes, stream);
     if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_igemm_f32 launch: %s", hipGetErrorString(e));
     const long long n = (long long)d->M * pl.Q;
-    int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, n, dw);
+    launch_wgrad_reduce(stream, partial, pl.P, n, dw);
     return check_launch("wgrad_reduce_kernel");
 }
 

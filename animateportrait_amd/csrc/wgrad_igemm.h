@@ -226,6 +226,64 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int P, lo
     }
 }
 
+// The same sum for SMALL gradients with MANY partials (the 7x7 stems: 9408 elements x 128 partials; the final layer:
+// 3136 x 512; the narrow first layers: 72 .. 2048 x thousands): wgrad_reduce_kernel gives such a launch a handful of
+// lanes that each walk all P partials one after the other (a single workgroup ran 234 us).  Here S = 2^k threads share
+// an element: thread (element, slice s) adds partials s, s + S, s + 2S, ... in that order, and the S slice sums are
+// combined by a fixed-order tree through LDS -- deterministic for a given (n, P).  Requires n % 4 == 0 and 16-byte
+// aligned pointers (the caller checks).
+__device__ __forceinline__ float4 f4add(const float4 a, const float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float f4add(const float a, const float b) { return a + b; }
+template <typename T> __device__ __forceinline__ T f4zero();
+template <> __device__ __forceinline__ float4 f4zero<float4>() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+template <> __device__ __forceinline__ float f4zero<float>() { return 0.f; }
+
+// T = float4 (n % 4 == 0, 16-byte aligned pointers) or float (anything: gradient-block slots are 4-byte aligned);
+// nT = elements in units of T
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_reduce_sliced_kernel(const float* __restrict__ partial, int P, long long nT,
+                                                                  float* __restrict__ dw, int S) {
+    __shared__ T red[256];
+    const int IL = 256 / S;                                     // elements per workgroup
+    const int li = threadIdx.x % IL, sl = threadIdx.x / IL;
+    const long long i = (long long)blockIdx.x * IL + li;
+    const T* pT = reinterpret_cast<const T*>(partial);
+    T s = f4zero<T>();
+    if (i < nT) {
+        int k = sl;
+        for (; k + 3 * S < P; k += 4 * S) {                     // four partials in flight; the order k, k + S, ... is kept
+            const T a = pT[(long long)k * nT + i], b = pT[(long long)(k + S) * nT + i];
+            const T c = pT[(long long)(k + 2 * S) * nT + i], d = pT[(long long)(k + 3 * S) * nT + i];
+            s = f4add(f4add(f4add(f4add(s, a), b), c), d);
+        }
+        for (; k < P; k += S) s = f4add(s, pT[(long long)k * nT + i]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = S >> 1; h >= 1; h >>= 1) {
+        if (sl < h) red[threadIdx.x] = f4add(red[threadIdx.x], red[threadIdx.x + h * IL]);
+        __syncthreads();
+    }
+    if (sl == 0 && i < nT) reinterpret_cast<T*>(dw)[i] = red[li];
+}
+
+// picks the form: slices when the plain kernel would run fewer than ~16 K threads over many partials
+inline void launch_wgrad_reduce(hipStream_t stream, const float* partial, int P, long long n, float* dw) {
+    const bool vec = (n & 3) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(partial) & 15) == 0;
+    const long long nT = vec ? n >> 2 : n;
+    if (P >= 16 && nT < 16384) {
+        int S = 2;
+        while (S < 64 && S * 2 <= P / 4 && nT * S * 2 <= 65536) S *= 2;
+        const int IL = 256 / S;
+        const dim3 grid((unsigned)((nT + IL - 1) / IL));
+        if (vec) hipLaunchKernelGGL(wgrad_reduce_sliced_kernel<float4>, grid, dim3(256), 0, stream, partial, P, nT, dw, S);
+        else hipLaunchKernelGGL(wgrad_reduce_sliced_kernel<float>, grid, dim3(256), 0, stream, partial, P, nT, dw, S);
+        return;
+    }
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, P, n, dw);
+}
+
 // ---- operand preparation: out[n][c][y][x] (Hp x Wp) = padded view of act(IN(concat(src)))
 //   (y, x) <-> source (y - pad, x - pad); reflection or zero padding inside [0, H+2pad) x [0, W+2pad), zeros beyond.
 struct PadParams {
