@@ -56,6 +56,36 @@ __device__ __forceinline__ float4 fold1_at4(const float* __restrict__ gp, int H,
     return a;
 }
 
+// The same for pad p = 2, 3 (the 7x7 layers: p = 3) with W % 4 == 0, W >= 4 + 2 p, H >= 2 p + 2: only the first and the last
+// group of a row have reflected column partners (pixel x in [1, p] <- padded column p - x; x in [W - 1 - p, W - 2] <- padded
+// column 2 (W - 1) - x + p), and only rows [1, p] / [H - 1 - p, H - 2] a partner row: no per-pixel loops (FoldReader::at walks
+// up to 3 x 3 taps per pixel with data-dependent trip counts -- one memory round trip each).
+__device__ __forceinline__ float4 foldp_row4(const float* __restrict__ gp, int W, int p, int py, int x4) {
+    const float* rp = gp + py * (W + 2 * p);
+    const float4u t = *reinterpret_cast<const float4u*>(rp + x4 + p);
+    float4 v = make_float4(t.x, t.y, t.z, t.w);
+    if (x4 == 0) {                                   // pixels 1 .. 3 <- padded columns p - 1, p - 2, p - 3
+        v.y += rp[p - 1];
+        if (p >= 2) v.z += rp[p - 2];
+        if (p >= 3) v.w += rp[p - 3];
+    }
+    if (x4 == W - 4) {                               // pixels W - 4 .. W - 2 <- padded columns W + p + 2, W + p + 1, W + p
+        v.z += rp[W + p];
+        if (p >= 2) v.y += rp[W + p + 1];
+        if (p >= 3) v.x += rp[W + p + 2];
+    }
+    return v;
+}
+
+__device__ __forceinline__ float4 foldp_at4(const float* __restrict__ gp, int H, int W, int p, int y, int x4) {
+    float4 a = foldp_row4(gp, W, p, y + p, x4);
+    int py2 = -1;
+    if (y >= 1 && y <= p) py2 = p - y;
+    else if (y >= H - 1 - p && y <= H - 2) py2 = 2 * (H - 1) - y + p;
+    if (py2 >= 0) { const float4 t = foldp_row4(gp, W, p, py2, x4); a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w; }
+    return a;
+}
+
 __device__ __forceinline__ float act_grad_from_xhat(float xh, int act) {
     if (act == 1) return xh > 0.f ? 1.f : 0.f;
     if (act == 2) return xh > 0.f ? 1.f : 0.2f;
@@ -290,6 +320,7 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const floa
             } else {
                 const int yy = i / W4, xx = (i - yy * W4) * 4;
                 if (p1 == 1 && H >= 3) gq = fold1_at4(fr.g, H, W, yy, xx);
+                else if (p1 <= 3 && W >= 4 + 2 * p1 && H >= 2 * p1 + 2) gq = foldp_at4(fr.g, H, W, p1, yy, xx);
                 else gq = make_float4(fr.at(yy, xx), fr.at(yy, xx + 1), fr.at(yy, xx + 2), fr.at(yy, xx + 3));
             }
             if (gb) { const float4 t = gb[i]; gq.x += t.x; gq.y += t.y; gq.z += t.z; gq.w += t.w; }
