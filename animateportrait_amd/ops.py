@@ -879,9 +879,10 @@ def bias_grad(dy, out=None):
     n, c, h, w = dy.shape
     db = _grad_out(out, (c,), dy.device)
     lib = C.lib()
-    if c >= 128:
+    if c >= 1024:
         C.check(lib.ap_bias_grad(_ptr(dy), n, c, h * w, _ptr(db), _stream()), 'bias_grad')
-    else:   # few channels: one workgroup per channel would leave the GPU idle
+    else:   # one workgroup per channel leaves the GPU idle below ~1 K channels (256 channels x 32 x 64^2: 210 us, 0.6 TB/s):
+            # slices of every (n, c) plane in parallel, then a fixed-order sum per channel
         nws = C.check(lib.ap_bias_grad_workspace_floats(n, c, h * w), 'bias_grad_workspace_floats')
         ws = torch.empty(nws, dtype=torch.float32, device=dy.device)
         C.check(lib.ap_bias_grad_ws(_ptr(dy), n, c, h * w, _ptr(ws), _ptr(db), _stream()), 'bias_grad')
