@@ -17,8 +17,8 @@ constexpr int kTpsMaxN = 125;   // control points (+3 <= 128)
 
 __device__ __forceinline__ float phi2(float r) { return 0.5f * r * logf(fmaxf(r, 1e-10f)); }
 
-// grid: (B); block 256.  src/dst: B x n x 2 (row, col).  coef: B x (n+3) x 2 (w rows then v rows)
-__global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict__ src, const float* __restrict__ dst,
+// grid: (B); block 1024.  src/dst: B x n x 2 (row, col).  coef: B x (n+3) x 2 (w rows then v rows)
+__global__ __launch_bounds__(1024) void tps_solve_kernel(const float* __restrict__ src, const float* __restrict__ dst,
                                                         int n, float* __restrict__ coef, int* __restrict__ status) {
     extern __shared__ float sm[];
     const int m = n + 3, ld = m + 2;           // augmented matrix [A | f0 f1]
@@ -27,12 +27,12 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
     float* cy = cx + n;                         // n
     __shared__ int piv_row;
     __shared__ float piv_val;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;   // 1024 threads: the elimination steps are LDS-latency bound
     const float* s = src + (long long)b * n * 2;
     const float* d = dst + (long long)b * n * 2;
-    for (int i = tid; i < n; i += 256) { cx[i] = d[i * 2]; cy[i] = d[i * 2 + 1]; }
+    for (int i = tid; i < n; i += nt) { cx[i] = d[i * 2]; cy[i] = d[i * 2 + 1]; }
     __syncthreads();
-    for (int e = tid; e < m * ld; e += 256) {
+    for (int e = tid; e < m * ld; e += nt) {
         const int i = e / ld, j = e - i * ld;
         float v = 0.f;
         if (i < n && j < n) {
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
         const int pr = piv_row;
         if (piv_val == 0.f) { singular = true; break; }
         if (pr != k) {
-            for (int j = tid; j < ld; j += 256) {
+            for (int j = tid; j < ld; j += nt) {
                 const float t = A[k * ld + j];
                 A[k * ld + j] = A[pr * ld + j];
                 A[pr * ld + j] = t;
@@ -77,28 +77,31 @@ __global__ __launch_bounds__(256) void tps_solve_kernel(const float* __restrict_
         }
         __syncthreads();
         const float inv = 1.f / A[k * ld + k];
-        const int rows = m - k - 1, cols = ld - k - 1;
-        for (int e = tid; e < rows * cols; e += 256) {
-            const int i = k + 1 + e / cols, j = k + 1 + e % cols;
-            A[i * ld + j] -= A[i * ld + k] * inv * A[k * ld + j];
+        // (nt / 32) rows x 32 columns of the trailing block per trip; same products, same order as a flat walk
+        for (int i = k + 1 + (tid >> 5); i < m; i += nt >> 5) {
+            const float f = A[i * ld + k] * inv;
+            for (int j = k + 1 + (tid & 31); j < ld; j += 32) A[i * ld + j] -= f * A[k * ld + j];
         }
         __syncthreads();
     }
     if (singular) {
         if (tid == 0 && status) atomicExch(status, 1);
-        for (int e = tid; e < m * 2; e += 256) coef[(long long)b * m * 2 + e] = 0.f;
+        for (int e = tid; e < m * 2; e += nt) coef[(long long)b * m * 2 + e] = 0.f;
         return;
     }
-    // back substitution for the two right-hand sides (threads 0 and 1)
-    if (tid < 2) {
-        for (int i = m - 1; i >= 0; --i) {
-            float v = A[i * ld + m + tid];
-            for (int j = i + 1; j < m; ++j) v -= A[i * ld + j] * A[j * ld + m + tid];
-            A[i * ld + m + tid] = v / A[i * ld + i];
+    // back substitution for the two right-hand sides, column-oriented: x[i] is final once the rows below it are done, and
+    // every row above subtracts its A[r][i] x[i] at once (thread = (row, right-hand side)).  (Two threads walking the
+    // triangle row by row -- 2.5 K dependent LDS round trips each -- were most of the kernel's 190 us.)
+    for (int i = m - 1; i >= 0; --i) {
+        if (tid < 2) A[i * ld + m + tid] = A[i * ld + m + tid] / A[i * ld + i];
+        __syncthreads();
+        if (tid < 2 * i) {
+            const int r = tid >> 1, c = tid & 1;
+            A[r * ld + m + c] -= A[r * ld + i] * A[i * ld + m + c];
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int e = tid; e < m * 2; e += 256) coef[(long long)b * m * 2 + e] = A[(e >> 1) * ld + m + (e & 1)];
+    for (int e = tid; e < m * 2; e += nt) coef[(long long)b * m * 2 + e] = A[(e >> 1) * ld + m + (e & 1)];
 }
 
 // grid: (ceil(H*W/256), B).  img/out: B x C x H x W; dst: B x n x 2; coef: B x (n+3) x 2; flow (optional): B x H x W x 2
@@ -173,7 +176,7 @@ int ap_tps_solve(const float* src, const float* dst, int32_t B, int32_t n, float
     const int m = n + 3;
     const size_t lds = ((size_t)m * (m + 2) + 2 * n) * sizeof(float);
     if (lds > 64 * 1024) return fail(AP_ERR_UNSUPPORTED, "tps_solve: system of %d unknowns does not fit LDS", m);
-    hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, src, dst, n, coef, status);
+    hipLaunchKernelGGL(tps_solve_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, src, dst, n, coef, status);
     return check_launch("tps_solve_kernel");
 }
 
