@@ -34,4 +34,37 @@ __device__ __forceinline__ unsigned xcd_logical_block(unsigned nblk, unsigned b)
     const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// V accumulators of a lane summed over the 64 lanes of its wave, into out[0 .. V).  By halving: at the step of lane bit b
+// a lane keeps one half of its values and receives the partner's partial sums of that half, so the V values cost
+// V (1 - 1/64) exchanges instead of 6 V butterfly steps -- with 128 accumulators the butterfly (768 dependent
+// ds_bpermute, each waited for) WAS the narrow weight-gradient kernel: ~40 us per workgroup against a main loop of a few.
+template <int V>
+__device__ __forceinline__ void wave_sums_to_lds(const float (&acc)[V], int tid, float* out) {
+    constexpr int VP = V <= 64 ? 64 : (V <= 128 ? 128 : 256);          // padded to a power of two >= 64
+    static_assert(V <= 256, "at most 256 accumulators per lane");
+    const int lane = tid & 63;
+    float v[VP];
+#pragma unroll
+    for (int i = 0; i < VP; ++i) v[i] = i < V ? acc[i < V ? i : 0] : 0.f;
+    int cnt = VP;
+#pragma unroll
+    for (int bit = 32; bit >= 1; bit >>= 1) {
+        const int h = cnt >> 1;
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int j = 0; j < VP / 2; ++j) {
+            if (j < h) {
+                const float keep = up ? v[h + j] : v[j], give = up ? v[j] : v[h + j];
+                v[j] = keep + __shfl_xor(give, bit, 64);
+            }
+        }
+        cnt = h;
+    }
+    // lane l now holds the wave totals of values (VP / 64) l .. (VP / 64) l + VP / 64 - 1
+    constexpr int PER = VP / 64;
+#pragma unroll
+    for (int t = 0; t < PER; ++t)
+        if (PER * lane + t < V) out[PER * lane + t] = v[t];
+}
 }  // namespace apamd

@@ -139,14 +139,8 @@ static __global__ __launch_bounds__(256) void wgrad_final_kernel(const WgradFina
             __syncthreads();
         }
     }
-    // block sums: lanes by butterfly, then the four waves in fixed order
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        float a = acc[t];
-#pragma unroll
-        for (int sh = 1; sh < 64; sh <<= 1) a += __shfl_xor(a, sh, 64);
-        if ((tid & 63) == 0) red[tid >> 6][t] = a;
-    }
+    // block sums: lanes by halving exchanges (common.h), then the four waves in fixed order
+    wave_sums_to_lds<T>(acc, tid, red[tid >> 6]);
     __syncthreads();
     if (tid < T) p.partial[((long long)blockIdx.x * p.C + ci) * T + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
 }

@@ -14,6 +14,15 @@
 
 namespace apamd {
 
+// The COB x Q accumulators of a lane summed over the 64 lanes of its wave, into out[c * Q + q] (common.h: wave_sums_to_lds).
+template <int COB, int Q>
+__device__ __forceinline__ void wave_sums_to_lds(const float (&acc)[COB][Q], int tid, float* out) {
+    float v[COB * Q];
+#pragma unroll
+    for (int i = 0; i < COB * Q; ++i) v[i] = acc[i / Q][i % Q];
+    wave_sums_to_lds<COB * Q>(v, tid, out);
+}
+
 struct WgradNarrowParams {
     SrcSeg src;               // A: [N][CIN][H][W], possibly virtual
     const float* g;           // G: [N][M][GH][GW], plain
@@ -82,16 +91,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(const WgradNarrowPara
                 for (int q = 0; q < Q; ++q) acc[c][q] += gv[c] * xw[q];
         }
     }
-    // block sums (fixed order: lanes by butterfly, then the four waves)
-#pragma unroll
-    for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            float a = acc[c][q];
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) a += __shfl_xor(a, sh, 64);
-            if ((tid & 63) == 0) red[tid >> 6][c * Q + q] = a;
-        }
+    // block sums (fixed order: lanes by halving exchanges, then the four waves)
+    wave_sums_to_lds<COB, Q>(acc, tid, red[tid >> 6]);
     __syncthreads();
     if (tid < COB * Q) {
         const int c = tid / Q, q = tid - c * Q;
@@ -220,16 +221,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarro
         if (more) stage(buf ^ 1);
         __syncthreads();                                           // next buffer written; this one free for the one after
     }
-    // block sums (fixed order: lanes by butterfly, then the four waves)
-#pragma unroll
-    for (int c = 0; c < COB; ++c)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            float a = acc[c][q];
-#pragma unroll
-            for (int sh = 1; sh < 64; sh <<= 1) a += __shfl_xor(a, sh, 64);
-            if ((tid & 63) == 0) red[tid >> 6][c * Q + q] = a;
-        }
+    // block sums (fixed order: lanes by halving exchanges, then the four waves)
+    wave_sums_to_lds<COB, Q>(acc, tid, red[tid >> 6]);
     __syncthreads();
     if (tid < COB * Q) {
         const int c = tid / Q, q = tid - c * Q;
