@@ -46,6 +46,13 @@ __global__ __launch_bounds__(256) void conv_tsmall_f32(const TSmallParams p) {
     typedef const float __attribute__((address_space(4))) cfloat;    // uniform -> scalar loads
     cfloat* const wc = (cfloat*)(uintptr_t)p.w;
     const float* src = p.src.data + (long long)n * p.C * HW;
+    // the neighbourhood of channel ci + 1 is in flight while channel ci multiplies (a run-time loop: left alone, every
+    // channel waited for its own nine loads)
+    float nx[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) nx[a][b] = src[off[a][b]];
     for (int ci = 0; ci < p.C; ++ci) {
         float m = 0.f, rs = 1.f;
         if (p.src.mean != nullptr) { m = p.src.mean[n * p.C + ci]; rs = p.src.rstd[n * p.C + ci]; }
@@ -53,15 +60,17 @@ __global__ __launch_bounds__(256) void conv_tsmall_f32(const TSmallParams p) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) v[a][b] = src[(long long)ci * HW + off[a][b]];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
             for (int b = 0; b < 3; ++b) {
-                float t = (v[a][b] - m) * rs;
+                float t = (nx[a][b] - m) * rs;
                 t = t > 0.f ? t : slope * t;
                 v[a][b] = ok[a][b] ? t : 0.f;
             }
+        if (ci + 1 < p.C) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) nx[a][b] = src[(long long)(ci + 1) * HW + off[a][b]];
+        }
 #pragma unroll
         for (int co = 0; co < COUT; ++co) {
             if (co >= p.Cout) continue;                          // Cout = 3 runs the 4-channel instantiation
