@@ -455,8 +455,19 @@ __global__ __launch_bounds__(256) void warp_concat_bwd_tiled_kernel(const float*
     __shared__ int s_xy[2][kBwdPix];                 // (y0 + 8) << 16 | (x0 + 8) of the north-west tap; bit 31: branch live
     __shared__ float s_w[2][4][kBwdPix];             // tap weights: > 0 inside the window, < 0 (negated) outside, 0 dead
     __shared__ unsigned short s_claim[4][kBwdWin + 64];
-    const int tid = threadIdx.x, n = blockIdx.z, wave = tid >> 6, lane = tid & 63;
-    const int ty0 = (blockIdx.x / tiles_x) * kBwdTileH, tx0 = (blockIdx.x % tiles_x) * kBwdTileW;
+    // logical block (tile fastest, then channel group, then image) contiguous per XCD, as in the forward kernel: the tiles whose
+    // windows overlap -- and whose flushes add into the same lines of dx -- run on one XCD
+    int bx, by, bz;
+    {
+        const unsigned L = xcd_logical_block(gridDim.x * gridDim.y * gridDim.z,
+                                             blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+        bx = L % gridDim.x;
+        const unsigned t = L / gridDim.x;
+        by = t % gridDim.y;
+        bz = t / gridDim.y;
+    }
+    const int tid = threadIdx.x, n = bz, wave = tid >> 6, lane = tid & 63;
+    const int ty0 = (bx / tiles_x) * kBwdTileH, tx0 = (bx % tiles_x) * kBwdTileW;
     if (tid == 0) { s_box[0] = W; s_box[1] = H; s_box[2] = -1; s_box[3] = -1; }
     __syncthreads();
     PixelTaps pt[2];
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256) void warp_concat_bwd_tiled_kernel(const float*
         bx0 += (bw - nw) / 2; by0 += (bh - nh) / 2;
         bw = nw; bh = nh;
     }
-    const int c0 = blockIdx.y * kWarpCG;
+    const int c0 = by * kWarpCG;
     const int nc = c0 + kWarpCG <= C ? kWarpCG : C - c0;
     const int HW = H * W, area = bw * bh;
     // the taps in window terms, so that the walk below spends a handful of VALU instructions per tap (it is VALU-bound)
