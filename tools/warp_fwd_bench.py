@@ -40,7 +40,7 @@ def main():
             f = ops.Feat(torch.empty(1, device=dev).expand(x.shape), m, r, ops.ACT_RELU)
             f.oct = xo
             return f
-        kw = dict(emit_xs=True, keep_fp32=False, s2d=level < 2)
+        kw = dict(emit_xs=True, keep_fp32=False, s2d=level < 2 and "nos2d" not in sys.argv)
         t0 = timeit(lambda: ops.warp_concat(feat(False), mo, fl, mk, level, **kw))
         t1 = timeit(lambda: ops.warp_concat(feat(True), mo, fl, mk, level, **kw))
         inb, outb = x.numel() * 4 / 1e6, 2 * x.numel() * 4 / 1e6
