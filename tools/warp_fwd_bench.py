@@ -45,7 +45,7 @@ def main():
         t1 = timeit(lambda: ops.warp_concat(feat(True), mo, fl, mk, level, **kw))
         inb, outb = x.numel() * 4 / 1e6, 2 * x.numel() * 4 / 1e6
         print('warp level %d C=%3d %3dx%3d: NCHW %.1f us, octet %.1f us  (alg. %.0f MB in + %.0f MB out: %.2f TB/s)'
-              % (level, c, h, h, t0, t1, inb, outb, (inb + outb) / t1 / 1e6 * 1e6 / 1e6))
+              % (level, c, h, h, t0, t1, inb, outb, (inb + outb) / t1))        # MB / us = TB/s
     torch.manual_seed(0)
     for name, cin, cout, k, stride, pad, pm, h in (('tri00 stem 3->32 7x7', 3, 32, 7, 1, 3, ops.PAD_REFLECT, 256),
                                                   ('tri11 64->64 3x3 s2', 64, 64, 3, 2, 1, ops.PAD_ZERO, 256),
