@@ -38,7 +38,9 @@ class StandinLandmarkNet(nn.Module):
     def forward(self, x):
         f = F.relu(self.c2(F.relu(self.c1(x))))
         out = torch.sigmoid(self.fc(F.adaptive_avg_pool2d(f, 4).flatten(1)))
-        return out, f
+        # a copy: the reference's get_lm re-projects the regressor's output IN PLACE (:412-413), which autograd only allows
+        # when the producing op does not keep its output for backward (MobileFaceNet ends in a Linear; sigmoid keeps it)
+        return out.clone(), f
 
 
 class StandinFaceNet(nn.Module):

@@ -11,10 +11,12 @@ or plainly as ``python bench.py --gpus N`` -- without WORLD_SIZE in the environm
 under torch.distributed.run with N ranks.  A world size that differs from --gpus is a hard error.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying also
-  "roofline":        the convolution kernel with the largest total time per step (today a split-bf16 matrix kernel:
-                     conv_wino / conv_bf16x3), HIP-event time on the launch stream; `achieved` = the bf16 MFMA FLOPs the
-                     kernel EXECUTES per second (3 per split product; Winograd: 16 products per 2x2 outputs), `peak` =
-                     the dense bf16 MFMA peak, `algorithmic_tflops` = 2 x MACs of the convolution per second;
+  "roofline":        the convolution kernel with the largest total time per step (today the split-bf16 3x3 matrix kernel
+                     conv_bf16x3), HIP-event time on the launch stream; `achieved` = ALGORITHMIC FLOP/s (2 x MACs of the
+                     convolution / launch time, SURVEY.md 8d), `peak` = the dense bf16 MFMA peak, `frac` = achieved / peak;
+                     `executed_tflops` / `mfma_pipe_utilisation` = the bf16 MFMA FLOPs the kernel EXECUTES (3 per multiply);
+  "parity_linf_vs_oracle": the gate -- output of the last timed step vs the oracle on the same batch and weights (< 1e-3 or
+                     no line at all);
   "cpu_baseline":    the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample of the
                      same workload;
   "exact_fp32" / "plain_bf16_inference": the same step in the two other arithmetic modes (the strict-fp32 figure and the
@@ -85,7 +87,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(warmup=3, iters=5):
+def cpu_baseline(sd, warmup=3, iters=5):
     """Oracle generator forward on the host cores, BASELINE.md section 3 protocol: fp32, B=1 and B=16, 3 warm-up +
     5 timed iterations each, median; all physical cores.  ~25-40 s of CPU work in total."""
     import statistics
@@ -93,9 +95,9 @@ def cpu_baseline(warmup=3, iters=5):
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
     cores = host_cores()
     torch.set_num_threads(cores)
-    sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
     res = {}
     t_all = time.time()
+    ref = None
     with torch.no_grad():
         for b in (1, BATCH):
             args = generator_args(make_generator_inputs(b, seed=1234))
@@ -104,15 +106,29 @@ def cpu_baseline(warmup=3, iters=5):
             ts = []
             for _ in range(iters):
                 t0 = time.perf_counter()
-                og.generator_forward(sd, *args, div=3, disp=3)
+                ref = og.generator_forward(sd, *args, div=3, disp=3)
                 ts.append(time.perf_counter() - t0)
             res[b] = b / statistics.median(ts)
     # value = the better of the two batch sizes (oneDNN on many cores is often faster per frame at B=1)
-    return {'value': round(max(res.values()), 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+    # `ref` = the oracle's output on the B=16 batch of seed 1234: the checker of the parity gate in main()
+    return ref, {'value': round(max(res.values()), 3), 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
             'bs1_frames_per_s': round(res[1], 3), 'bs16_frames_per_s': round(res[BATCH], 3), 'cpu_model': cpu_model(),
             'sample': 'oracle.generator_forward ngf=64 fp32, B=1 (3 warm-up) and B=16 (1 warm-up), median of %d timed '
                       'iterations each (%.1f s in total), torch CPU %d threads; value = max(B=1, B=16) rate'
                       % (iters, time.time() - t_all, cores)}
+
+
+def oracle_reference_output(sd):
+    """The oracle's forward of the reported batch (B=16, seed 1234), untimed: the parity checker when the CPU-baseline
+    leg -- which computes the same tensor -- does not run (N > 1, --no-cpu-baseline)."""
+    from oracle import generator as og
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    torch.set_num_threads(host_cores())
+    with torch.no_grad():
+        return og.generator_forward(sd, *generator_args(make_generator_inputs(BATCH, seed=1234)), div=3, disp=3)
+
+
+PARITY_BUDGET = 1e-3      # BASELINE.md: every reported number needs the generator output within 1e-3 L-inf (fp32, outputs in [-1, 1])
 
 
 def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
@@ -174,6 +190,8 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
             'loss_G': round(losses.get('G', float('nan')), 4),
             'losses': {k: round(v, 5) for k, v in losses.items()},
             'gflop_per_sample_algorithmic': 1234.0,
+            'algorithmic_tflops': round(BATCH * 1.234 / dt, 1),
+            'frac_algorithmic': round(BATCH * 1.234 / dt / PEAK_BF16_MFMA_TFLOPS, 4),
             'note': 'geomgm_ifw_fore drawing config, all nine backward_G terms in the timed region; the frozen landmark / '
                     'identity nets (MobileFaceNet, Sphere20a: checkpoints absent from the reference tree) are fixed-seed '
                     'stand-in aux nets (animateportrait_amd/standins.py); matte / intrinsic flow are synthetic batch inputs'}
@@ -282,6 +300,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity-gate', action='store_true',
+                    help='development only: skip the oracle comparison of the timed output; the line then says value_unverified')
     ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32 comparison leg')
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
     ap.add_argument('--no-stream', action='store_true', help='skip the 10 s clip sub-record (BASELINE configs[4]) of the default run')
@@ -337,17 +357,20 @@ def main():
         if rccl_world != a.gpus:
             raise SystemExit('RCCL all-reduce saw %d ranks, --gpus %d' % (rccl_world, a.gpus))
 
-    # ---- CPU baseline first (rank 0, N=1 only): the GPU legs then run last, back to back
-    cpu = None
-    if not a.no_cpu_baseline and world == 1:
-        cpu = cpu_baseline()
-
     from animateportrait_amd import ops
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):      # keep stdout = the one JSON line
         G = build_generator(dev)
+    # ---- CPU baseline first (rank 0, N=1 only): the GPU legs then run last, back to back.  The oracle runs on a host copy
+    # of the product generator's own weights, and its B=16 output is the checker of the parity gate below
+    sd_host = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    cpu = ref16 = None
+    if not a.no_cpu_baseline and world == 1:
+        ref16, cpu = cpu_baseline(sd_host)
+    elif rank == 0 and not a.no_parity_gate:
+        ref16 = oracle_reference_output(sd_host)
     args =[t.to(dev) for t in generator_args(make_generator_inputs(BATCH, seed=1234, rank=rank))]
 
     def step():
@@ -373,6 +396,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(y).all())
+    # ---- parity gate ("every reported number: generator output within 1e-3 L-inf"): the output of the LAST timed
+    # step on rank 0's batch (seed 1234) against the oracle's forward of the same batch with the same weights.  No `value`
+    # is printed for a run that fails it
+    parity = None
+    if ref16 is not None:
+        parity = float((y.detach().cpu() - ref16).abs().max())
+        if not parity < PARITY_BUDGET:
+            raise SystemExit('bench.py: parity gate FAILED -- generator output differs from the oracle by %.3e L-inf '
+                             '(budget %.0e) at ngf=64 B=%d; no number is reported' % (parity, PARITY_BUDGET, BATCH))
 
     # ---- per-kernel attribution: every conv launch bracketed by events on the launch stream
     prof = ops.LaunchProfiler()
@@ -391,32 +423,40 @@ def main():
     dname, dk = dom
     alg = dk['flops'] / (dk['ms'] * 1e-3) / 1e12          # algorithmic TFLOP/s (2 * MACs of the convolution)
     if dname.startswith('Bf3Cfg'):
-        # split-bf16 kernel: every algorithmic FLOP is executed as 3 bf16 MFMA FLOPs (xh*wh + xh*wl + xl*wh);
-        # the pipe that bounds it is the bf16 matrix pipe, so that is what `achieved` / `peak` quote
-        kname, mult, peak, pipe = 'conv_bf16x3<%s>' % dname, 3.0, PEAK_BF16_MFMA_TFLOPS, 'bf16 MFMA (fp32 operands split 3-way)'
+        # split-bf16 kernel: operands are split 2-way (bf16 head + tail) and every algorithmic FLOP is executed as 3 bf16
+        # MFMA FLOPs (xh*wh + xh*wl + xl*wh); the pipe that bounds it is the bf16 matrix pipe
+        kname, mult, peak, pipe = 'conv_bf16x3<%s>' % dname, 3.0, PEAK_BF16_MFMA_TFLOPS, \
+            'bf16 MFMA (fp32 operands as bf16 head + tail, 3 products per multiply)'
     elif dname.startswith('DirectCfg'):
         kname, mult, peak, pipe = 'conv_direct_f32<%s>' % dname, 1.0, PEAK_FP32_MFMA_TFLOPS, 'fp32 VALU'
     else:
         kname, mult, peak, pipe = 'conv_igemm_f32<%s>' % dname, 1.0, PEAK_FP32_MFMA_TFLOPS, 'fp32 MFMA'
-    ach = alg * mult
+    # achieved = ALGORITHMIC FLOP/s (2 x MACs of the convolution) / launch time; frac = achieved / peak
+    # of the pipe the kernel multiplies on.  The matrix-pipe utilisation (executed MFMA FLOP/s / peak: what the PMC
+    # counters of profiles/ measure) is carried next to it under its own name
     roofline = {'bound': 'mfma', 'kernel': kname, 'pipe': pipe,
-                'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                'frac': round(ach / peak, 4),
-                'algorithmic_tflops': round(alg, 2), 'executed_flops_per_algorithmic_flop': mult,
+                'achieved': round(alg, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                'frac': round(alg / peak, 4), 'frac_algorithmic': round(alg / peak, 4),
+                'executed_tflops': round(alg * mult, 2), 'mfma_pipe_utilisation': round(alg * mult / peak, 4),
+                'executed_flops_per_algorithmic_flop': mult,
                 'launches_per_step': dk['launches'] // psteps,
                 'avg_launch_us': round(dk['ms'] * 1e3 / dk['launches'], 2),
                 'gflop_per_launch': round(dk['flops'] / dk['launches'] / 1e9, 3),
                 'conv_ms_per_step': round(sum(v['ms'] for v in agg.values()) / psteps, 3),
                 'bracket_outliers_replaced': sum(v['outliers'] for v in agg.values()),
                 'traffic': None}
+    # HBM bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure comes from the
+    # committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_prof.sh -> profiles/hbm_traffic.json), stamped with the
+    # profile round it was taken in.  A dominant kernel without an entry is an error, not a silent null
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(tpath):
-        try:
-            ent = json.load(open(tpath)).get(dname)
-            roofline['traffic'] = ent and ent.get('hbm_bytes_per_launch')
-            roofline['traffic_unit'] = 'bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/)'
-        except Exception:
-            pass
+    tab = {k.replace(' ', ''): v for k, v in json.load(open(tpath)).items()}
+    ent = tab.get(dname.replace(' ', ''))
+    if ent is None:
+        raise SystemExit('bench.py: profiles/hbm_traffic.json has no HBM-traffic entry for the dominant kernel %s -- rerun '
+                         'tools/round_profiles.sh and commit the PMC passes' % dname)
+    roofline['traffic'] = ent['hbm_bytes_per_launch']
+    roofline['traffic_unit'] = 'bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)'
+    roofline['traffic_source'] = 'profiles/hbm_traffic.json, PMC passes of profile round %s (not collected in this run)' % ent.get('round')
 
     # ---- the same workload with every product on the exact-fp32 MFMA (APAMD_PRECISION=fp32): reported next to the
     # headline so that the split-bf16 arithmetic (3 bf16 MFMAs per fp32 product, fp32 accumulate) is an explicit,
@@ -480,13 +520,20 @@ def main():
                'n_gpus': world, 'rccl_world_size': rccl_world, 'collective_backend': backend if world > 1 else None,
                'ranks_share_one_gpu': share_gpu, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(dt / a.steps * 1e3, 3),
                'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-               'dtype': 'f32 (fp32 tensors; wide convs multiply on the bf16 pipe with operands split 3-way, fp32 accumulate)',
+               'dtype': 'f32 (fp32 tensors; wide convs multiply fp32-class on the bf16 pipe: operands as bf16 head + tail, '
+                        '3 products of 16-bit significands per multiply, ~2^-17 relative per product, fp32 accumulate)',
                'data': 'synthetic',
                'config': {'workload': 'Module2 generator resnet_9blocks_rcatland32_full_ifw fwd-only, ngf=64, '
                                       'bs=16/GPU, 256x256, fp32 (BASELINE configs[1])',
                           'global_batch': BATCH * world, 'parallelism': 'dp%d (frame batches sharded, no collective)' % world,
                           'weights': 'random init N(0,0.02), seed 1234'},
+               'parity_linf_vs_oracle': parity, 'parity_budget': PARITY_BUDGET,
+               'parity_note': 'output of the last timed step (rank 0, B=%d, seed 1234) vs oracle.generator_forward on the same '
+                              'batch and weights; a run that fails the gate prints no line' % BATCH if parity is not None
+                              else 'SKIPPED (--no-parity-gate): value_unverified',
+               'value_unverified': parity is None,
                'whole_generator_algorithmic_tflops': round(fps / world * GFLOP_PER_FRAME / 1e3, 2),
+               'whole_net_frac_algorithmic': round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_BF16_MFMA_TFLOPS, 4),
                'vs_fp32_mfma_conv_roofline': round(fps / world * GFLOP_PER_FRAME / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
                'roofline': roofline}
         if exact is not None:

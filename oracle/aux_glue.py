@@ -92,7 +92,9 @@ def flow_network_warp(netF, real_A, lm1, lm2):
     with torch.no_grad():
         j1 = kp_to_map_some((224, 224), lm1.cpu().numpy() * 7 / 8)
         j2 = kp_to_map_some((224, 224), lm2.cpu().numpy() * 7 / 8)
-        flow_out, vis_out = netF(torch.cat([j1, j2], 1))[:2]
+        jm = torch.cat([j1, j2], 1)                               # float32 joint maps whatever the model's dtype
+        pdt = next((p.dtype for p in netF.parameters()), jm.dtype) if hasattr(netF, 'parameters') else jm.dtype
+        flow_out, vis_out = netF(jm.to(pdt))[:2]
         vis = vis_out.argmax(dim=1, keepdim=True).float()
         mask = (vis < 2).float()
         flow = flow_out * 20. * mask

@@ -15,9 +15,11 @@ supplied by the caller.  The fp32 spline solve is ill-conditioned (0.1-0.2 px be
 tests/test_train_gpu.py::test_tps_vs_reference_golden); the composed-gradient test feeds the product's warps here
 so that every other difference is held to fp32-rounding level.
 
-The reference model class itself cannot be instantiated here (cv2, .cuda(), absent checkpoints -- SURVEY.md
-section 8c); the pieces this composition is made of (G, D, GANLoss, masked, sparse_image_warp) are each pinned to
-goldens captured from the reference.
+Pinned (round 4) to the reference's OWN model class: tests/golden/make_train_golden.py instantiates
+``GeomGMIFWForeModel`` in the build container (cv2 / .cuda() / checkpoint shims, stand-in aux nets, ngf = ndf = 8, b = 1) and
+runs its ``set_input / forward / backward_G / backward_D_* / optimize_parameters``; tests/test_train_golden_cpu.py holds this
+file to that golden (every loss term, every gradient tensor, three optimiser steps).  The pieces (G, D, GANLoss, masked,
+sparse_image_warp) are in addition pinned one by one (tests/golden/make_golden.py).
 """
 import numpy as np
 import torch
@@ -149,3 +151,52 @@ def d_losses(sdD, o, batch, opt=Opt):
     other = torch.cat((batch['B3'], batch['B4']), 1)
     out['D_A_coh'] = ol.d_loss_basic2(D(sdD['D_A_coh'], real), D(sdD['D_A_coh'], fake), D(sdD['D_A_coh'], other))
     return out
+
+
+def set_input_aux(batch, aux):
+    """The two frozen-net stages of set_input / forward that produce batch-level tensors (:503-505, :519-520): intrinsic flow
+    + visibility mask from netF for both targets, matte from MODNet.  Returns a copy of ``batch`` with ``iw_flow, if_mask,
+    iw_flow2, if_mask2, mask`` filled in from ``aux['netF']`` / ``aux['modnet']`` (keys that are absent stay as they were)."""
+    b = dict(batch)
+    if aux.get('netF') is not None:
+        b['iw_flow'], b['if_mask'] = oa.flow_network_warp(aux['netF'], b['A'], b['A_lm_68'][:, :68], b['tB_lm_68'][:, :68])
+        b['iw_flow2'], b['if_mask2'] = oa.flow_network_warp(aux['netF'], b['A'], b['A_lm_68'][:, :68], b['tB2_lm_68'][:, :68])
+    if aux.get('modnet') is not None:
+        with torch.no_grad():
+            b['mask'] = aux['modnet'](b['A'], True)[2]
+    return b
+
+
+class TrainState:
+    """Leaf tensors + the two Adam optimisers of :346-360 (G; the concatenation of the D parameter lists in model_names order)."""
+
+    def __init__(self, sdG, sdD, lr=5e-5, beta1=0.5):
+        self.G = {k: v.clone().requires_grad_(True) for k, v in sdG.items()}
+        self.D = {n: {k: v.clone().requires_grad_(True) for k, v in sd.items()} for n, sd in sdD.items()}
+        self.opt_G = torch.optim.Adam(list(self.G.values()), lr=lr, betas=(beta1, 0.999))
+        self.opt_D = torch.optim.Adam([v for n in ('D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh') if n in self.D
+                                       for v in self.D[n].values()], lr=lr, betas=(beta1, 0.999))
+
+    def d_requires_grad(self, flag):
+        for sd in self.D.values():
+            for v in sd.values():
+                v.requires_grad_(flag)
+
+
+def optimize_parameters(state, batch, opt=Opt, aux=None):
+    """:782-819: forward; G step with the D's frozen (zero_grad, backward_G, Adam step); then the D step on the frames of THAT
+    forward (detached: generated before G's update), each D loss backpropagated, one Adam step over all D parameters.
+    Returns (g terms, d losses) as detached scalars."""
+    o = forward(state.G, batch, opt)
+    state.d_requires_grad(False)
+    state.opt_G.zero_grad()
+    terms = g_loss(state.D, o, batch, opt, aux)
+    terms['G'].backward()
+    state.opt_G.step()
+    state.d_requires_grad(True)
+    state.opt_D.zero_grad()
+    dl = d_losses(state.D, o, batch, opt)
+    for v in dl.values():
+        v.backward()
+    state.opt_D.step()
+    return {k: v.detach() for k, v in terms.items()}, {k: v.detach() for k, v in dl.items()}

@@ -459,3 +459,127 @@ def test_gradient_block_path_respects_autograd_contract(dev):
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-7 * float(ref.abs().max()))
     opt.step()                                            # _rebind copies the fresh gradients into the flat buffer
     assert all(p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * p._flat_off for p in D.parameters())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The product model against the golden made by the REFERENCE's own model class (tests/golden/make_train_golden.py)
+def _golden_model(dev, gd, lr=None):
+    from test_train_golden_cpu import golden_setup, DNAMES
+    from animateportrait_amd import networks as N, standins
+    batch, sdG, sdD, aux, Opt = golden_setup(gd, torch.float32)
+    model, opt = _make_model(dev, int(gd['width']), int(gd['width']))
+    if lr is not None:
+        for o in model.optimizers:
+            for g in o.param_groups:
+                g['lr'] = lr
+    model.netG_A.load_state_dict(sdG, strict=True)
+    for n in DNAMES:
+        getattr(model, 'net' + n).load_state_dict(sdD[n], strict=True)
+    model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
+    model.aux['faceloss'] = N.FaceLoss(standins.StandinFaceNet().to(dev))
+    return model, batch, aux
+
+
+def test_aux_stages_of_set_input_vs_reference_class_golden(dev, golden):
+    """set_input's frozen-net stages on the device (netF pre / post through ap_kp_to_map / ap_flow_post, MODNet matte
+    threshold) against what the reference class computed (:503-505, :519-520).  argmax / > 0.5 are discontinuous: a few
+    pixels may take the other side."""
+    from animateportrait_amd import standins
+    gd = golden('train_step.npz')
+    model, batch, _ = _golden_model(dev, gd)
+    model.aux['netF'] = standins.StandinFlowNet().to(dev)
+    model.aux['modnet'] = standins.StandinMatteNet().to(dev)
+    model.set_input(batch)
+    for mine, key in ((model.iw_flow, 'iw_flow'), (model.iw_flow2, 'iw_flow2'), (model.real_A_if_mask, 'if_mask'),
+                      (model.real_A_if_mask2, 'if_mask2')):
+        d = (mine.cpu()[..., ::2, ::2] - gd[key + '_sub2']).abs() / float(gd[key + '_sub2'].abs().max())
+        assert float((d > 1e-4).float().mean()) < 2e-3, (key, float(d.max()), float((d > 1e-4).float().mean()))
+    assert float((model.mask.cpu()[..., ::2, ::2] != gd['mask_sub2']).float().mean()) < 1e-3
+
+
+@pytest.mark.parametrize('precision', ['fp32', 'bf16x3'])
+def test_train_step_vs_reference_class_golden(dev, golden, precision, monkeypatch):
+    """forward / backward_G / backward_D_* of the product model == the reference class's own methods (golden: the reference in
+    fp64, with the distance of its fp32 evaluation as the per-tensor noise bar): the frames, all eleven G loss values, the five D
+    losses, and EVERY gradient tensor elementwise.  The four TPS-warped constants are replayed from the golden (the fp32 spline
+    solve is ill-conditioned; the product's own warps are checked against the golden's to the bar of test_tps_*), the
+    discontinuous aux stages (previous test) are evaluated on the host."""
+    from animateportrait_amd import ops
+    from oracle import train_step as ts
+    from test_train_golden_cpu import G_TERMS, DNAMES
+    import animateportrait_amd.models.geomgm_ifw_fore_model as pm
+    monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_FP32 if precision == 'fp32' else ops.PRECISION_BF16X3)
+    floor = 5e-5 if precision == 'fp32' else 2e-3
+    floor_d = 5e-5 if precision == 'fp32' else 1e-2
+    gd = golden('train_step.npz')
+    model, batch, aux = _golden_model(dev, gd)
+    batch = ts.set_input_aux({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()},
+                             {k: (v.double() if k in ('netF', 'modnet') else None) for k, v in aux.items()})
+    batch = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+    replay = [torch.cat([gd['mask1'], gd['mask2']], 0), gd['fakeB_static_warp'], gd['fake_B_warp']]
+    own, real_warp = [], pm.warp_nchw
+
+    def warp(img, src, dst):
+        w = real_warp(img, src, dst)
+        ref = replay[len(own)].to(w.device)
+        own.append(float((w - ref).abs().mean()))
+        return ref
+    monkeypatch.setattr(pm, 'warp_nchw', warp)
+    model.set_input(batch)
+    model.forward()
+    for k in ('fake_B_fore', 'fake_B2_fore', 'fake_B', 'fake_B2'):
+        assert linf(getattr(model, k), gd[k]) < 1e-3, k
+    for k in ('fake_B_l', 'fake_B2_l', 'real_B_l', 'fake_B_le', 'real_B_le', 'fake_B2_ll', 'real_B_ll'):
+        assert linf(getattr(model, k)[..., ::2, ::2], gd[k + '_sub2']) < 1e-3, k
+    nets_D = [getattr(model, 'net' + n) for n in DNAMES]
+    model.set_requires_grad(nets_D, False)
+    model.optimizer_G.zero_grad()
+    model.backward_G()
+    assert len(own) == 3 and max(own[:2]) < 2e-3 and own[2] < 2e-2, own     # mean |product TPS warp - reference fp64 warp|
+    assert float((model.getlipline(model.target_B_lm_68).cpu()[..., ::2, ::2] != gd['liplinemask1_sub2']).float().sum()) == 0
+    for k in G_TERMS:
+        a, t = float(getattr(model, 'loss_' + k)), float(gd['loss_' + k])
+        assert abs(a - t) <= 1e-3 * abs(t) + 1e-5, (k, a, t)
+    bad = []
+
+    def check(tag, mine, key, fl):
+        g64 = gd[key]
+        if key.endswith('.bias') and float(mine.abs().max()) == 0.0:
+            assert float(g64.abs().max()) < 1e-6, key         # bias in front of InstanceNorm: exact zero here, noise there
+            return
+        e = _relerr(mine, g64)
+        if e > 3.0 * float(gd[key + '_noise']) + fl:
+            bad.append((tag, key, e, float(gd[key + '_noise'])))
+    for k, p in model.netG_A.named_parameters():
+        check('G', p.grad, 'gG/' + k, floor)
+    model.set_requires_grad(nets_D, True)
+    model.optimizer_D.zero_grad()
+    model.backward_D_A(); model.backward_D_A_l(); model.backward_D_A_le(); model.backward_D_A_ll(); model.backward_D_A_coh()
+    for n in DNAMES:
+        a, t = float(getattr(model, 'loss_' + n)), float(gd['loss_' + n])
+        assert abs(a - t) <= 1e-3 * abs(t) + 1e-6, (n, a, t)
+        for k, p in getattr(model, 'net' + n).named_parameters():
+            check(n, p.grad, 'gD/%s/%s' % (n, k), floor_d)
+    assert not bad, bad
+
+
+def test_optimize_parameters_sequence_vs_reference_class_golden(dev, golden):
+    """Three optimize_parameters() calls at lr 1e-3 (G step, then the D step on the pre-update frames, two Adams), everything
+    on the device and nothing replayed: every loss of every step against the reference class's sequence.  Adam's first steps
+    are sign-like, so rounding differences grow (the reference's own fp32 run is 0.1-0.3 % from its fp64 run by step 2)."""
+    from animateportrait_amd import standins
+    from test_train_golden_cpu import G_TERMS, DNAMES
+    gd = golden('train_step.npz')
+    model, batch, _ = _golden_model(dev, gd, lr=float(gd['seq_lr']))
+    model.aux['netF'] = standins.StandinFlowNet().to(dev)
+    model.aux['modnet'] = standins.StandinMatteNet().to(dev)
+    worst = 0.0
+    for it in range(int(gd['seq_steps'])):
+        model.set_input(batch)
+        model.optimize_parameters()
+        for k in G_TERMS + DNAMES:
+            a, t = float(getattr(model, 'loss_' + k)), float(gd['seq%d_loss_%s' % (it, k)])
+            f32 = float(gd['seq%d_loss_%s_f32' % (it, k)])
+            worst = max(worst, abs(a - t) / abs(t))
+            assert abs(a - t) <= 3.0 * abs(f32 - t) + 2e-2 * abs(t), (it, k, a, t, f32)
+    print('largest relative loss difference over the sequence: %.3e' % worst)
