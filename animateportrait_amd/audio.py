@@ -12,10 +12,10 @@ Host-side numpy / scipy, as in the reference (the mel stage runs once per clip o
   * ``window_frames``     = the test-time collate of ``Audio2landmark_Dataset``
     (Module1/src/dataset/audio2landmark/audio2landmark_dataset.py:73-78): windows ``au[i : i + 18]`` for
     ``i in range(0, T - 18, 1)``.
-NOT here, because their code or weights are not in this image: the AutoVC content converter between the mel spectrogram
-and the windows (``Generator(16, 256, 512, 16)`` + checkpoint, :205-208), the RAPT f0 track it consumes (pysptk) and the
-speaker embedding (resemblyzer).  ``clip_audio_features`` therefore hands the mel spectrogram itself to the windows (the
-converter maps a (T, 80) mel to a (T, 80) mel) and takes the speaker embedding as an argument.
+The AutoVC content converter between the mel spectrogram and the windows (``Generator(16, 256, 512, 16)``, :205-208) lives in
+``autovc.py`` (round 4) and enters ``clip_audio_features`` as the ``converter`` callable.  NOT here, because the packages are
+not in this image: the RAPT f0 track the converter consumes (pysptk) and the speaker embedding (resemblyzer) -- both are
+arguments of ``autovc.convert_mel``.
 The mel filter bank restates librosa 0.7's ``filters.mel`` (Slaney scale, Slaney area normalisation, the version the
 reference pins); librosa is absent from this image, so that table is **parity unpinned** -- everything around it is pinned
 to the reference's own function (tests/golden/make_audio_golden.py).
@@ -128,12 +128,17 @@ def window_frames(au, num_window_frames=WINDOW_FRAMES, step=1):
     return np.stack([au[i:i + num_window_frames] for i in range(0, n, step)])
 
 
-def clip_audio_features(path, max_frames=None, normalize=True):
-    """wav file -> float32 windows (F, 18, 80) for ``module1.predict_landmarks*``; F output frames at 62.5 fps."""
+def clip_audio_features(path, max_frames=None, normalize=True, converter=None):
+    """wav file -> float32 windows (F, 18, 80) for ``module1.predict_landmarks*``; F output frames at 62.5 fps.
+    converter: the AutoVC stage between the mel spectrogram and the windows (main_end2end_module2.py:218-224), a callable
+    (T, 80) mel -> (T, 80) mel -- ``lambda mel: autovc.convert_mel(G, mel, f0, emb_src, emb_trg)``.  None hands the RAW mel to
+    the windows, which is NOT what checkpoints trained by the reference expect (they saw converted spectrograms)."""
     x, sr = read_wav(path)
     x = resample_to_16k(x, sr)
     if normalize:
         x = normalize_loudness(x)
     s = mel_spectrogram(x).astype(np.float32)
+    if converter is not None:
+        s = np.asarray(converter(s), dtype=np.float32)
     w = window_frames(s)
     return w if max_frames is None else w[:max_frames]

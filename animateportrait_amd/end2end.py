@@ -59,7 +59,8 @@ def load_matte(path, size):
 
 
 def landmarks_from_audio(a, device):
-    """The audio half of main_end2end_module2.py:181-272 in process: returns (photo landmarks (68, 2), clip (T, 68, 2)) px."""
+    """main_end2end_module2.py:205-272 in process (mel -> AutoVC conversion -> both Module1 networks -> post-processing), with
+    the clip's f0 track and speaker embedding as inputs: returns (photo landmarks (68, 2), clip (T, 68, 2)) px."""
     from . import audio, module1
     shape = np.loadtxt(a.photo_landmarks).reshape(68, -1)
     if shape.shape[1] == 2:
@@ -67,8 +68,19 @@ def landmarks_from_audio(a, device):
     std_z = np.loadtxt(a.std_face).reshape(68, 3)[:, 2] if a.std_face else None
     face_id, scale, shift = module1.adjust_and_norm_input_face(shape, std_z)
     net_g, net_c = module1.load_module1(a.load_a2l_G_name, a.load_a2l_C_name, device)
-    emb = np.loadtxt(a.speaker_emb).reshape(-1) if a.speaker_emb else np.zeros(256, dtype=np.float32)
-    windows = audio.clip_audio_features(a.wav, max_frames=a.max_frames)
+    emb = np.loadtxt(a.speaker_emb).reshape(-1).astype(np.float32)
+    converter = None
+    if not a.no_autovc:
+        # main_end2end_module2.py:218-224: Module1 sees the AutoVC-converted spectrogram, not the raw mel
+        from . import autovc
+        G = autovc.load_generator(a.load_AUTOVC_name, device)
+        emb_trg = autovc.load_target_embedding(a.autovc_target_emb)
+        f0 = np.load(a.f0_npy) if a.f0_npy else None
+        if f0 is None:
+            print('WARNING: no --f0_npy: the converter runs on an all-unvoiced f0 track (the reference extracts RAPT f0 with '
+                  'pysptk, which is not in this image)')
+        converter = lambda mel: autovc.convert_mel(G, mel, None if f0 is None else f0[:mel.shape[0]], emb, emb_trg, device)   # noqa: E731
+    windows = audio.clip_audio_features(a.wav, max_frames=a.max_frames, converter=converter)
     fl = module1.predict_landmarks_speaker_aware(net_g, net_c, windows, emb, face_id.reshape(-1))
     seq = module1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
     return module1.photo_landmarks_in_pixels(face_id, scale, shift), seq.astype(np.float32)
@@ -86,7 +98,14 @@ def main(argv=None):
     ap.add_argument('--audio', default=None)
     ap.add_argument('--wav', default=None, help='drive the clip from this audio file (needs --photo_landmarks)')
     ap.add_argument('--photo_landmarks', default=None, help='txt, 68 rows "x y z": the photo\'s detected landmarks in pixels')
-    ap.add_argument('--speaker_emb', default=None, help='txt with the 256-d speaker embedding (default: zeros)')
+    ap.add_argument('--speaker_emb', default=None, help='txt with the 256-d resemblyzer speaker embedding of the clip (required with --wav)')
+    ap.add_argument('--load_AUTOVC_name', default='Module1/checkpoints/ckpt_autovc.pth',
+                    help='AutoVC converter checkpoint (main_end2end_module2.py:43); Module1 is fed the converted spectrogram')
+    ap.add_argument('--autovc_target_emb', default=None, help='target-speaker embedding txt (default: the reference checkout\'s obama_emb.txt)')
+    ap.add_argument('--f0_npy', default=None, help='normalised RAPT f0 track of the clip (extract_f0_func_audiofile), one value per mel frame')
+    ap.add_argument('--no_autovc', action='store_true',
+                    help='feed the RAW mel spectrogram to Module1 (NOT what the reference does: its checkpoints were trained on '
+                         'AutoVC-converted spectrograms); for experiments with networks trained that way')
     ap.add_argument('--std_face', default=None, help='STD_FACE_LANDMARKS.txt (its depth column replaces the detected one)')
     ap.add_argument('--load_a2l_G_name', default='Module1/checkpoints/ckpt_speaker_branch.pth')
     ap.add_argument('--load_a2l_C_name', default='Module1/checkpoints/ckpt_content_branch.pth')
@@ -98,6 +117,12 @@ def main(argv=None):
         ap.error('exactly one of --landmarks / --landmarks_npy / --wav')
     if a.wav is not None and a.photo_landmarks is None:
         ap.error('--wav needs --photo_landmarks')
+    if a.wav is not None and a.speaker_emb is None:
+        ap.error('--wav needs --speaker_emb (the 256-d resemblyzer embedding the speaker-aware branch is conditioned on, '
+                 'main_end2end_module2.py:215-217); a zero vector is not a neutral default')
+    if a.wav is not None and not a.no_autovc and not os.path.exists(a.load_AUTOVC_name):
+        ap.error('--wav: AutoVC checkpoint %s not found; the reference converts the spectrogram before Module1 '
+                 '(pass --load_AUTOVC_name, or --no_autovc to feed the raw mel on purpose)' % a.load_AUTOVC_name)
     # the model's own options: the test settings of test_gan_new (:95-104) unless given
     defaults = ['--model', 'geomcgt_ifw_test', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--netg_resb_div', '3',
                 '--netg_resb_disp', '3', '--output_nc', '1', '--dataset_mode', 'synthetic', '--blendbg', '1', '--gpu_ids', '0']

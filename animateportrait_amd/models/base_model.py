@@ -55,6 +55,7 @@ class BaseModel(ABC):
         # rank 0's weights, as the reference's single replicated nn.DataParallel module does (networks.py:115-118)
         parallel.broadcast_model(self)
         self.attach_flow_network()
+        self.attach_aux_networks()
         self.print_networks(opt.verbose)
 
     FLOW_CHECKPOINT_DIR = 'checkpoints'
@@ -79,6 +80,13 @@ class BaseModel(ABC):
                 # ... unless its configuration cannot be folded (norm='instance'): then the stock-PyTorch mirror
                 print('[netF] %s: running FlowUnet_v2 as stock PyTorch modules' % e)
                 aux['netF'] = net
+
+    def attach_aux_networks(self):
+        """The frozen MODNet / MobileFaceNet / Sphere20a (geomgm_ifw_fore_model.py:362-376, geomcgt_ifw_test_model.py:218-223)
+        from ``checkpoints/`` (and ``--face_recog_model``) when the files are there: stock PyTorch-ROCm mirrors that load the
+        published checkpoints strictly (aux_nets.py).  Slots a caller filled already are left alone."""
+        from ..aux_nets import attach_aux_networks
+        return attach_aux_networks(self, self.FLOW_CHECKPOINT_DIR)
 
     def eval(self):
         for name in self.model_names:

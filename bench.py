@@ -22,7 +22,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) carrying also
   "exact_fp32" / "plain_bf16_inference": the same step in the two other arithmetic modes (the strict-fp32 figure and the
                      reduced-precision one; neither is `value`);
   "train_step" / "train_step_bf16": the full geomgm_ifw_fore drawing-config step (all nine backward_G terms: the frozen
-                     aux nets are fixed-seed stand-ins, animateportrait_amd/standins.py), B=16 per GPU;
+                     aux nets MODNet / MobileFaceNet / Sphere20a run at the reference architectures, aux_nets.py), B=16 per GPU;
   "stream":          BASELINE configs[4], the 10 s clip end to end (N=1 only);
   "env_switches":    every APAMD_* variable that was set (they select alternative kernels; none skips work).
 """
@@ -131,10 +131,14 @@ def oracle_reference_output(sd):
 PARITY_BUDGET = 1e-3      # every reported number needs the generator output within 1e-3 L-inf (fp32, outputs in [-1, 1])
 
 
-def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
+def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3', aux_kind='reference-architecture'):
     """Time `steps` full train steps (after 1 warm-up) of the drawing config (readme.md:65 flags), B=16/GPU.
     precision: 'bf16x3' (fp32-class arithmetic, fp32 tensors) or 'bf16' (plain bf16 products, fp32 accumulation and
-    fp32 master weights -- BASELINE configs[2-3])."""
+    fp32 master weights -- BASELINE configs[2-3]).
+    aux_kind: 'reference-architecture' = the three frozen nets the reference's step calls at their REAL architectures
+    (MODNet matte in set_input, MobileFaceNet in the geometry term, Sphere20a in the identity term: aux_nets.py, stock
+    PyTorch-ROCm, random init -- their checkpoints are not in the reference tree); 'standin' = the toy nets of standins.py
+    (what rounds 1-3 timed; kept as the comparison that isolates the aux nets' cost)."""
     from animateportrait_amd.options.base_options import TrainOptions
     from animateportrait_amd.models import create_model
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
@@ -152,9 +156,16 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
         # stand-ins with the same call contracts: the geometry and identity terms of backward_G
         # (geomgm_ifw_fore_model.py:704-713, :741-752) -- window crop + bicubic / bilinear resize, both aux forwards and
         # data gradients, FaceLoss -- are then INSIDE the timed step
-        from animateportrait_amd import parallel, standins, networks as _nets
-        model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
-        model.aux['faceloss'] = _nets.FaceLoss(standins.StandinFaceNet().to(dev))
+        from animateportrait_amd import parallel, standins, aux_nets, networks as _nets
+        if aux_kind == 'standin':
+            model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
+            model.aux['faceloss'] = _nets.FaceLoss(standins.StandinFaceNet().to(dev))
+        else:
+            torch.manual_seed(4321)
+            frozen = lambda net: aux_nets._frozen(net, dev)                                       # noqa: E731
+            model.aux['landmarks'] = frozen(aux_nets.MobileFaceNet((112, 112), 136))              # geomgm_ifw_fore_model.py:362
+            model.aux['faceloss'] = _nets.FaceLoss(frozen(aux_nets.Sphere20a()))                  # :374-376
+            model.aux['modnet'] = frozen(aux_nets.MODNet())                                       # :369-373, called in forward :519
         parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
         drift0 = parallel.replica_drift(model)
         batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
@@ -192,9 +203,13 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3'):
             'gflop_per_sample_algorithmic': 1234.0,
             'algorithmic_tflops': round(BATCH * 1.234 / dt, 1),
             'frac_algorithmic': round(BATCH * 1.234 / dt / PEAK_BF16_MFMA_TFLOPS, 4),
-            'note': 'geomgm_ifw_fore drawing config, all nine backward_G terms in the timed region; the frozen landmark / '
-                    'identity nets (MobileFaceNet, Sphere20a: checkpoints absent from the reference tree) are fixed-seed '
-                    'stand-in aux nets (animateportrait_amd/standins.py); matte / intrinsic flow are synthetic batch inputs'}
+            'aux_nets': aux_kind,
+            'note': 'geomgm_ifw_fore drawing config, all nine backward_G terms in the timed region; ' + (
+                'MODNet (matte), MobileFaceNet (geometry term) and Sphere20a (identity term) run at the reference architectures '
+                '(aux_nets.py, stock PyTorch-ROCm, random init: their checkpoints are absent from the reference tree); intrinsic '
+                'flow (netF: hyper-parameters in an absent train_opt.json, SURVEY 8a excludes it) is a synthetic batch input'
+                if aux_kind != 'standin' else
+                'the frozen landmark / identity nets are the toy stand-ins of standins.py, matte / intrinsic flow are batch inputs')}
 
 
 def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
@@ -228,6 +243,15 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     content = module1.Audio2LandmarkContent(use_prior_net=True, drop_out=0.5).to(dev).eval()      # train_audio2landmark.py:71-73
     pose = module1.Audio2LandmarkPos(drop_out=0.5).to(dev).eval()                                  # :55-59
     spk = torch.randn(256, generator=torch.Generator().manual_seed(7))
+    # the AutoVC converter between the mel spectrogram and the windows (main_end2end_module2.py:218-224): the reference
+    # architecture (autovc.py), random init; synthetic speaker embeddings and an all-voiced synthetic f0 track (RAPT / resemblyzer
+    # are third-party packages absent from this image)
+    from animateportrait_amd import autovc
+    torch.manual_seed(99)
+    vc = autovc.Generator(16, 256, 512, 16).to(dev).eval()
+    e_src = np.abs(np.random.RandomState(3).randn(256)).astype(np.float32) * 0.1
+    e_trg = np.abs(np.random.RandomState(4).randn(256)).astype(np.float32) * 0.1
+    convert = lambda mel: autovc.convert_mel(vc, mel, 0.5 + 0.4 * np.sin(np.arange(mel.shape[0]) / 9.0), e_src, e_trg, dev)   # noqa: E731
     g = torch.Generator().manual_seed(1234)
     photo = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
@@ -244,7 +268,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
         # main_end2end_module2.py:262-272 (timed; its output is not fed on -- random weights do not draw faces -- the
         # synthetic sequence of the same length is)
         # audio front end on the host, as in the reference: wav -> loudness -> mel (62.5 frames/s) -> 18-frame windows
-        au = audio.clip_audio_features(wav, max_frames=frames)
+        au = audio.clip_audio_features(wav, max_frames=frames, converter=convert)
         assert au.shape == (frames, 18, 80)
         fl = module1.predict_landmarks_speaker_aware(pose, content, au, spk, fid)
         module1.to_image_landmarks(fl, scale=0.01, shift=(-128.0, -128.0), rng=np.random.RandomState(0))
@@ -290,8 +314,9 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
             'speedup_vs_cpu': round(cpu_s * frames / wall, 1),
             'note': 'random-init weights; netF = FlowUnet_v2 (nf 64, 4 scales) on the HIP conv kernels, stand-in matte; Module1 = both landmark networks (content + speaker-aware '
                     'pose branch) and their post-processing on the mel windows of the reference\'s example clip '
-                    '(tests/golden/female12.wav; mel stage inside the timed region); synthetic speaker embedding; the AutoVC '
-                    'converter, RAPT f0 and the checkpoints are absent from the reference tree'}
+                    '(tests/golden/female12.wav; mel stage and the AutoVC converter -- reference architecture, random init -- inside '
+                    'the timed region); synthetic speaker embeddings and f0 track (resemblyzer / RAPT are third-party packages '
+                    'absent from this image); no checkpoint of any of these nets is in the reference tree'}
 
 
 def main():
@@ -505,6 +530,11 @@ def main():
             train = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16x3')
             torch.cuda.empty_cache()
             train_bf16 = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16')
+            torch.cuda.empty_cache()
+            # the same bf16 step with the toy aux nets of rounds 1-3: the difference is what the three real nets cost
+            toy = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16', aux_kind='standin')
+            train_bf16['ms_per_step_with_standin_aux'] = toy['ms_per_step']
+            train_bf16['aux_ms_per_step'] = round(train_bf16['ms_per_step'] - toy['ms_per_step'], 2)
         finally:
             ops.DEFAULT_PRECISION = old
 

@@ -235,7 +235,7 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch):
             y = G(*[a.to(dev) for a in args])
     finally:
         ops.PROFILER = None
-    names = {r[0] for r in prof.records}
+    names = {r[0].replace(' ', '') for r in prof.records}
     with torch.no_grad():
         ref = og.generator_forward(sd, *args, div=3, disp=3)
     err = linf(y, ref)

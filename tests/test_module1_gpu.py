@@ -123,11 +123,21 @@ def test_end2end_cli_from_wav(dev, golden, tmp_path, monkeypatch):
     lm0 = make_landmarks(1, torch.Generator().manual_seed(9))[0].numpy()
     lm0[0, 0], lm0[16, 0] = 190.0, 70.0              # jaw ends set the normalisation scale (util/utils.py:349)
     np.savetxt('photo_lm.txt', np.concatenate([lm0, np.zeros((68, 1))], 1))
-    np.savetxt('spk.txt', np.random.RandomState(3).randn(256))
+    np.savetxt('spk.txt', np.abs(np.random.RandomState(3).randn(256)) * 0.1)
+    np.savetxt('trg.txt', np.abs(np.random.RandomState(4).randn(256)) * 0.1)
+    from animateportrait_amd import autovc
+    torch.manual_seed(5)
+    vc = autovc.Generator(16, 256, 512, 16)
+    torch.save({'model': vc.state_dict()}, 'm1/autovc.pth')
     wav = os.path.join(GOLDEN, 'female12.wav')
-    argv = ['--photo', 'photo.png', '--matte', 'matte.png', '--wav', wav, '--photo_landmarks', 'photo_lm.txt',
-            '--speaker_emb', 'spk.txt', '--load_a2l_G_name', 'm1/g.pth', '--load_a2l_C_name', 'm1/c.pth', '--max_frames', '64',
+    base = ['--photo', 'photo.png', '--matte', 'matte.png', '--wav', wav, '--photo_landmarks', 'photo_lm.txt',
+            '--load_a2l_G_name', 'm1/g.pth', '--load_a2l_C_name', 'm1/c.pth', '--max_frames', '64',
             '--out', 'out', '--batch', '8', '--name', 'e2e', '--epoch', '7', '--ngf', '8', '--checkpoints_dir', 'checkpoints']
+    # the reference feeds Module1 the AutoVC-converted spectrogram and the clip's speaker embedding: neither is optional
+    for bad in (base, base + ['--speaker_emb', 'spk.txt']):            # no embedding / no converter checkpoint at the default path
+        with pytest.raises(SystemExit):
+            end2end.main(bad)
+    argv = base + ['--speaker_emb', 'spk.txt', '--load_AUTOVC_name', 'm1/autovc.pth', '--autovc_target_emb', 'trg.txt']
     np.random.seed(0)
     assert end2end.main(argv) == 0
     files = sorted(os.listdir('out/frames'))
@@ -137,7 +147,10 @@ def test_end2end_cli_from_wav(dev, golden, tmp_path, monkeypatch):
     # the landmark sequence the CLI derived: finite, inside a sane range around the photo's landmarks
     fid, scale, shift = m1.adjust_and_norm_input_face(np.loadtxt('photo_lm.txt'))
     g2, c2 = m1.load_module1('m1/g.pth', 'm1/c.pth', dev)
-    fl = m1.predict_landmarks_speaker_aware(g2, c2, audio.clip_audio_features(wav, max_frames=64), np.loadtxt('spk.txt'), fid.reshape(-1))
+    vc2 = autovc.load_generator('m1/autovc.pth', dev)
+    conv = lambda mel: autovc.convert_mel(vc2, mel, None, np.loadtxt('spk.txt'), np.loadtxt('trg.txt'), dev)       # noqa: E731
+    fl = m1.predict_landmarks_speaker_aware(g2, c2, audio.clip_audio_features(wav, max_frames=64, converter=conv),
+                                            np.loadtxt('spk.txt'), fid.reshape(-1))
     np.random.seed(0)
     seq = m1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
     assert np.isfinite(seq).all() and np.abs(seq.mean(0) - m1.photo_landmarks_in_pixels(fid, scale, shift)).max() < 400
