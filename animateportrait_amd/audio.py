@@ -54,13 +54,17 @@ def resample_to_16k(x, sr):
 
 def normalize_loudness(x, target_dbfs=-20.0):
     """pydub ``sound.apply_gain(target_dBFS - sound.dBFS)`` on 16-bit samples: dBFS = 20 log10(rms / 32768) with the rms
-    over ALL samples of all channels (audioop.rms), gain applied in the integer domain with rounding and clipping."""
+    over ALL samples of all channels (audioop.rms), gain applied in the integer domain as audioop.mul does (clamp, then floor)."""
     q = np.clip(np.round(np.asarray(x, dtype=np.float64) * 32768.0), -32768, 32767)
     rms = int(np.sqrt(np.mean(q.astype(np.float64) ** 2)))              # audioop.rms truncates to an integer
     if rms == 0:
         return q / 32768.0
     gain = 10.0 ** ((target_dbfs - 20.0 * np.log10(rms / 32768.0)) / 20.0)
-    return np.clip(np.round(q * gain), -32768, 32767) / 32768.0
+    # audioop.mul (what AudioSegment.apply_gain runs): fbound() = clamp to [minval, maxval] -- anything below minval + 1 becomes
+    # minval -- THEN floor toward -inf; not round-to-nearest
+    v = q * gain
+    v = np.where(v > 32767.0, 32767.0, np.where(v < -32767.0, -32768.0, v))
+    return np.floor(v) / 32768.0
 
 
 def _hz_to_mel(f):

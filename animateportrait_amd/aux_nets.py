@@ -21,6 +21,16 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+class _PReLU(nn.PReLU):
+    """nn.PReLU (same ``weight`` key) evaluated as max(x, 0) + w * min(x, 0): the same values, but its backward is two plain
+    elementwise kernels -- aten's prelu_backward also forms the (unused: the net is frozen) slope gradient and ran 155 us per
+    layer on these small maps, 5 of the 8 ms of a MobileFaceNet forward + backward (tools/aux_bench.py)."""
+
+    def forward(self, x):
+        w = self.weight.view(1, -1, *([1] * (x.dim() - 2)))
+        return torch.clamp_min(x, 0) + w * torch.clamp_max(x, 0)
+
+
 # ----------------------------------------------------------------------------------------------- MobileFaceNet
 class _ConvBN(nn.Module):
     """conv (no bias) -> BatchNorm2d [-> PReLU]; attribute names are the checkpoint's (conv / bn / prelu)."""
@@ -30,7 +40,7 @@ class _ConvBN(nn.Module):
         self.conv = nn.Conv2d(cin, cout, k, s, p, groups=groups, bias=False)
         self.bn = nn.BatchNorm2d(cout)
         if act:
-            self.prelu = nn.PReLU(cout)
+            self.prelu = _PReLU(cout)
         self._act = act
 
     def forward(self, x):
@@ -112,7 +122,7 @@ class Sphere20a(nn.Module):
         for s, (c, units) in enumerate(self.STAGES, 1):
             for i in range(1, 2 * units + 2):
                 setattr(self, 'conv%d_%d' % (s, i), nn.Conv2d(cin if i == 1 else c, c, 3, 2 if i == 1 else 1, 1))
-                setattr(self, 'relu%d_%d' % (s, i), nn.PReLU(c))
+                setattr(self, 'relu%d_%d' % (s, i), _PReLU(c))
             cin = c
         self.fc5 = nn.Linear(512 * 7 * 6, 512)
 
@@ -289,11 +299,14 @@ class MODNet(nn.Module):
         self.lr_branch = _LRBranch(self.backbone)
         self.hr_branch = _HRBranch(hr_channels, self.backbone.enc_channels)
         self.f_branch = _FusionBranch(hr_channels, self.backbone.enc_channels)
+        self.fast_layout = False       # set by prepare_frozen: NHWC activations (MIOpen's NHWC solvers: 11.8 -> 8.8 ms at B=16)
 
     def forward(self, img, inference=True):
+        if self.fast_layout and img.is_cuda:
+            img = img.contiguous(memory_format=torch.channels_last)
         sem, lr8x, enc2x, enc4x = self.lr_branch(img, inference)
         detail, hr2x = self.hr_branch(img, enc2x, enc4x, lr8x, inference)
-        return sem, detail, self.f_branch(img, lr8x, hr2x)
+        return sem, detail, self.f_branch(img, lr8x, hr2x).contiguous()
 
 
 # ----------------------------------------------------------------------------------------------- loaders
@@ -301,35 +314,60 @@ MOBILEFACENET_CKPT = 'mobilefacenet_model_best.pth.tar'              # geomgm_if
 MODNET_CKPT = 'modnet_photographic_portrait_matting.ckpt'            # :371, geomcgt_ifw_test_model.py:222
 
 
-def _frozen(net, device):
+def fold_batchnorm(net):
+    """Fold every eval-mode ``Conv2d -> BatchNorm2d`` pair that sits side by side in a module into the convolution (in place;
+    the BatchNorm becomes an Identity).  Only for a net that is already loaded and frozen: its state_dict keys change."""
+    from torch.nn.utils.fusion import fuse_conv_bn_eval
+
+    def walk(m):
+        names = list(m._modules.keys())
+        for a, b in zip(names, names[1:]):
+            ma, mb = m._modules[a], m._modules[b]
+            if isinstance(ma, nn.Conv2d) and isinstance(mb, nn.BatchNorm2d):
+                m._modules[a] = fuse_conv_bn_eval(ma.eval(), mb.eval())
+                m._modules[b] = nn.Identity()
+        for c in m._modules.values():
+            if c is not None:
+                walk(c)
+    walk(net)
+    return net
+
+
+def _frozen(net, device, fold=True):
+    """eval mode, no parameter gradients, BatchNorm folded into the convolutions (the net never trains), MODNet in NHWC."""
     net = net.to(device).eval()
+    if fold:
+        fold_batchnorm(net)
+    if isinstance(net, MODNet) and torch.device(device).type == 'cuda':
+        net = net.to(memory_format=torch.channels_last)
+        net.fast_layout = True
     for p in net.parameters():
         p.requires_grad_(False)
     return net
 
 
-def load_mobilefacenet(path, device):
+def load_mobilefacenet(path, device, fold=True):
     """geomgm_ifw_fore_model.py:362-366: checkpoint dict with the weights under 'state_dict'."""
     net = MobileFaceNet((112, 112), 136)
     ck = torch.load(path, map_location='cpu')
     net.load_state_dict(ck['state_dict'], strict=True)
-    return _frozen(net, device)
+    return _frozen(net, device, fold)
 
 
-def load_modnet(path, device):
+def load_modnet(path, device, fold=True):
     """:369-373: the checkpoint was saved from nn.DataParallel(MODNet) -- every key carries a ``module.`` prefix."""
     net = MODNet(backbone_pretrained=False)
     sd = torch.load(path, map_location='cpu')
     net.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()}, strict=True)
-    return _frozen(net, device)
+    return _frozen(net, device, fold)
 
 
-def load_sphere20a(path, device):
+def load_sphere20a(path, device, fold=True):
     """networks.py:3044-3053: the classifier head ``fc6*`` of the published checkpoint is dropped, the rest loads strictly."""
     net = Sphere20a()
     sd = torch.load(path, map_location='cpu')
     net.load_state_dict({k: v for k, v in sd.items() if not k.startswith('fc6')}, strict=True)
-    return _frozen(net, device)
+    return _frozen(net, device, fold)
 
 
 def attach_aux_networks(model, checkpoints_dir='checkpoints', verbose=True):

@@ -346,12 +346,29 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
-        // one pipeline stage = one 16-channel chunk; P = its LDS stage buffer (compile-time in each copy)
-        auto stage = [&](auto ptag, int c) __attribute__((always_inline)) {
+        // one pipeline stage = one 16-channel chunk; P = its LDS stage buffer (compile-time in each copy).
+        // MASK != 0 (space-to-depth 3x3 layers, K == 0 with 4 taps): the stage's taps are known at COMPILE time -- the set bits of
+        // MASK -- so an absent tap costs neither MFMAs nor fragment reads.  With the run-time mask only the MFMAs were skipped:
+        // a stage then issued 32 ds_read_b128 per wave for 27 MFMAs on average (4 / 2 / 2 / 1 taps of the four input phases),
+        // and the LDS read port, not the matrix pipe, bounded the kernel (8 waves per CU, profiles/r03_ablate_layers.md).
+        auto stage = [&](auto ptag, auto mtag, int c) __attribute__((always_inline)) {
             constexpr int P = decltype(ptag)::value;
+            constexpr unsigned MASK = decltype(mtag)::value;
+            static_assert(MASK == 0 || (K == 0 && (MASK & 1u)), "compile-time tap sets: run-time-tap family, tap 0 always present");
+            constexpr int NREAL = MASK ? __builtin_popcount(MASK) : TMAX;
+            auto tap_of = [](int i) constexpr {                   // i-th tap of the stage
+                if (!MASK) return i;
+                int n = 0;
+                for (int b = 0; b < TMAX; ++b)
+                    if ((MASK >> b) & 1u) {
+                        if (n == i) return b;
+                        ++n;
+                    }
+                return 0;
+            };
             // taps of this stage: of the tile's phase, or (space-to-depth 3x3) of the chunk's input phase
-            const unsigned tm = (K == 0 && p.s2d_div > 0) ? p.s2d_mask[c / p.s2d_div < 3 ? c / p.s2d_div : 3] : tmask;
-            constexpr int FP = (XPF && (TMAX & 1)) ? P : 0;        // register buffer of tap 0
+            const unsigned tm = MASK ? MASK : ((K == 0 && p.s2d_div > 0) ? p.s2d_mask[c / p.s2d_div < 3 ? c / p.s2d_div : 3] : tmask);
+            constexpr int FP = (XPF && (NREAL & 1)) ? P : 0;       // register buffer of tap 0
             constexpr int WP = (XPF && (K & 1)) ? P : 0;           // window buffer of kx = 0
             if (!XPF || c == 0) {
                 if constexpr (WIN) {
@@ -363,12 +380,14 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                 }
             }
 #pragma unroll
-            for (int tp = 0; tp < TMAX; ++tp) {
+            for (int ti = 0; ti < NREAL; ++ti) {
+                const int tp = tap_of(ti);
                 // windowed form: taps column by column; t = the tap's index in the weight image
-                const int kx = WIN ? tp / K : 0, ky = WIN ? tp % K : 0;
+                constexpr int KD = K > 0 ? K : 1;                    // (K == 0 instantiations never take the windowed form)
+                const int kx = WIN ? tp / KD : 0, ky = WIN ? tp % KD : 0;
                 const int t = WIN ? ky * K + kx : tp;
-                const int cb = (tp + FP) & 1, wb = (kx + WP) & 1;
-                const bool last = tp == TMAX - 1;
+                const int cb = (ti + FP) & 1, wb = (kx + WP) & 1;
+                const bool last = ti == NREAL - 1;
                 auto mfma_one = [&](int i) __attribute__((always_inline)) {
                     // the three partial products go round all MT*NT accumulators in turn, so consecutive MFMAs
                     // never wait on each other's result (small terms first)
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                 if (!last) {
                     int nrd = NRD;                                  // LDS reads issued for the next tap
                     if constexpr (WIN) {
-                        const int kx2 = (tp + 1) / K, ky2 = (tp + 1) % K;
+                        const int kx2 = (tp + 1) / KD, ky2 = (tp + 1) % KD;
                         fetch_a(P, ky2 * K + kx2, cb ^ 1);
                         if (kx2 == kx) {
                             fetch_brow(P, kx, ky2 + NT - 1, wb);
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
                             for (int q = 0; q < NT; ++q) fetch_brow(P, kx2, q, wb ^ 1);
                         }
                     } else {
-                        fetch(P, t + 1, cb ^ 1);
+                        fetch(P, MASK ? tap_of(ti + 1) : t + 1, cb ^ 1);
                     }
                     if (K != 0 || ((tm >> tp) & 1u)) {       // (an absent tap of a fused phase: zero weights, nothing to add)
 #pragma unroll
@@ -456,9 +475,31 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         };
         // nchunks is even: chunk pairs run straight-line through stage buffers 0 and 1 (a run-time choice of the
         // buffer per stage makes the register allocator shuttle all accumulators between VGPRs and AGPRs)
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
         for (int c = 0; c < nchunks; c += 2) {
-            stage(std::integral_constant<int, 0>{}, c);
-            stage(std::integral_constant<int, 1>{}, c + 1);
+            if constexpr (K == 0 && TMAX == 4) {
+                // space-to-depth 3x3 layer with an even chunk count per input phase: both stages of the pair belong to one
+                // phase, whose tap set (all four / left column / top row / corner) picks the straight-line copy
+                if (p.s2d_div > 0 && (p.s2d_div & 1) == 0) {
+                    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)p.s2d_mask[c / p.s2d_div < 3 ? c / p.s2d_div : 3]);
+                    if (m == 0x5u) {
+                        stage(P0{}, std::integral_constant<unsigned, 0x5u>{}, c);
+                        stage(P1{}, std::integral_constant<unsigned, 0x5u>{}, c + 1);
+                        continue;
+                    } else if (m == 0x3u) {
+                        stage(P0{}, std::integral_constant<unsigned, 0x3u>{}, c);
+                        stage(P1{}, std::integral_constant<unsigned, 0x3u>{}, c + 1);
+                        continue;
+                    } else if (m == 0x1u) {
+                        stage(P0{}, std::integral_constant<unsigned, 0x1u>{}, c);
+                        stage(P1{}, std::integral_constant<unsigned, 0x1u>{}, c + 1);
+                        continue;
+                    }
+                }
+            }
+            stage(P0{}, std::integral_constant<unsigned, 0u>{}, c);
+            stage(P1{}, std::integral_constant<unsigned, 0u>{}, c + 1);
         }
         constexpr int pl = 1;                                      // stage buffer of the last chunk: free now; the
                                                                    // next tile's chunk 0 sits in buffer 0 again

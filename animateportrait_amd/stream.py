@@ -107,6 +107,8 @@ class ClipStreamer:
         out = torch.empty((t_total, m.opt.output_nc, s, s), dtype=torch.float32, device=dev)
         self.timing = {}
         photo_b, alm_b, matte_b = {}, {}, {}
+        ClipStreamer._clips = getattr(ClipStreamer, '_clips', 0) + 1
+        clip_id = ('clip', ClipStreamer._clips)      # names this run's constant photo landmark map for the generator's cache
         for lo in range(0, t_total, self.batch):
             hi = min(lo + self.batch, t_total)
             b = hi - lo
@@ -126,7 +128,7 @@ class ClipStreamer:
                 self._tick('landmark_maps', t0)
             data = {'A': photo_b[b], 'warp_motion': motion, 'A_lm': alm_b[b], 'tB_lm': tb_lm,
                     'A_lm_68': lm0.view(1, 68, 2).expand(b, -1, -1).to(dev), 'tB_lm_68': lm_dev,
-                    'image_paths': ['%05d' % i for i in range(lo, hi)]}
+                    'image_paths': ['%05d' % i for i in range(lo, hi)], 'clip_id': clip_id}
             if matte is not None:
                 data['matte'] = matte_b[b]
             if m.aux['netF'] is None:                # no intrinsic-flow network: no flow, nothing masked out

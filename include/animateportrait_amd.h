@@ -23,7 +23,12 @@
  *     let no other kernel share the device with it): a kernel that shares
  *     compute units with the library's matrix kernels was measured to read
  *     wrong data in lanes 48-63 on MI355X ("Concurrent
- *     streams"; tools/conc_warp.py reproduces it).
+ *     streams"; tools/conc_warp.py / tools/hazard/run_hazard.py reproduce it);
+ *   - inputs are FINITE fp32 values.  Zero padding and out-of-frame sampling taps
+ *     are evaluated as (some in-range element) x (weight 0) and the consumer-side
+ *     activations as max(v, slope * v): identical to the reference for finite data,
+ *     but a tensor that already holds Inf / NaN (a diverged training run) spreads
+ *     it to every padded / out-of-frame position, where ATen would write 0.
  */
 #ifndef ANIMATEPORTRAIT_AMD_H
 #define ANIMATEPORTRAIT_AMD_H

@@ -72,3 +72,20 @@ def test_loudness_normalisation_hits_the_target():
     db = 20 * np.log10(np.sqrt(np.mean(q ** 2)) / 32768)
     assert abs(db - (-20.0)) < 0.05 and np.abs(y).max() <= 1.0
     assert audio.resample_to_16k(np.zeros(22050), 22050).shape == (16000,)
+
+
+def test_loudness_normalisation_matches_audioop_sample_for_sample():
+    """pydub's ``match_target_amplitude`` (AutoVC_mel_Convertor_retrain_version.py:13-15, :222-224) is ``audioop.rms`` +
+    ``audioop.mul`` on the 16-bit samples; audioop is in this interpreter's standard library, so the restatement is pinned
+    bit for bit: truncated integer rms, gain 10^(dB/20), clamp then FLOOR (not round-to-nearest)."""
+    import audioop
+    import math
+    rs = np.random.RandomState(5)
+    for scale, ch in ((0.01, 1), (0.3, 2), (0.9, 1)):            # quiet / loud (the gain is < 1) / near full scale
+        q = np.clip(np.round(rs.randn(4000, ch).squeeze() * scale * 32768), -32768, 32767).astype(np.int16)
+        data = q.tobytes()
+        rms = audioop.rms(data, 2)
+        gain = 10 ** ((-20.0 - 20 * math.log(rms / 32768.0, 10)) / 20)                 # pydub: ratio_to_db / db_to_float
+        want = np.frombuffer(audioop.mul(data, 2, gain), dtype=np.int16).reshape(q.shape)
+        got = audio.normalize_loudness(q.astype(np.float64) / 32768.0, -20.0) * 32768.0
+        assert np.array_equal(got, want.astype(np.float64)), (scale, ch, np.abs(got - want).max())

@@ -83,12 +83,21 @@ def test_checkpoint_loaders_and_auto_attach(tmp_path):
     sph['fc6.weight'] = torch.zeros(512, 10574)              # the classifier head the reference drops
     torch.save(sph, tmp_path / 'sphere20a_20171020.pth')
     dev = torch.device('cpu')
-    for got, want in ((aux_nets.load_mobilefacenet(str(tmp_path / aux_nets.MOBILEFACENET_CKPT), dev), mf),
-                      (aux_nets.load_sphere20a(str(tmp_path / 'sphere20a_20171020.pth'), dev), sp),
-                      (aux_nets.load_modnet(str(tmp_path / aux_nets.MODNET_CKPT), dev), mo)):
+    x = inputs()
+    for load, path, want, xin, pick in ((aux_nets.load_mobilefacenet, aux_nets.MOBILEFACENET_CKPT, mf, x['mobilefacenet'], lambda o: o[0]),
+                                        (aux_nets.load_sphere20a, 'sphere20a_20171020.pth', sp, x['sphere20a'], lambda o: o[-1]),
+                                        (aux_nets.load_modnet, aux_nets.MODNET_CKPT, mo, x['modnet'], lambda o: o[2])):
+        got = load(str(tmp_path / path), dev, fold=False)
         assert not got.training and not any(p.requires_grad for p in got.parameters())
         for (ka, va), (kb, vb) in zip(want.state_dict().items(), got.state_dict().items()):
             assert ka == kb and torch.equal(va, vb)
+        # the default loader folds the (frozen) BatchNorms into the convolutions: same function
+        folded = load(str(tmp_path / path), dev)
+        nbn = lambda net: sum(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())          # noqa: E731
+        assert nbn(folded) == (0 if load is not aux_nets.load_modnet else nbn(want) - 52)       # MODNet keeps its half-BN IBNorm layers
+        with torch.no_grad():
+            a, b = pick(want(xin)), pick(folded(xin))
+        assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()) + 1e-6
     opt = types.SimpleNamespace(face_recog_model=str(tmp_path / 'sphere20a_20171020.pth'), identity_loss=2)
     model = types.SimpleNamespace(aux={'modnet': None, 'landmarks': None, 'faceloss': None, 'netF': None}, opt=opt, device=dev, isTrain=True)
     assert aux_nets.attach_aux_networks(model, str(tmp_path), verbose=False) == ['modnet', 'landmarks', 'faceloss']

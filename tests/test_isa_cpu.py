@@ -1,0 +1,70 @@
+"""CPU: checks on the ISA of the built library (no GPU needed: llvm-objdump of the gfx950 code objects inside libapamd.so).
+
+The LDS-DMA primitive of the matrix kernels (csrc/conv_bf16x3.h ``glds16_sv``, wgrad_bf16x3.h, conv_ph4.h) writes M0 inside
+inline assembly and lists it as clobbered; hipcc warns that a clobber of a reserved register "may lead to undefined behaviour"
+because its register allocator does not model M0.  That is only a hazard if the COMPILER ever keeps a value of its own in M0
+across such a statement or emits an instruction that reads M0 implicitly.  This test makes the assumption a checked one: in
+the whole library every instruction that names M0 is the assembly's own ``s_mov_b32 m0, sN`` directly in front of its
+``global_load_lds_dwordx4``, and no instruction with an implicit M0 operand (movrel, sendmsg, GWS, LDS-param loads) exists."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'animateportrait_amd', 'libapamd.so')
+LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def _disassembly(tmp_path):
+    fat = str(tmp_path / 'fat.bin')
+    subprocess.check_call(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', LIB, fat])
+    data = open(fat, 'rb').read()
+    offs = [m.start() for m in re.finditer(b'__CLANG_OFFLOAD_BUNDLE__', data)]
+    assert offs, 'no offload bundle in libapamd.so'
+    out = []
+    for i, o in enumerate(offs):
+        end = offs[i + 1] if i + 1 < len(offs) else len(data)
+        b, co = str(tmp_path / ('b%d.bin' % i)), str(tmp_path / ('b%d.co' % i))
+        open(b, 'wb').write(data[o:end])
+        subprocess.check_call([LLVM + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + b,
+                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+        out.append(subprocess.run([LLVM + '/llvm-objdump', '-d', co], capture_output=True, text=True, check=True).stdout)
+    return out
+
+
+@pytest.mark.skipif(not (os.path.exists(LIB) and os.path.exists(LLVM + '/llvm-objdump')), reason='needs the built library and llvm-objdump')
+def test_m0_is_touched_only_by_the_lds_dma_assembly(tmp_path):
+    """Per kernel: M0 is written either ONLY by the raw assembly (scalar-base form ``global_load_lds_dwordx4 vN, s[a:b]``, its
+    ``s_mov_b32 m0`` directly in front, nothing but s_nop between) or ONLY by the compiler for its own builtin LDS-DMA (vector
+    address form) -- never both in one kernel, where a compiler-held M0 value could straddle an assembly statement."""
+    implicit = re.compile(r'^\s*(s_movrel|v_movrel|s_sendmsg|ds_gws|ds_param_load|ds_direct_load|v_interp|s_ttrace)')
+    n_raw = n_builtin = 0
+    for text in _disassembly(tmp_path):
+        kernel, raw, builtin = None, {}, {}
+        ins = []
+        for ln in text.split('\n'):
+            m = re.match(r'^[0-9a-f]+ <(\S+)>:', ln)
+            if m:
+                kernel = m.group(1)
+                continue
+            i = ln.split('//')[0].strip()
+            if i and kernel:
+                ins.append((kernel, i))
+        for k, (kern, i) in enumerate(ins):
+            assert not implicit.match(i), 'instruction with an implicit M0 operand in %s: %s' % (kern, i)
+            if re.search(r'\bm0\b', i):
+                assert re.match(r's_mov_b32 m0, s\d+$', i), 'M0 used other than as an LDS-DMA address in %s: %s' % (kern, i)
+            if i.startswith('global_load_lds'):
+                if re.match(r'global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]', i):
+                    raw[kern] = raw.get(kern, 0) + 1
+                    prev = [j for kk, j in ins[max(0, k - 3):k] if kk == kern and not j.startswith('s_nop')]
+                    assert prev and re.match(r's_mov_b32 m0, s\d+$', prev[-1]), ('raw LDS-DMA without its M0 write directly in front', kern, prev)
+                else:
+                    builtin[kern] = builtin.get(kern, 0) + 1
+        both = set(raw) & set(builtin)
+        assert not both, 'kernels that mix assembly and compiler-managed M0: %s' % sorted(both)
+        n_raw += sum(raw.values())
+        n_builtin += sum(builtin.values())
+    assert n_raw > 1000, (n_raw, n_builtin)

@@ -36,7 +36,9 @@ def _worker(rank, world, port, q):
     assert torch.allclose(_Opt.flat_grad, sum(both) / world, atol=1e-6) and busy.shape == (64, 64)
     batch ={'x': torch.arange(8).view(8, 1), 'name': 'n'}
     shard = parallel.shard_batch(batch, rank, world)
-    q.put((rank, [p.grad.clone() for p in params], flat.clone(), shard['x'].clone()))
+    # numpy arrays travel by value; torch tensors would travel as file descriptors the parent has to fetch from this
+    # process while it is still alive (a race with the exit below)
+    q.put((rank, [p.grad.numpy().copy() for p in params], flat.numpy().copy(), shard['x'].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,6 +52,7 @@ def test_allreduce_mean_world2():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    res = [(r, [torch.from_numpy(g) for g in gs], torch.from_numpy(fl), torch.from_numpy(sh)) for r, gs, fl, sh in res]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -97,8 +97,19 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
     masked crop sum_pix g * a cancels to ~1e-3 of sum |g * a| -- the activation plane is almost constant and the
     InstanceNorm gradient sums to zero -- so the 2^-16 product error is amplified; fp32 mode shows the schedule
     itself is exact)."""
-    from animateportrait_amd import networks as N, standins, ops
+    from animateportrait_amd import ops
     monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_FP32 if precision == 'fp32' else ops.PRECISION_BF16X3)
+    # Full width: the row-wise flip allowance below exempts up to 1 % of a tensor's rows.  A ReLU flip depends on the data; a
+    # wrong row (a mis-indexed tile, a dropped partial sum) does not.  The step therefore runs on TWO batches and no
+    # (tensor, row) may be exempt in both.
+    exempt = [_train_step_vs_oracle(dev, precision, width, nb, seed) for seed in ((5, 6) if width == 64 else (5,))]
+    if len(exempt) == 2:
+        both = exempt[0] & exempt[1]
+        assert not both, 'rows outside the no-flip bar on two different batches: %s' % sorted(both)[:10]
+
+
+def _train_step_vs_oracle(dev, precision, width, nb, batch_seed):
+    from animateportrait_amd import networks as N, standins, ops
     floor = 5e-5 if precision == 'fp32' else 2e-3
     floor_d = 5e-5 if precision == 'fp32' else 1e-2
     from animateportrait_amd.data.synthetic_dataset import make_train_batch
@@ -114,7 +125,7 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
         getattr(model, 'net' + name).load_state_dict(sdD[name], strict=True)
     model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
     model.aux['faceloss'] = N.FaceLoss(standins.StandinFaceNet().to(dev))
-    batch = make_train_batch(nb, seed=5)
+    batch = make_train_batch(nb, seed=batch_seed)
     batch['winB'] = torch.tensor([[32, 224, 32, 224], [-12, 200, 24, 230]])[-nb:]  # one window leaves the frame
     batch['winB2'] = torch.tensor([[30, 226, 28, 220], [40, 260, 50, 256]])[-nb:]
     batch['winA'] = torch.tensor([[36, 220, 30, 210], [20, 230, 20, 228]])[-nb:]
@@ -171,7 +182,7 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
         a, t = float(getattr(model, 'loss_' + name)), float(r64['dl'][name])
         assert abs(a - t) <= 1e-3 * abs(t) + 1e-6, (name, a, t)
     # ---------------- gradients, elementwise, every tensor
-    bad, all_ = [], []
+    bad, all_, exempt_rows = [], [], set()
     # Full width: 40 M activations sit in front of a (leaky) ReLU, so a handful of them are within rounding of zero
     # and take the other branch in ANY two evaluations (the oracle's own fp32 pass against its fp64 pass shows ~1e-2
     # L-inf on the generator for that reason; measured on D_A_coh: one flipped pixel in one 31x31 plane moves that
@@ -202,6 +213,7 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
             # no-flip bar except at most 1 % of them (>= 1), and those stay below the size of a few flips
             d = (mine.detach().cpu().double() - g64.double()).abs().flatten(1).amax(1) / g64.double().abs().max().clamp_min(1e-30)
             over = d > 3.0 * noise + fl + 0.5 * flip
+            exempt_rows.update((tag, k, int(r)) for r in over.nonzero().flatten().tolist())
             if int(over.sum()) > max(1, mine.shape[0] // 100) or float(d.max()) > 0.15 or me > 3.0 * mnoise + fl + 0.5 * flip:
                 bad.append((tag, k, e, noise, me, mnoise, int(over.sum())))
         elif e > 3.0 * noise + fl + flip or me > 3.0 * mnoise + fl + 0.5 * flip:
@@ -212,8 +224,9 @@ def test_train_step_losses_and_grads_vs_oracle(dev, precision, width, nb, monkey
         for k in sdD[n]:
             check(n, k, gD[n][k], r32['gD'][n][k], r64['gD'][n][k])
     if os.environ.get('APAMD_TEST_DUMP'):
-        open(os.environ['APAMD_TEST_DUMP'], 'a').write('%s %d %r\n' % (precision, width, all_)) 
+        open(os.environ['APAMD_TEST_DUMP'], 'a').write('%s %d seed %d %r\n' % (precision, width, batch_seed, all_))
     assert not bad, bad
+    return exempt_rows
 
 
 def test_optimize_parameters_runs_and_updates(dev):
