@@ -42,9 +42,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // PARTS_ = 1: plain bf16 arithmetic (AP_PRECISION_BF16, the training configurations): only the head parts are
 // staged -- half the LDS image and half the LDS-DMA traffic -- and a product is ONE MFMA (fp32 accumulation).  The
 // global operand layouts (XS tensors, packed weights) are the same; the kernel just skips the tail planes.
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2>
+// S2D3_ = 1 (K_ == 0, NTAP_ == 4): the space-to-depth form of a 3x3 stride-2 layer with an even chunk count per input phase --
+// the four phases' tap sets (4 / 2 / 2 / 1 taps) are compile-time: four chunk loops in sequence, see `stage`.
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2, int S2D3_ = 0>
 struct Bf3Cfg {
     static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_, PARTS = PARTS_;
+    static constexpr int S2D3 = S2D3_;
+    static_assert(!S2D3_ || (K_ == 0 && NTAP_ == 4), "compile-time s2d tap sets: the 4-tap run-time-tap family");
     static_assert(PARTS == 1 || PARTS == 2, "head only, or head + tail");
     static constexpr int TMAX = K > 0 ? (ROW ? K : K * K) : NTAP_;
     static_assert(TMAX >= 1, "K == 0 needs a tap count");
@@ -70,6 +74,8 @@ struct Bf3Cfg {
     // stage being one contiguous [weight image | activation image] block -- and, where a head-only stage is smaller
     // than the patches, in EPI_EXTRA bytes behind it
     static_assert(IH < 128 && IW < 256, "piece geometry is packed into 15 bits");
+    // two workgroups share a CU when two stage pairs fit its 160 KB of LDS: the kernel is then compiled for <= 256 registers
+    static constexpr int WG_PER_CU = (PARTS == 1 || 2 * (X_SLOTS + PARTS * TMAX * 2 * CO_TILE) * 16 + 1024 <= 80 * 1024) ? 2 : 1;
     static int wfloats(int ntaps) { return 2 * ntaps * 2 * CO_TILE * 4; }   // floats per packed (cout tile, chunk) weight block: always both parts
     static size_t lds_bytes(int ntaps) {                                                          // two stages (+ patches)
         const size_t stage = (size_t)(X_SLOTS + w_slots(ntaps)) * 16, epi = (size_t)EPI_FLOATS * 4;
@@ -103,7 +109,7 @@ __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0
 // Launch with min(#tiles, #CUs) workgroups of 256 threads; needs nchunks >= 2.
 // (head-only arithmetic halves the LDS image: two workgroups per CU, i.e. two waves per SIMD and <= 256 registers each)
 template <class C>
-__global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const ConvKParams p) {
+__global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKParams p) {
     constexpr int S = C::S, K = C::K, TMAX = C::TMAX, MT = C::MT, NT = C::NT, WCO = C::WCO;
     constexpr int IW = C::IW, PLANE = C::PLANE, NIT = C::NIT, CO_TILE = C::CO_TILE, XP = C::XP;
     constexpr int IWE = (IW + 1) / 2;      // even columns of a row of the LDS image (stride-2 layout, see pgeo)
@@ -477,29 +483,32 @@ __global__ __launch_bounds__(256, C::PARTS == 1 ? 2 : 1) void conv_bf16x3(const 
         // buffer per stage makes the register allocator shuttle all accumulators between VGPRs and AGPRs)
         using P0 = std::integral_constant<int, 0>;
         using P1 = std::integral_constant<int, 1>;
-        for (int c = 0; c < nchunks; c += 2) {
-            if constexpr (K == 0 && TMAX == 4) {
-                // space-to-depth 3x3 layer with an even chunk count per input phase: both stages of the pair belong to one
-                // phase, whose tap set (all four / left column / top row / corner) picks the straight-line copy
-                if (p.s2d_div > 0 && (p.s2d_div & 1) == 0) {
-                    const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)p.s2d_mask[c / p.s2d_div < 3 ? c / p.s2d_div : 3]);
-                    if (m == 0x5u) {
-                        stage(P0{}, std::integral_constant<unsigned, 0x5u>{}, c);
-                        stage(P1{}, std::integral_constant<unsigned, 0x5u>{}, c + 1);
-                        continue;
-                    } else if (m == 0x3u) {
-                        stage(P0{}, std::integral_constant<unsigned, 0x3u>{}, c);
-                        stage(P1{}, std::integral_constant<unsigned, 0x3u>{}, c + 1);
-                        continue;
-                    } else if (m == 0x1u) {
-                        stage(P0{}, std::integral_constant<unsigned, 0x1u>{}, c);
-                        stage(P1{}, std::integral_constant<unsigned, 0x1u>{}, c + 1);
-                        continue;
-                    }
-                }
+        if constexpr (C::S2D3) {
+            // chunks [r * s2d_div, (r + 1) * s2d_div) belong to input phase r = (ry, rx), whose taps inside the 2 x 2 window are
+            // all four / the left column / the top row / the corner: one straight-line chunk loop per phase (s2d_div is even)
+            const int cpp = p.s2d_div;
+            int c = 0;
+            for (; c < cpp; c += 2) {
+                stage(P0{}, std::integral_constant<unsigned, 0xFu>{}, c);
+                stage(P1{}, std::integral_constant<unsigned, 0xFu>{}, c + 1);
             }
-            stage(P0{}, std::integral_constant<unsigned, 0u>{}, c);
-            stage(P1{}, std::integral_constant<unsigned, 0u>{}, c + 1);
+            for (; c < 2 * cpp; c += 2) {
+                stage(P0{}, std::integral_constant<unsigned, 0x5u>{}, c);
+                stage(P1{}, std::integral_constant<unsigned, 0x5u>{}, c + 1);
+            }
+            for (; c < 3 * cpp; c += 2) {
+                stage(P0{}, std::integral_constant<unsigned, 0x3u>{}, c);
+                stage(P1{}, std::integral_constant<unsigned, 0x3u>{}, c + 1);
+            }
+            for (; c < nchunks; c += 2) {
+                stage(P0{}, std::integral_constant<unsigned, 0x1u>{}, c);
+                stage(P1{}, std::integral_constant<unsigned, 0x1u>{}, c + 1);
+            }
+        } else {
+            for (int c = 0; c < nchunks; c += 2) {
+                stage(P0{}, std::integral_constant<unsigned, 0u>{}, c);
+                stage(P1{}, std::integral_constant<unsigned, 0u>{}, c + 1);
+            }
         }
         constexpr int pl = 1;                                      // stage buffer of the last chunk: free now; the
                                                                    // next tile's chunk 0 sits in buffer 0 again

@@ -58,7 +58,10 @@ struct Bf3Kernel {
     const char* name;
     const void* fn1;             // plain bf16 arithmetic (AP_PRECISION_BF16): the same tile with head parts only
     size_t (*lds_bytes1)(int);
+    const void* fn_s2d3 = nullptr;    // the same tile with the compile-time tap sets of a space-to-depth 3x3 layer (Bf3Cfg::S2D3)
+    const void* fn1_s2d3 = nullptr;
     const void* kernel(int precision) const { return precision == AP_PRECISION_BF16 ? fn1 : fn; }
+    const void* kernel_s2d3(int precision) const { return precision == AP_PRECISION_BF16 ? fn1_s2d3 : fn_s2d3; }
     size_t lds(int precision, int ntaps) const { return precision == AP_PRECISION_BF16 ? lds_bytes1(ntaps) : lds_bytes(ntaps); }
 };
 template <int S, int K, int WCO, int MT, int WPX, int NT, int NTAP = 0, int ROW = 0>
@@ -95,6 +98,12 @@ static const std::vector<Bf3Kernel>& bf3_registry() {
         // launches whose tiles are short in K and heavy in output (fused phases, space-to-depth layers)
         bk2<1, 0, 1, 2, 4, 2, 4>("Bf3Cfg<1, 0, 1, 2, 4, 2, 4>"),
     };
+    static bool once = [&] {
+        v.back().fn_s2d3 = reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 0, 1, 2, 4, 2, 4, 0, 2, 1>>);
+        v.back().fn1_s2d3 = reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 0, 1, 2, 4, 2, 4, 0, 1, 1>>);
+        return true;
+    }();
+    (void)once;
     return v;
 }
 // the kernel of one launch: K == 0 kernels are instantiated per tap count
@@ -984,6 +993,13 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 if (p.ntaps > 4) return fail(AP_ERR_UNSUPPORTED, "phase with %d taps", p.ntaps);
                 for (int t = 0; t < p.ntaps; ++t)
                     p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
+            }
+            if (p.s2d_div > 0 && (p.s2d_div & 1) == 0 && p.nchunks == 4 * p.s2d_div && kern->kernel_s2d3(d->precision) &&
+                !env_int("APAMD_NO_S2D3_TAPSETS", 0)) {
+                // even chunk count per input phase: the instantiation with compile-time tap sets (no fragment reads for absent taps)
+                kfn = kern->kernel_s2d3(d->precision);
+                rc = ensure_lds_attr(kfn);
+                if (rc) return rc;
             }
             const size_t lds = kern->lds(d->precision, p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);

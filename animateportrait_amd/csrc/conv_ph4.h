@@ -48,6 +48,28 @@ struct Ph4Cfg {
     }
     static constexpr int tap_ph(int i) { return tap_code(i) >> 2; }
     static constexpr int tap_tp(int i) { return tap_code(i) & 3; }
+    // Position of existing tap i inside the union window (row * 4 + column).  Several (phase, tap) pairs multiply the SAME
+    // activation fragment -- K = 3: 9 pairs over 4 positions, K = 4: 16 pairs over 9 -- so the pairs are walked position by
+    // position and a position's fragments are read once: 34 instead of 54 ds_read_b128 per wave and chunk for K = 3 (68 / 96
+    // for K = 4).  With one weight fragment against NT = 2 pixel rows the kernel issued one LDS read per MFMA and two
+    // workgroups per CU kept the LDS port, not the matrix pipe, busy (30 % MFMA busy, profiles/r03zz_pmc_mfma.md).
+    static constexpr int pos_of(int i) { return (org(tap_ph(i) >> 1) + (tap_tp(i) >> 1)) * 4 + org(tap_ph(i) & 1) + (tap_tp(i) & 1); }
+    static constexpr int order(int j) {                           // the j-th pair in (position, staging index) order
+        int n = 0;
+        for (int pos = 0; pos < 16; ++pos)
+            for (int i = 0; i < NTAPS; ++i)
+                if (pos_of(i) == pos) {
+                    if (n == j) return i;
+                    ++n;
+                }
+        return 0;
+    }
+    static constexpr bool new_pos(int j) { return j == 0 || pos_of(order(j)) != pos_of(order(j - 1)); }
+    static constexpr int xbuf_of(int j) {                         // register buffer of the j-th pair's activation fragments
+        int b = 0;
+        for (int k = 1; k <= j; ++k) b += new_pos(k) ? 1 : 0;
+        return b & 1;
+    }
 };
 
 template <class C>
@@ -191,31 +213,36 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
             else if (has_next) issue(nxt, ngoff, 0, buf ^ 1);
             const uint4* Wc = smem + buf * STAGE + half * CO_TILE + l32;
             const uint4* Xc = smem + buf * STAGE + W_SLOTS + half * PLANE + (wpx * NT) * IW + l32;
-            // the taps that exist, in (phase, tap) order; the fragments of tap i + 1 are read while tap i multiplies
+            // the pairs that exist, position by position; the fragments of pair j + 1 are read while pair j multiplies
             bf16x8 ah[2], al[2], xh[2][NT], xl[2][NT];
-            auto fetch = [&](int i, int fb) __attribute__((always_inline)) {
-                const int ph = C::tap_ph(i), tp = C::tap_tp(i);
-                const int toff = (C::org(ph >> 1) + (tp >> 1)) * IW + C::org(ph & 1) + (tp & 1);
+            auto fetch_w = [&](int i, int fb) __attribute__((always_inline)) {
                 ah[fb] = *reinterpret_cast<const bf16x8*>(Wc + (i * PARTS) * 64);
                 if constexpr (PARTS == 2) al[fb] = *reinterpret_cast<const bf16x8*>(Wc + (i * PARTS + 1) * 64);
+            };
+            auto fetch_x = [&](int pos, int xb) __attribute__((always_inline)) {
+                const int toff = (pos >> 2) * IW + (pos & 3);
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
-                    xh[fb][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * IW);
-                    if constexpr (PARTS == 2) xl[fb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * IW);
+                    xh[xb][q] = *reinterpret_cast<const bf16x8*>(Xc + toff + q * IW);
+                    if constexpr (PARTS == 2) xl[xb][q] = *reinterpret_cast<const bf16x8*>(Xc + XP + toff + q * IW);
                 }
             };
-            fetch(0, 0);
+            fetch_w(C::order(0), 0);
+            fetch_x(C::pos_of(C::order(0)), 0);
 #pragma unroll
-            for (int i = 0; i < C::NTAPS; ++i) {
-                const int fb = i & 1, ph = C::tap_ph(i);
-                if (i + 1 < C::NTAPS) fetch(i + 1, fb ^ 1);
+            for (int j = 0; j < C::NTAPS; ++j) {
+                const int fb = j & 1, xb = C::xbuf_of(j), ph = C::tap_ph(C::order(j));
+                if (j + 1 < C::NTAPS) {
+                    fetch_w(C::order(j + 1), fb ^ 1);
+                    if (C::new_pos(j + 1)) fetch_x(C::pos_of(C::order(j + 1)), C::xbuf_of(j + 1));
+                }
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
                     if constexpr (PARTS == 2) {
-                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fb], xh[fb][q], acc[ph][q], 0, 0, 0);
-                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xl[fb][q], acc[ph][q], 0, 0, 0);
+                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[fb], xh[xb][q], acc[ph][q], 0, 0, 0);
+                        acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xl[xb][q], acc[ph][q], 0, 0, 0);
                     }
-                    acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xh[fb][q], acc[ph][q], 0, 0, 0);
+                    acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xh[xb][q], acc[ph][q], 0, 0, 0);
                 }
             }
         }

@@ -13,6 +13,8 @@
 // computed once per pixel and reused for CG channels.
 #include "common.h"
 #include <cstdlib>
+#include <cstring>
+#include <type_traits>
 
 namespace apamd {
 
@@ -42,6 +44,16 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int H, int W) {
     t.off[2] = (xin0 && yin1) ? y1 * W + x0 : -1;
     t.off[3] = (xin1 && yin1) ? y1 * W + x1 : -1;
     return t;
+}
+
+// north-west corner of a sample (the clamped floor make_taps uses): what the quad-cooperative gather addresses rows by
+__device__ __forceinline__ void tap_corner(float gx, float gy, int H, int W, int& x0, int& y0) {
+    float ix = ((gx + 1.f) * (float)W - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)H - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, -2.f), (float)W + 1.f);
+    iy = fminf(fmaxf(iy, -2.f), (float)H + 1.f);
+    x0 = (int)floorf(ix);
+    y0 = (int)floorf(iy);
 }
 
 struct Lerp { int i0, i1; float l0, l1; };
@@ -133,7 +145,12 @@ __device__ __forceinline__ void store_split_slot_s2d(uint4* xs, int n, int CG2, 
 // grid: (ceil(H*W/256), ceil(C/CG), N).  out (fp32 [N, 2C, H, W]) and xs (its split-bf16 copy) are both optional.
 // ACT (= x_act) is a template parameter: with a run-time activation the compiler evaluated ReLU AND LeakyReLU for every
 // one of the 64 gathered values and selected (12 vector instructions per value; the kernel is as much VALU- as memory-bound).
-template <int ACT, int WPE>
+// GATHER = 1 (tools / A-B runs only, APAMD_WARP_GATHER=quad): the "wavefront-shuffle" gather BASELINE.json names, in its cheapest
+// form for the channel-octet layout -- the four lanes of a quad fetch each other's 64-byte tap-row segments (two neighbouring
+// pixels x 8 channels) as ONE contiguous request per member and row, then transpose the 4 x 4 x 16-byte block inside the quad
+// with DPP quad_perm exchanges: a quarter of the L1 requests of the lane-per-pixel gather for ~200 more vector instructions per
+// pixel.  Measured slower (profiles/r04_warp_variants.md); kept so that the rejection has its measurement.
+template <int ACT, int WPE, int GATHER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
                                                           const float* __restrict__ x_rstd, int x_act,
                                                           const float* __restrict__ motion,
@@ -231,6 +248,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // a tap is the 32 contiguous bytes of the group's 8 channels: two 16-byte loads instead of 8 dword gathers
             // from 8 planes (the NCHW form is bound by the L1's line rate: every lane's tap is its own line per channel)
             const float4* og = reinterpret_cast<const float4*>(x + ((long long)n * (C >> 3) + by) * HW * 8);
+            if constexpr (GATHER == 1) {
+                const int qi = (int)threadIdx.x & 3;
+                auto dppi = [](int v, auto ctl) { return __builtin_amdgcn_update_dpp(0, v, decltype(ctl)::value, 0xf, 0xf, false); };
+                auto dppf = [&](float v, auto ctl) { return __int_as_float(dppi(__float_as_int(v), ctl)); };
+                using BC0 = std::integral_constant<int, 0x00>; using BC1 = std::integral_constant<int, 0x55>;
+                using BC2 = std::integral_constant<int, 0xAA>; using BC3 = std::integral_constant<int, 0xFF>;
+                using X1 = std::integral_constant<int, 0xB1>;  using X2 = std::integral_constant<int, 0x4E>;
+                // one tap row of one sampler: own segment = pixels (xb, xb + 1) of row y, 4 x 16 bytes; returns the segment's chunks
+                auto row_segment = [&](int y, int xb, float4 (&B)[4]) __attribute__((always_inline)) {
+                    const int base = (y * W + xb) * 2;
+                    const int b0 = dppi(base, BC0{}), b1 = dppi(base, BC1{}), b2 = dppi(base, BC2{}), b3 = dppi(base, BC3{});
+                    B[0] = og[b0 + qi]; B[1] = og[b1 + qi]; B[2] = og[b2 + qi]; B[3] = og[b3 + qi];     // round j: member j's segment
+                    // 4 x 4 transpose of 16-byte elements inside the quad: B[j] of lane i  ->  B[i] of lane j
+                    const bool o1 = qi & 1, o2 = qi & 2;
+                    auto xchg = [&](float4& lo, float4& hi, bool odd, auto ctl) __attribute__((always_inline)) {
+                        float4 snd = odd ? lo : hi, rcv;
+                        rcv.x = dppf(snd.x, ctl); rcv.y = dppf(snd.y, ctl); rcv.z = dppf(snd.z, ctl); rcv.w = dppf(snd.w, ctl);
+                        if (odd) lo = rcv; else hi = rcv;
+                    };
+                    xchg(B[0], B[1], o1, X1{}); xchg(B[2], B[3], o1, X1{});
+                    xchg(B[0], B[2], o2, X2{}); xchg(B[1], B[3], o2, X2{});
+                };
+                auto sampler = [&](float sgx, float sgy, float (&dst)[8][4]) __attribute__((always_inline)) {
+                    int x0, y0;
+                    tap_corner(sgx, sgy, H, W, x0, y0);
+                    const int xb = min(max(x0, 0), W - 2);
+                    const bool i0 = x0 - xb >= 1, i1 = x0 + 1 - xb >= 1;          // pixel of the segment that is the west / east tap
+#pragma unroll
+                    for (int rowk = 0; rowk < 2; ++rowk) {
+                        float4 B[4];
+                        row_segment(min(max(y0 + rowk, 0), H - 1), xb, B);
+                        const float4 w0 = i0 ? B[2] : B[0], w1 = i0 ? B[3] : B[1], e0 = i1 ? B[2] : B[0], e1 = i1 ? B[3] : B[1];
+                        const int kw = rowk * 2, ke = rowk * 2 + 1;
+                        dst[0][kw] = w0.x; dst[1][kw] = w0.y; dst[2][kw] = w0.z; dst[3][kw] = w0.w;
+                        dst[4][kw] = w1.x; dst[5][kw] = w1.y; dst[6][kw] = w1.z; dst[7][kw] = w1.w;
+                        dst[0][ke] = e0.x; dst[1][ke] = e0.y; dst[2][ke] = e0.z; dst[3][ke] = e0.w;
+                        dst[4][ke] = e1.x; dst[5][ke] = e1.y; dst[6][ke] = e1.z; dst[7][ke] = e1.w;
+                    }
+                };
+                sampler(gx, gy, a);          // (taps outside the frame carry weight 0, whatever in-range pixel stands in for them)
+                sampler(wgx, wgy, b);
+            } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float4 a0 = og[om[k] * 2], a1 = og[om[k] * 2 + 1];
@@ -239,6 +298,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
                 a[4][k] = a1.x; a[5][k] = a1.y; a[6][k] = a1.z; a[7][k] = a1.w;
                 b[0][k] = b0.x; b[1][k] = b0.y; b[2][k] = b0.z; b[3][k] = b0.w;
                 b[4][k] = b1.x; b[5][k] = b1.y; b[6][k] = b1.z; b[7][k] = b1.w;
+            }
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -840,6 +900,11 @@ extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const 
     // (WPE = 4: 112 registers, no spills.  A budget for 5 waves per SIMD -- 96 registers, a dozen spills -- measured 210 us
     // against 154 us at the 256^2 level.)
     auto* kern = x_act == 1 ? warp_concat_kernel<1, 4> : (x_act == 2 ? warp_concat_kernel<2, 4> : warp_concat_kernel<0, 4>);
+    // A/B switch for tools/warp_fwd_bench.py: the quad-cooperative gather (channel-octet inputs, whole 256-pixel blocks of
+    // 4-aligned rows, so that every quad is four live neighbours of one row)
+    static const bool quad = getenv("APAMD_WARP_GATHER") && !strcmp(getenv("APAMD_WARP_GATHER"), "quad");
+    if (quad && (flags & 2) && (W & 3) == 0 && W >= 4 && ((H * W) & 255) == 0)
+        kern = x_act == 1 ? warp_concat_kernel<1, 4, 1> : (x_act == 2 ? warp_concat_kernel<2, 4, 1> : warp_concat_kernel<0, 4, 1>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
                        flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, flags & 3, tw_shift);
     return check_launch("warp_concat_kernel");

@@ -310,8 +310,10 @@ class GeomGMIFWForeModel(BaseModel):
         cs = o.crop_size
         if self.aux['landmarks'] is not None:                                     # geometry loss :704-713
             mse = torch.nn.functional.mse_loss
-            lm1 = self.get_lm(self.fake_B, self.winB)
-            lm2 = self.get_lm(self.fake_B2, self.winB2)
+            # both frames through the frozen regressor as ONE 2B batch (eval-mode BatchNorm: samples are independent)
+            w4 = lambda w: torch.as_tensor(w).detach().to('cpu', torch.int32).reshape(-1, 4).expand(b, 4)     # noqa: E731
+            lm12 = self.get_lm(torch.cat([self.fake_B, self.fake_B2], 0), torch.cat([w4(self.winB), w4(self.winB2)], 0))
+            lm1, lm2 = lm12[:b], lm12[b:]
             t1, t2 = self.target_B_lm_68[:, :68], self.target_B2_lm_68[:, :68]
             if o.more_weight_for_lip != 2:
                 g = mse(lm1 / cs, t1 / cs) + mse(lm2 / cs, t2 / cs)

@@ -78,7 +78,7 @@ def a_conv():
 
 
 def a_wgrad():
-    return ops.wgrad(3, 1, 1, ops.PAD_REFLECT, ga, [xa], (256, 256, 3, 3))
+    return ops.wgrad(3, 1, 1, ops.PAD_REFLECT, Feat(ga), [xa], (256, 256, 3, 3))
 
 
 def a_synth(v):

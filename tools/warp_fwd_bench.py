@@ -43,6 +43,10 @@ def main():
         kw = dict(emit_xs=True, keep_fp32=False, s2d=level < 2 and "nos2d" not in sys.argv)
         t0 = timeit(lambda: ops.warp_concat(feat(False), mo, fl, mk, level, **kw))
         t1 = timeit(lambda: ops.warp_concat(feat(True), mo, fl, mk, level, **kw))
+        # checksum of the octet path's split output: equal between the default gather and APAMD_WARP_GATHER=quad
+        chk = ops.warp_concat(feat(True), mo, fl, mk, level, emit_xs=False).data
+        print('   octet-input fp32 output: sum %.10e  |sum| %.10e (gather: %s)' % (float(chk.double().sum()), float(chk.double().abs().sum()),
+                                                                                   __import__('os').environ.get('APAMD_WARP_GATHER', 'lane')))
         inb, outb = x.numel() * 4 / 1e6, 2 * x.numel() * 4 / 1e6
         print('warp level %d C=%3d %3dx%3d: NCHW %.1f us, octet %.1f us  (alg. %.0f MB in + %.0f MB out: %.2f TB/s)'
               % (level, c, h, h, t0, t1, inb, outb, (inb + outb) / t1))        # MB / us = TB/s
