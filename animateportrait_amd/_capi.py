@@ -35,6 +35,12 @@ class ApConvDesc(ctypes.Structure):
                 ('src', ApSrc * 3)]
 
 
+class ApFusedNorm(ctypes.Structure):
+    _fields_ = [('act', ctypes.c_int32), ('eps', ctypes.c_float), ('res_oct', ctypes.c_void_p), ('res_nchw', ctypes.c_void_p),
+                ('y_oct', ctypes.c_void_p), ('xs', ctypes.c_void_p), ('mean', ctypes.c_void_p), ('rstd', ctypes.c_void_p),
+                ('partials', ctypes.c_void_p), ('counters', ctypes.c_void_p)]
+
+
 class ApWeightView(ctypes.Structure):
     _fields_ = [('w', c_f32p), ('s_co', ctypes.c_int64), ('s_ci', ctypes.c_int64), ('s_ky', ctypes.c_int64),
                 ('s_kx', ctypes.c_int64), ('s2d_c', ctypes.c_int32), ('rows_c', ctypes.c_int32), ('ksrc', ctypes.c_int32),
@@ -55,7 +61,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 6      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 7      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -94,6 +100,9 @@ SIGNATURES = {
     'ap_instnorm_finalize_octet': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                                   ctypes.c_float, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_octet_ok': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_fused_norm_ok': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_fused_norm_counters': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_fwd_norm': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, ctypes.POINTER(ApFusedNorm), ctypes.c_void_p]),
     'ap_conv2d_fwd_octet': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),

@@ -44,8 +44,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // global operand layouts (XS tensors, packed weights) are the same; the kernel just skips the tail planes.
 // S2D3_ = 1 (K_ == 0, NTAP_ == 4): the space-to-depth form of a 3x3 stride-2 layer with an even chunk count per input phase --
 // the four phases' tap sets (4 / 2 / 2 / 1 taps) are compile-time: four chunk loops in sequence, see `stage`.
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2, int S2D3_ = 0>
+// FNORM_ = 1 (inference, stride-1 3x3 tall tile): InstanceNorm (+ activation, + residual) of the layer's OWN output inside the
+// epilogue -- the workgroups that hold the tiles of one (image, cout tile) exchange their per-channel sums through global
+// memory (two rounds: mean, then centred squares), so the raw fp32 output never travels to HBM and the norm_split pass
+// between two convolutions disappears.  See fused_norm_epilogue in the kernel and ap_conv2d_fwd_norm.
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2, int S2D3_ = 0, int FNORM_ = 0>
 struct Bf3Cfg {
+    static constexpr int FNORM = FNORM_;
+    static_assert(!FNORM_ || (K_ == 3 && S_ == 1 && WCO_ == 1 && PARTS_ == 2), "fused normalisation: the 3x3 stride-1 split-bf16 tile");
     static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_, PARTS = PARTS_;
     static constexpr int S2D3 = S2D3_;
     static_assert(!S2D3_ || (K_ == 0 && NTAP_ == 4), "compile-time s2d tap sets: the 4-tap run-time-tap family");
@@ -705,7 +711,177 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 }
             }
         };
-        if (AP_ABLATE(p, 8)) {
+        // ---- FNORM: out = act((conv - mean) * rstd) [+ residual], mean / rstd over the whole (n, c) plane.  The plane is
+        // spread over p.fn_group tiles held by as many workgroups that run CONCURRENTLY (the host checks that all tiles of a group
+        // fall into one round of one XCD's workgroups): each writes its per-channel partial to p.stats, bumps the group's
+        // counter and waits for the others -- once for the sums, once for the squares centred on the mean (the two-pass
+        // variance: no E[x^2] - E[x]^2 cancellation, whatever the plane's mean).  The accumulators stay in registers
+        // meanwhile; the result leaves as the split-bf16 copy the next convolution stages and / or as channel-octet fp32
+        // (the residual stream).  MFMA C/D layout: lane (half, l32) holds couts (r & 3) + 8 (r >> 2) + 4 half of pixel column l32,
+        // i.e. 4 consecutive channels per register quad: 8-byte bf16 half-slots, 16-byte fp32 octet halves.
+        auto fused_norm_epilogue = [&]() __attribute__((always_inline)) {
+            float* const epi = reinterpret_cast<float*>(smem + pl * STAGE);
+            float* const sred = epi;                          // [WPX][CO_TILE]
+            float* const smean = epi + C::WPX * CO_TILE;      // [CO_TILE]
+            float* const srstd = smean + CO_TILE;             // [CO_TILE]
+            const int n = cur.n, cot = cur.cot;
+            const int co_base = cot * CO_TILE;
+            const int tile_in_plane = cur.ty * p.tiles_x + cur.tx;
+            unsigned* const ctr = p.fn_counters + ((long long)n * p.co_tiles + cot) * 2;
+            const unsigned group = (unsigned)(p.tiles_y * p.tiles_x);
+            // 16 row sums over the 32 lanes of a half-wave as a transpose-reduce (see the octet epilogue)
+            auto fold = [&](float (&v)[16]) {
+                const bool b16 = l32 & 16, b8 = l32 & 8, b4 = l32 & 4, b2 = l32 & 2;
+                float w8[8], w4[4], w2[2];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) w8[i] = (b16 ? v[i + 8] : v[i]) + __shfl_xor(b16 ? v[i] : v[i + 8], 16, 64);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w4[i] = (b8 ? w8[i + 4] : w8[i]) + __shfl_xor(b8 ? w8[i] : w8[i + 4], 8, 64);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) w2[i] = (b4 ? w4[i + 2] : w4[i]) + __shfl_xor(b4 ? w4[i] : w4[i + 2], 4, 64);
+                const float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 2, 64);
+                return w1 + __shfl_xor(w1, 1, 64);
+            };
+            const int rr = ((l32 >> 4) & 1) * 8 + ((l32 >> 3) & 1) * 4 + ((l32 >> 2) & 1) * 2 + ((l32 >> 1) & 1);
+            const int my_row = (rr & 3) + 8 * (rr >> 2) + 4 * half;       // the row this lane's fold result belongs to
+            // one exchange round: per-lane values -> per-workgroup channel totals -> global partial `which` -> all tiles' total
+            auto exchange = [&](float (&part)[MT], int which, float (&total)[1]) __attribute__((always_inline)) {
+                if ((l32 & 1) == 0) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) sred[wpx * CO_TILE + m * 32 + my_row] = part[m];
+                }
+                __syncthreads();
+                if (tid < CO_TILE) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < C::WPX; ++w) t += sred[w * CO_TILE + tid];
+                    float* slot = p.stats + (((long long)n * p.Cout + co_base + tid) * p.stat_tiles + tile_in_plane) * 2 + which;
+                    __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __threadfence();
+                __syncthreads();
+                if (tid == 0) {
+                    __hip_atomic_fetch_add(ctr + which, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    // bounded wait (~0.2 s): if the group's other workgroups never arrive -- the device is shared with work that
+                    // keeps them from being scheduled -- give up, raise the launch's error flag and let the host fail loudly
+                    unsigned spins = 0;
+                    while (__hip_atomic_load(ctr + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < group) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1u << 22)) {
+                            __hip_atomic_store(p.fn_counters + (long long)p.N * p.co_tiles * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                    }
+                }
+                __syncthreads();
+                total[0] = 0.f;
+                if (tid < CO_TILE) {
+                    const float* slot = p.stats + ((long long)n * p.Cout + co_base + tid) * p.stat_tiles * 2 + which;
+                    double t = 0.0;                                        // fixed order over the tiles: every workgroup of the
+                    for (unsigned k = 0; k < group; ++k)                     // group computes the same bits
+                        t += (double)__hip_atomic_load(slot + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    total[0] = (float)(t * p.fn_inv_count);
+                }
+            };
+            // ---- round 0: mean
+            float part[MT], tot[1];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[m][0][r];
+#pragma unroll
+                    for (int q = 1; q < NT; ++q) v[r] += acc[m][q][r];
+                }
+                part[m] = fold(v);
+            }
+            exchange(part, 0, tot);
+            if (tid < CO_TILE) smean[tid] = tot[0];
+            __syncthreads();
+            // ---- round 1: variance from the squares centred on the mean
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float mu = smean[m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half];
+                    v[r] = 0.f;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const float dlt = acc[m][q][r] - mu;
+                        v[r] += dlt * dlt;
+                    }
+                }
+                part[m] = fold(v);
+            }
+            exchange(part, 1, tot);
+            if (tid < CO_TILE) {
+                const float rs = 1.0f / sqrtf(tot[0] + p.fn_eps);
+                srstd[tid] = rs;
+                if (tile_in_plane == 0) {                                  // the finished statistics, for whoever reads them later
+                    p.fn_mean[(long long)n * p.Cout + co_base + tid] = smean[tid];
+                    p.fn_rstd[(long long)n * p.Cout + co_base + tid] = rs;
+                }
+            }
+            __syncthreads();
+            // ---- output
+            const long long ohw = (long long)p.OH * p.OW;
+            const int CG = p.Cout >> 3;
+            const int ox = cur.tx * 32 + l32;
+            unsigned char* const xsb = reinterpret_cast<unsigned char*>(p.fn_xs);
+            if (xsb != nullptr && tile_in_plane == 0 && tid < 2 * (CO_TILE / 8)) {      // the all-zero slot that closes every plane
+                const int part_ = tid & 1, cg = (co_base >> 3) + (tid >> 1);
+                *reinterpret_cast<uint4*>(xsb + (((long long)(n * 2 + part_) * CG + cg) * (ohw + 1) + ohw) * 16) = make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = m * 32 + g * 8 + 4 * half;              // 4 consecutive channels of the tile
+                    const int co = co_base + cl;
+                    float mu[4], rs[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { mu[j] = smean[cl + j]; rs[j] = srstd[cl + j]; }
+                    const long long obase = ((long long)n * CG + (co >> 3)) * ohw;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) {
+                        const long long pix = (long long)(cur.ty * C::TH + wpx * NT + q) * p.OW + ox;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = (acc[m][q][g * 4 + j] - mu[j]) * rs[j];
+                            if (p.fn_act == 1) v[j] = fmaxf(v[j], 0.f);
+                            else if (p.fn_act == 2) v[j] = v[j] > 0.f ? v[j] : 0.2f * v[j];
+                        }
+                        if (p.fn_res_oct != nullptr) {
+                            const float4 rv = *reinterpret_cast<const float4*>(p.fn_res_oct + (obase + pix) * 8 + 4 * half);
+                            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+                        } else if (p.fn_res_nchw != nullptr) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += p.fn_res_nchw[((long long)n * p.Cout + co + j) * ohw + pix];
+                        }
+                        if (p.fn_y_oct != nullptr)
+                            *reinterpret_cast<float4*>(p.fn_y_oct + (obase + pix) * 8 + 4 * half) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (xsb != nullptr) {
+                            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                            bf16x4 hv, lv;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const __bf16 h = (__bf16)v[j];
+                                hv[j] = h;
+                                lv[j] = (__bf16)(v[j] - (float)h);
+                            }
+                            const long long slot = ((long long)(n * 2) * CG + (co >> 3)) * (ohw + 1) + pix;
+                            *reinterpret_cast<bf16x4*>(xsb + slot * 16 + 8 * half) = hv;
+                            *reinterpret_cast<bf16x4*>(xsb + (slot + (long long)CG * (ohw + 1)) * 16 + 8 * half) = lv;
+                        }
+                    }
+                }
+        };
+        if constexpr (C::FNORM) {
+            fused_norm_epilogue();
+        } else if (AP_ABLATE(p, 8)) {
             if (acc[0][0][0] == 123.456f) p.y[0] = 1.f;
         } else if (p.act == 0) {
             epilogue(std::integral_constant<int, 0>{});

@@ -803,7 +803,7 @@ int ap_conv2d_pack_run(const void* entries_dev, int32_t count, ap_stream_t strea
 }
 
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream, bool octet = false);
+                           float* stat_partials, ap_stream_t stream, bool octet = false, const ap_fused_norm* fn = nullptr);
 
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream) {
@@ -834,11 +834,70 @@ int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float*
     return conv2d_fwd_impl(d, nullptr, packed, bias, y, stat_partials, stream, true);
 }
 
+// ---- convolution + InstanceNorm in one launch (conv_bf16x3<..., FNORM>): which plans qualify, and is the launch deadlock-free?
+// The workgroups holding the tiles of one (image, cout tile) wait for each other inside the kernel, so they must all be running
+// at the same time: the persistent grid puts at most one workgroup on a CU and walks the tile list in rounds (workgroup b of an XCD
+// takes tiles base + idx, base + idx + step, ...); every group has to lie inside ONE round of ONE XCD's range.
+static const void* fnorm_kernel() { return reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 3, 1, 2, 4, 4, 0, 0, 2, 0, 1>>); }
+static bool fnorm_plan_ok(const ap_conv_desc* d, const Plan& pl) {
+    if (!pl.bf3 || pl.fused_phases || pl.ph4 || pl.launches.size() != 1 || d->transposed || d->precision != AP_PRECISION_BF16X3 ||
+        env_int("APAMD_NO_FUSED_NORM", 0))
+        return false;
+    const Bf3Kernel* k = pl.bk;
+    if (!k || k->S != 1 || k->K != 3 || k->ROW || k->TH != 16 || k->CO_TILE != 64) return false;
+    if ((d->Cout % 64) || (pl.Hout % 16) || (pl.Wout % 32)) return false;           // whole tiles only: every lane holds real pixels
+    const Launch& L = pl.launches[0];
+    const long long per_image = (long long)L.tiles_y * L.tiles_x * pl.co_tiles, ntl = d->N * per_image;
+    const long long G = ntl < num_cus() ? ntl : num_cus();
+    const long long nx = G < 8 ? G : 8, q = ntl / nx, r = ntl % nx;
+    for (int n = 0; n < d->N; ++n) {
+        // the tiles of image n are contiguous in the list ((n, ty, tx) major, cout tile fastest): all of them in one round
+        const long long t0 = n * per_image, t1 = t0 + per_image - 1;
+        auto where = [&](long long t, long long& xcd, long long& round) {
+            for (xcd = 0; xcd < nx; ++xcd) {
+                const long long base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q, cnt = q + (xcd < r ? 1 : 0);
+                if (t >= base && t < base + cnt) {
+                    const long long step = (G - xcd + nx - 1) / nx;
+                    round = (t - base) / step;
+                    return;
+                }
+            }
+        };
+        long long x0 = -1, r0 = -1, x1 = -2, r1 = -2;
+        where(t0, x0, r0);
+        where(t1, x1, r1);
+        if (x0 != x1 || r0 != r1) return false;
+    }
+    return true;
+}
+
+int32_t ap_conv2d_fused_norm_ok(const ap_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, pl)) return 0;
+    return fnorm_plan_ok(d, pl) ? 1 : 0;
+}
+
+int32_t ap_conv2d_fused_norm_counters(const ap_conv_desc* d) {
+    Plan pl;
+    int rc = make_plan(d, pl);
+    return rc ? rc : d->N * pl.co_tiles * 2 + 1;        // + the launch's error flag (set when a workgroup gave up waiting)
+}
+
+int ap_conv2d_fwd_norm(const ap_conv_desc* d, const float* packed, const ap_fused_norm* fn, ap_stream_t stream) {
+    if (!fn || !fn->partials || !fn->counters || !fn->mean || !fn->rstd) return fail(AP_ERR_INVALID, "conv2d_fwd_norm: null workspace");
+    if (!fn->xs && !fn->y_oct) return fail(AP_ERR_INVALID, "conv2d_fwd_norm: neither a split nor a channel-octet output");
+    if (fn->res_oct && fn->res_nchw) return fail(AP_ERR_INVALID, "conv2d_fwd_norm: two residuals");
+    if (fn->act < 0 || fn->act > 2) return fail(AP_ERR_INVALID, "conv2d_fwd_norm: act %d", fn->act);
+    return conv2d_fwd_impl(d, nullptr, packed, nullptr, fn->partials, fn->partials, stream, false, fn);
+}
+
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream, bool octet) {
+                           float* stat_partials, ap_stream_t stream, bool octet, const ap_fused_norm* fn) {
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc) return rc;
+    if (fn && !fnorm_plan_ok(d, pl))
+        return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_norm: this layer / shape cannot normalise in its epilogue (ap_conv2d_fused_norm_ok)");
     if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
     if (octet && !octet_plan_ok(d, pl))
         return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_octet: only single-launch split-bf16 layers of the run-time-tap / row kernel "
@@ -1000,6 +1059,14 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 kfn = kern->kernel_s2d3(d->precision);
                 rc = ensure_lds_attr(kfn);
                 if (rc) return rc;
+            }
+            if (fn) {
+                kfn = fnorm_kernel();
+                rc = ensure_lds_attr(kfn);
+                if (rc) return rc;
+                p.fn_act = fn->act; p.fn_eps = fn->eps; p.fn_inv_count = 1.0 / ((double)pl.Hout * pl.Wout);
+                p.fn_res_oct = fn->res_oct; p.fn_res_nchw = fn->res_nchw; p.fn_y_oct = fn->y_oct; p.fn_xs = fn->xs;
+                p.fn_mean = fn->mean; p.fn_rstd = fn->rstd; p.fn_counters = fn->counters;
             }
             const size_t lds = kern->lds(d->precision, p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);

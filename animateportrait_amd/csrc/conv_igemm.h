@@ -77,6 +77,17 @@ struct ConvKParams {
     unsigned ph_tapmask[4];   // bit t: tap t of the 2 x 2 window exists in that phase (split-bf16 run-time-tap kernels skip
                               // the MFMAs of the others -- their weights are zero: 7 of the 16 taps of a fused 3x3 up-convolution)
     int o_octet;              // conv_bf16x3 run-time-tap / row families: output as y[n][Cout/8][OH*OW][8] (ap_conv2d_fwd_octet)
+    // conv_bf16x3<..., FNORM = 1> only (ap_conv2d_fwd_norm): InstanceNorm of the layer's own output inside the epilogue
+    int fn_act;               // activation after the normalisation
+    float fn_eps;
+    double fn_inv_count;      // 1 / (OH * OW)
+    const float* fn_res_oct;  // residual added after the normalisation: channel-octet fp32, or
+    const float* fn_res_nchw; // ... plain NCHW fp32, or neither
+    float* fn_y_oct;          // fp32 result, channel-octet layout (or null)
+    void* fn_xs;              // split-bf16 copy of the result (or null)
+    float* fn_mean;           // [N * Cout] finished statistics
+    float* fn_rstd;
+    unsigned* fn_counters;    // [N * co_tiles * 2], zero at launch: arrivals of a group's workgroups (stats is the exchange buffer)
 };
 
 // K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a

@@ -11,6 +11,8 @@
 // Operands are the ones conv_bf16x3 uses: XS split tensors, and the packed phase blocks [phase][cout tile][chunk] of
 // [part][tap][k-group][32 couts] 16-byte slots written by pack_bf16x3_kernel for a 32-cout tile.
 #pragma once
+#include <utility>
+
 #include "conv_bf16x3.h"
 
 namespace apamd {
@@ -71,6 +73,15 @@ struct Ph4Cfg {
         return b & 1;
     }
 };
+
+template <class F, int... J>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, J...>) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
@@ -229,12 +240,14 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
             };
             fetch_w(C::order(0), 0);
             fetch_x(C::pos_of(C::order(0)), 0);
-#pragma unroll
-            for (int j = 0; j < C::NTAPS; ++j) {
-                const int fb = j & 1, xb = C::xbuf_of(j), ph = C::tap_ph(C::order(j));
-                if (j + 1 < C::NTAPS) {
+            // (the pair index is a TEMPLATE constant: with a run-time loop variable the constexpr tables above are evaluated at run
+            // time for K = 4 -- 16 pairs -- and the fragment buffers, indexed by their results, move to scratch memory)
+            static_for<C::NTAPS>([&](auto jt) __attribute__((always_inline)) {
+                constexpr int j = decltype(jt)::value;
+                constexpr int fb = j & 1, xb = C::xbuf_of(j), ph = C::tap_ph(C::order(j));
+                if constexpr (j + 1 < C::NTAPS) {
                     fetch_w(C::order(j + 1), fb ^ 1);
-                    if (C::new_pos(j + 1)) fetch_x(C::pos_of(C::order(j + 1)), C::xbuf_of(j + 1));
+                    if constexpr (C::new_pos(j + 1)) fetch_x(C::pos_of(C::order(j + 1)), C::xbuf_of(j + 1));
                 }
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
@@ -244,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
                     }
                     acc[ph][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[fb], xh[xb][q], acc[ph][q], 0, 0, 0);
                 }
-            }
+            });
         }
         // ---- epilogue.  MFMA C/D layout: pixel column = lane & 31, cout row = (r & 3) + 8 (r >> 2) + 4 half.  The phases
         // (phy, 0) and (phy, 1) are the even / odd output columns of one row: one 8-byte store per lane.

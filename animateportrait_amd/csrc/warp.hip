@@ -902,7 +902,8 @@ extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const 
     auto* kern = x_act == 1 ? warp_concat_kernel<1, 4> : (x_act == 2 ? warp_concat_kernel<2, 4> : warp_concat_kernel<0, 4>);
     // A/B switch for tools/warp_fwd_bench.py: the quad-cooperative gather (channel-octet inputs, whole 256-pixel blocks of
     // 4-aligned rows, so that every quad is four live neighbours of one row)
-    static const bool quad = getenv("APAMD_WARP_GATHER") && !strcmp(getenv("APAMD_WARP_GATHER"), "quad");
+    const char* gather = getenv("APAMD_WARP_GATHER");           // read per call: tests flip it inside one process
+    const bool quad = gather && !strcmp(gather, "quad");
     if (quad && (flags & 2) && (W & 3) == 0 && W >= 4 && ((H * W) & 255) == 0)
         kern = x_act == 1 ? warp_concat_kernel<1, 4, 1> : (x_act == 2 ? warp_concat_kernel<2, 4, 1> : warp_concat_kernel<0, 4, 1>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,

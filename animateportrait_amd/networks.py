@@ -85,6 +85,18 @@ class ConvLayer(nn.Module):
             return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act, out_octet=out_octet)
         return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act, out_octet=out_octet)
 
+    def fused_norm_ok(self, srcs):
+        """Inference only: can this layer produce act(IN(conv)) [+ residual] in one launch (ops.conv2d_norm)?"""
+        if not isinstance(srcs, (list, tuple)):
+            srcs = [srcs]
+        return (not ops.stem_rows_eligible(self.spec) and not ops.s2d_eligible(self.spec, *srcs[0].data.shape[2:])
+                and ops.fused_norm_ok(self.spec, srcs))
+
+    def run_norm(self, srcs, act=ACT_NONE, residual=None, want_oct=False, want_xs=True):
+        if not isinstance(srcs, (list, tuple)):
+            srcs = [srcs]
+        return ops.conv2d_norm(self.spec, srcs, self.packed(), act=act, residual=residual, want_oct=want_oct, want_xs=want_xs)
+
     def s2d_spec(self):
         if self._s2d_spec is None:
             self._s2d_spec = ops.s2d_spec(self.spec)
@@ -116,8 +128,14 @@ class ResnetBlock(nn.Module):
                                _5=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT))
 
     def run(self, x, tape=None):
-        y = conv_forward(tape, self.conv_block['1'], x, norm_act=ACT_RELU)
-        y = conv_forward(tape, self.conv_block['5'], y, norm_act=ACT_NONE)
+        c1, c5 = self.conv_block['1'], self.conv_block['5']
+        if tape is None and not x.virtual and c1.fused_norm_ok(x):
+            # inference: each convolution normalises its own output in the epilogue (ap_conv2d_fwd_norm) -- no raw fp32 output,
+            # no norm_split pass; the block's result lives as the split copy (next convolution) + channel-octet fp32 (next residual)
+            y = c1.run_norm(x, act=ACT_RELU)
+            return c5.run_norm(y, act=ACT_NONE, residual=x, want_oct=True)
+        y = conv_forward(tape, c1, x, norm_act=ACT_RELU)
+        y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
         return materialize_forward(tape, y, residual=x)
 
 
@@ -131,9 +149,15 @@ class ResnetBlock2(nn.Module):
         self.shortcut = _seq(_0=ConvLayer(segs, dim_out, 3, 1, 1, PAD_ZERO))
 
     def run(self, srcs, tape=None):
-        y = conv_forward(tape, self.conv_block['1'], srcs, norm_act=ACT_RELU)
-        y = conv_forward(tape, self.conv_block['5'], y, norm_act=ACT_NONE)
-        s = conv_forward(tape, self.shortcut['0'], srcs, norm_act=ACT_NONE)
+        c1, c5, sc = self.conv_block['1'], self.conv_block['5'], self.shortcut['0']
+        if tape is None and c1.fused_norm_ok(srcs):
+            # inference (see ResnetBlock.run): the shortcut's IN(conv) is the residual of the main branch's second convolution
+            s = sc.run_norm(srcs, act=ACT_NONE, want_oct=True, want_xs=False)
+            y = c1.run_norm(srcs, act=ACT_RELU)
+            return c5.run_norm(y, act=ACT_NONE, residual=s, want_oct=True)
+        y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU)
+        y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
+        s = conv_forward(tape, sc, srcs, norm_act=ACT_NONE)
         return materialize_forward(tape, y, residual=s)
 
 

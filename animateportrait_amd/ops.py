@@ -556,6 +556,89 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
     return Feat(y, act=out_act, pending=(partial, tiles))
 
 
+_FNORM_FLAGS = []          # counter buffers of recent ap_conv2d_fwd_norm launches (their last element is the kernel's error flag)
+
+
+def fused_norm_ok(spec, srcs):
+    """Can this layer, at this shape, normalise its own output in the epilogue (ap_conv2d_fwd_norm)?"""
+    if spec.precision != PRECISION_BF16X3 or DEFAULT_PRECISION != PRECISION_BF16X3:
+        return False
+    n, _, h, w = srcs[0].data.shape
+    d = spec.desc(n, h, w, None, ACT_NONE)
+    d.presplit = 1
+    return C.lib().ap_conv2d_fused_norm_ok(ctypes.byref(d)) == 1
+
+
+def conv2d_norm(spec, srcs, packed, act=ACT_NONE, residual=None, want_oct=False, want_xs=True):
+    """``act(InstanceNorm(conv(srcs))) [+ residual]`` in ONE launch (inference: nothing is kept for a backward pass).
+    residual: a materialised Feat -- its channel-octet fp32 copy (``.oct``) when it has one, else its NCHW tensor.
+    Returns a materialised Feat that exists as its split-bf16 copy (``.xs``, want_xs) and / or as channel-octet fp32 (``.oct``,
+    want_oct: what the next block's residual add reads); its NCHW tensor is never written."""
+    x0 = srcs[0].data
+    n, _, h, w = x0.shape
+    d = spec.desc(n, h, w, None, ACT_NONE)
+    d.presplit = 1
+    for i, f in enumerate(srcs):
+        d.src[i].data = presplit(f, spec.precision).data_ptr()
+        d.src[i].mean = d.src[i].rstd = None
+        d.src[i].act = ACT_NONE
+    lib = C.lib()
+    ho, wo = ctypes.c_int32(), ctypes.c_int32()
+    C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
+    dev, cout, hw = x0.device, spec.cout, ho.value * wo.value
+    tiles = C.check(lib.ap_conv2d_stat_tiles(ctypes.byref(d)), 'conv2d_stat_tiles')
+    nctr = C.check(lib.ap_conv2d_fused_norm_counters(ctypes.byref(d)), 'fused_norm_counters')
+    fn = C.ApFusedNorm()
+    fn.act, fn.eps = act, EPS
+    partial = torch.empty((n * cout, tiles, 2), dtype=torch.float32, device=dev)
+    counters = torch.zeros(nctr, dtype=torch.int32, device=dev)
+    mean = torch.empty(n * cout, dtype=torch.float32, device=dev)
+    rstd = torch.empty_like(mean)
+    fn.partials, fn.counters, fn.mean, fn.rstd = partial.data_ptr(), counters.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    if residual is not None:
+        if residual.virtual:
+            raise RuntimeError('conv2d_norm: the residual must be a materialised feature')
+        if residual.oct is not None:
+            fn.res_oct = residual.oct.data_ptr()
+        else:
+            if residual.is_split_only:
+                raise RuntimeError('conv2d_norm: the residual exists only as its split-bf16 copy')
+            _require_device(residual.data, 'residual')
+            fn.res_nchw = residual.data.data_ptr()
+    y_oct = xs = None
+    if want_oct:
+        y_oct = torch.empty((n, cout // 8, hw, 8), dtype=torch.float32, device=dev)
+        fn.y_oct = y_oct.data_ptr()
+    if want_xs:
+        nbytes = C.check(lib.ap_split_prepass_bytes(n, cout, ho.value, wo.value), 'split_prepass_bytes')
+        xs = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        fn.xs = xs.data_ptr()
+    if PROFILER is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.check(lib.ap_conv2d_fwd_norm(ctypes.byref(d), _ptr(packed), ctypes.byref(fn), _stream()), 'conv2d_fwd_norm')
+    if PROFILER is not None:
+        e1.record()
+        macs = sum(spec.cin_segments) * spec.k ** 2
+        PROFILER.records.append(('Bf3Cfg<1, 3, 1, 2, 4, 4> +IN', 2.0 * n * hw * cout * macs, e0, e1))
+    _FNORM_FLAGS.append(counters)
+    if len(_FNORM_FLAGS) > 256:
+        check_fused_norm()
+    res = Feat(torch.empty(1, dtype=torch.float32, device=dev).expand((n, cout, ho.value, wo.value)))
+    res.xs, res.oct = xs, y_oct
+    return res
+
+
+def check_fused_norm():
+    """Deferred check of the error flags of the ap_conv2d_fwd_norm launches since the last call (one device read): a set flag
+    means a workgroup gave up waiting for its group -- the device was shared with other work -- and the results are invalid."""
+    global _FNORM_FLAGS
+    flags, _FNORM_FLAGS = _FNORM_FLAGS, []
+    if flags and int(torch.stack([c[-1] for c in flags]).max()) != 0:
+        raise RuntimeError('animateportrait_amd: a convolution with in-kernel InstanceNorm timed out waiting for its peer workgroups '
+                           '(is the GPU shared with another process or stream?); set APAMD_NO_FUSED_NORM=1')
+
+
 def _conv2d_view(spec, srcs, packed, out, view):
     """ap_conv2d_fwd_view: the split-bf16 convolution ``spec`` of ``srcs`` into a window of ``out`` (no bias, no
     activation, no statistics)."""

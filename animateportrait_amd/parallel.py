@@ -57,14 +57,22 @@ def shard_batch(batch, rank, world):
     return out
 
 
-# RCCL runs its kernels on its own HIP stream.  Measured on MI355X (tools/conc_warp.py): while one
-# of this library's large matrix kernels (LDS-DMA + MFMA, > 256 registers per lane) shares compute units with a kernel
-# of ANOTHER stream, that kernel can read wrong data in lanes 48-63 -- the library's own warp kernel did, in 60 % of its
-# launches, and a compiler-only reproducer exists (tools/xcdvis/aggr_lib.hip).  A collective must therefore never be
-# in flight next to the backward pass: the compute stream is ordered behind every collective at once (``work.wait()``
-# is a stream wait on RCCL, no host block), which costs ~1-2 ms of exposed exchange per train step on one node.
-# APAMD_OVERLAP_COLLECTIVES=1 restores the overlapped form (collectives travel under the following backward passes).
+# RCCL runs its kernels on its own HIP stream.  Measured on MI355X (round 3: tools/conc_warp.py; round 4: tools/hazard/run_hazard.py,
+# profiles/r04_cohazard.md): while one of this library's LDS-DMA + MFMA kernels shares compute units with a kernel of ANOTHER
+# stream, that kernel can compute wrong values -- the library's own warp kernel did in 50-80 % of its launches.  The trigger on the
+# aggressor's side is narrowed down (VALU select traffic between the LDS-DMA pieces and the MFMAs; not the register count, not M0),
+# the mechanism is not understood; a ring-reduce-shaped victim (RCCL's reduceCopy shape) stayed bit-exact over 1000 launches
+# beside conv_bf16x3 and wgrad_bf16x3, but RCCL's real kernels were never tested (no multi-GPU node).  So by DEFAULT a collective is
+# never in flight next to the backward pass: the compute stream is ordered behind every collective at once (``work.wait()`` is
+# a stream wait on RCCL, no host block), ~1-2 ms of exposed exchange per train step on one node.  APAMD_OVERLAP_COLLECTIVES=1
+# restores the overlapped form and says what it risks.
 OVERLAP_COLLECTIVES = os.environ.get('APAMD_OVERLAP_COLLECTIVES', '0') == '1'
+if OVERLAP_COLLECTIVES:
+    import warnings
+    warnings.warn('APAMD_OVERLAP_COLLECTIVES=1: gradient all-reduces will run NEXT TO the backward kernels.  Kernels sharing compute '
+                  'units with this library\'s matrix kernels were measured to compute wrong values on MI355X (profiles/r04_cohazard.md); '
+                  'an RCCL-shaped kernel was clean in that test, RCCL itself is untested.  Compare replica fingerprints '
+                  '(parallel.assert_replicas_in_sync) and a serial run before trusting results.', RuntimeWarning, stacklevel=2)
 
 
 def allreduce_flat_(flat, async_op=False):

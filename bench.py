@@ -476,6 +476,8 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     tab = {k.replace(' ', ''): v for k, v in json.load(open(tpath)).items()}
     ent = tab.get(dname.replace(' ', ''))
+    if ent is None and os.environ.get('APAMD_BENCH_NO_TRAFFIC'):
+        ent = {'hbm_bytes_per_launch': None, 'round': 'NONE (APAMD_BENCH_NO_TRAFFIC: development run before the PMC passes exist)'}
     if ent is None:
         raise SystemExit('bench.py: profiles/hbm_traffic.json has no HBM-traffic entry for the dominant kernel %s -- rerun '
                          'tools/round_profiles.sh and commit the PMC passes' % dname)

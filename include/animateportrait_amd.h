@@ -101,10 +101,38 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 6
+#define AP_ABI_VERSION 7
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
+
+/* ---- convolution + InstanceNorm2d (+ ReLU, + residual add) in ONE launch (round 4, inference):
+ * replaces  x + IN(conv(pad(.)))  /  relu(IN(conv(pad(.))))  of ResnetBlock / ResnetBlock2
+ * (Module2/models/networks.py:2329-2360, :2389-2420) for the wide stride-1 3x3 layers.  The workgroups that hold the tiles of
+ * one (image, 64-channel tile) exchange per-channel sums through `partials` and `counters` (two rounds: mean, then squares
+ * centred on it) while the accumulators stay in registers, so neither the raw convolution output nor a separate
+ * normalisation pass touches HBM.  Outputs: the split-bf16 copy `xs` the next convolution stages (ap_split_prepass layout)
+ * and / or the fp32 values in the channel-octet layout `y_oct` [N][Cout/8][OH*OW][8] (the residual stream between blocks).
+ * Only where ap_conv2d_fused_norm_ok(d) == 1 (split-bf16 arithmetic, 3x3 stride 1, whole 64 x 16 x 32 tiles, and a tile
+ * list whose per-image groups fall into one round of the persistent grid -- the waiting workgroups must all be resident:
+ * keep the device free of other work, as the single-stream rule above says).  `counters` (ap_conv2d_fused_norm_counters
+ * uint32) must be ZERO at launch; its LAST element is an error flag the kernel sets (and the results are then invalid) when a
+ * workgroup waited ~0.2 s in vain for its group; `partials` has ap_conv2d_stat_tiles(d) float pairs per (n, c). */
+typedef struct ap_fused_norm {
+    int32_t act;            /* AP_ACT_NONE / RELU / LRELU applied after the normalisation */
+    float eps;              /* nn.InstanceNorm2d eps (1e-5) */
+    const float* res_oct;   /* residual added after normalisation + activation: channel-octet fp32, or */
+    const float* res_nchw;  /* ... NCHW fp32, or neither (both NULL) */
+    float* y_oct;           /* fp32 result, channel-octet layout, or NULL */
+    void* xs;               /* split-bf16 copy of the result, or NULL */
+    float* mean;            /* [N * Cout] finished statistics (written) */
+    float* rstd;
+    float* partials;        /* [N * Cout][stat_tiles][2] exchange buffer */
+    uint32_t* counters;     /* zero-initialised by the caller */
+} ap_fused_norm;
+int32_t ap_conv2d_fused_norm_ok(const ap_conv_desc* d);
+int32_t ap_conv2d_fused_norm_counters(const ap_conv_desc* d);
+int ap_conv2d_fwd_norm(const ap_conv_desc* d, const float* packed, const ap_fused_norm* fn, ap_stream_t stream);
 
 /* ---- convolution: nn.Conv2d / nn.ConvTranspose2d (+ fused pad, bias, act, IN statistics)
  * replaces F.conv2d / F.conv_transpose2d / F.pad(reflect) launched by

@@ -215,7 +215,7 @@ def test_generator_ngf64_headline_tolerance(dev, golden):
     assert torch.equal(y1, y[:1]), 'samples must be independent (InstanceNorm): B=1 == B=2[0] bitwise'
 
 
-@pytest.mark.parametrize('batch', [16, 5])
+@pytest.mark.parametrize('batch', [16, 8, 5])
 def test_generator_ngf64_at_the_reported_batch(dev, batch):
     """The configuration bench.py reports (BASELINE configs[1]: ngf=64, B=16, seed 1234) against the oracle's forward of the
     SAME batch (networks.py:1315-1340 restated in oracle/generator.py; a few seconds of host time): at B=16 the plan takes
@@ -241,6 +241,10 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch):
     err = linf(y, ref)
     print('ngf64 B=%d generator L-inf vs oracle: %.3e; kernels: %s' % (batch, err, sorted(names)))
     assert 'Bf3Cfg<1,3,1,2,4,4>' in names, names      # the 16-row tile of the 3x3 stride-1 kernel
+    # B = 16 / 8: every image's tiles fall into one round of the persistent grid, so the trunk convolutions normalise in their
+    # epilogues (ap_conv2d_fwd_norm); B = 5 does not qualify and takes the conv + norm_split path
+    assert ('Bf3Cfg<1,3,1,2,4,4>+IN' in names) == (batch in (16, 8)), names
+    ops.check_fused_norm()
     assert err < 1e-3
     # the batch is sample-independent: the first frame alone gives the same bits
     with torch.no_grad():
@@ -1154,3 +1158,80 @@ def test_warp_reads_channel_octet_input(dev, level):
     fo = ops.Feat(torch.empty(1, device=dev).expand(x3.shape))
     fo.oct = x3.view(1, 1, 8, 9).permute(0, 1, 3, 2).contiguous()
     assert torch.equal(ops.warp_concat(ops.Feat(x3), mo3, fl3, mk3, 0).data, ops.warp_concat(fo, mo3, fl3, mk3, 0).data)
+
+
+def test_warp_quad_gather_variant_is_bitwise_the_lane_gather(dev, monkeypatch):
+    """APAMD_WARP_GATHER=quad (the quad-cooperative "wavefront-shuffle" gather BASELINE.json names; rejected on its measurement,
+    profiles/r04_warp_variants.md, and kept for A/B runs) fetches the same taps through shared 64-byte requests and a DPP
+    transpose: the same values in the same order of operations, so the output equals the default kernel's bit for bit --
+    also with samples that leave the frame on every side."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.synthetic import make_generator_inputs
+    d = make_generator_inputs(2, seed=21)
+    mo, fl, mk = d['motion'].clone(), d['flow'].clone(), d['ifmask']
+    mo[0, :40] += 0.9                     # a band sampled far outside on the right / bottom
+    mo[1, :, :30] -= 1.3                  # ... and on the left / top
+    fl[:, :, 100:140] *= 30.0
+    mo, fl, mk = mo.to(dev), fl.to(dev), mk.to(dev)
+    g = torch.Generator().manual_seed(4)
+    for level, c in ((0, 32), (1, 64), (2, 128)):
+        h = 256 >> level
+        x = torch.randn(2, c, h, h, generator=g)
+        m = x.mean((2, 3)).reshape(-1).to(dev)
+        r = (1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)).to(dev)
+        xo = x.view(2, c // 8, 8, h * h).permute(0, 1, 3, 2).contiguous().to(dev)
+
+        def run():
+            f = ops.Feat(torch.empty(1, device=dev).expand(x.shape), m, r, ops.ACT_RELU)
+            f.oct = xo
+            return ops.warp_concat(f, mo, fl, mk, level).data
+        monkeypatch.delenv('APAMD_WARP_GATHER', raising=False)
+        lane = run()
+        nchw = ops.warp_concat(ops.Feat(x.to(dev), m, r, ops.ACT_RELU), mo, fl, mk, level).data
+        monkeypatch.setenv('APAMD_WARP_GATHER', 'quad')
+        quad = run()
+        monkeypatch.delenv('APAMD_WARP_GATHER', raising=False)
+        assert torch.equal(lane, nchw), level
+        assert torch.equal(quad, lane), (level, float((quad - lane).abs().max()))
+
+
+@pytest.mark.parametrize('n,act,res', [(8, 1, None), (8, 0, 'oct'), (16, 0, 'nchw'), (8, 2, 'oct')])
+def test_conv_with_in_kernel_instancenorm(dev, n, act, res):
+    """ap_conv2d_fwd_norm (the convolution normalises its own output: per-channel sums exchanged between the workgroups of a
+    plane, two rounds) against conv + InstanceNorm + activation + residual in fp64: both output forms -- the split-bf16 copy and
+    the channel-octet fp32 tensor -- and the finished statistics; and against the unfused product path."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    g = torch.Generator().manual_seed(10 * n + act)
+    layer = ConvLayer([256], 256, 3, 1, 1, ops.PAD_REFLECT).to(dev)
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(layer.weight.shape, generator=g) * 0.02)
+    x = torch.randn(n, 256, 64, 64, generator=g)
+    x[:, :7] += 40.0                                   # planes with a large mean: the two-pass variance must not care
+    src = ops.Feat(x.to(dev))
+    assert layer.fused_norm_ok(src)
+    r = torch.randn(n, 256, 64, 64, generator=g) if res else None
+    rf = None
+    if res == 'nchw':
+        rf = ops.Feat(r.to(dev))
+    elif res == 'oct':
+        rf = ops.Feat(torch.empty(1, device=dev).expand(r.shape))
+        rf.oct = r.view(n, 32, 8, 4096).permute(0, 1, 3, 2).contiguous().to(dev)
+    out = layer.run_norm(src, act=act, residual=rf, want_oct=True, want_xs=True)
+    ops.check_fused_norm()
+    with torch.no_grad():
+        y = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode='reflect'), layer.weight.detach().cpu().double())
+        ref = F.instance_norm(y)
+        ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.2) if act == 2 else ref)
+        if r is not None:
+            ref = ref + r.double()
+    got = out.oct.cpu().view(n, 32, 4096, 8).permute(0, 1, 3, 2).reshape(n, 256, 64, 64)
+    scale = float(ref.abs().max())
+    assert linf(got, ref) < 1e-4 * scale, linf(got, ref)           # split-bf16 products: ~2e-5 relative
+    val, zeros = _decode_split(out.xs, n, 256, 64, 64)
+    assert float(zeros.abs().max()) == 0.0
+    assert float(((val.cpu() - got).abs() - got.abs() * 2.0 ** -16).max()) <= 1e-30
+    # the unfused product path computes the same thing with one more pass
+    raw = layer.run(src, norm_act=act)
+    old = ops.materialize(raw, residual=ops.Feat(r.to(dev)) if r is not None else None)
+    assert linf(got, old.data) < 2e-5 * scale

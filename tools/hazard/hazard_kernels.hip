@@ -10,6 +10,8 @@
 //     4  baseline with amdgpu_waves_per_eu(1, 1) spelled out   5  LDS-DMA only (no MFMA)          6  MFMA only (no LDS-DMA)
 //     7  baseline with s_nop 7 after every LDS-DMA piece       8 / 9 / 10  arch VGPRs padded to 136 / 144 / 152 (264 / 272 / 280 in all:
 //        round 3's failing reproducer had 136 + 128)
+//     11 baseline + a dynamically indexed private array (round 3's failing flags 15)   12 the same with the raw-assembly LDS-DMA
+//        (flags 7)   13 = 11 padded to 160 arch VGPRs
 // VICTIMS
 //   hz_reduce_launch: a ring-reduce-shaped kernel (RCCL's reduceCopy inner loop: few workgroups, each thread streams 16-byte
 //     loads from two buffers, adds, stores; 4 loads in flight) -- stands for RCCL's all-reduce kernels beside the backward pass.
@@ -38,10 +40,19 @@ __device__ __forceinline__ void aggr_body(const unsigned char* __restrict__ src,
     if (V == 8) asm volatile("" ::: "v135");
     if (V == 9) asm volatile("" ::: "v143");
     if (V == 10) asm volatile("" ::: "v151");
+    if (V == 13) asm volatile("" ::: "v159");
+    int priv[5];                                 // variants 11-13: round 3's failing reproducer carried a dynamically indexed array
+    if (V >= 11)
+        for (int i = 0; i < 5; ++i) priv[i] = tid * (i + 1);
     for (int it = 0; it < iters; ++it) {
         if (V != 6) {
             for (int p = 0; p < pieces; ++p) {
                 const unsigned voff = (unsigned)((p * 4 + wave) * 64 + lane) * 16u;
+                if (V == 12) {          // the product's raw-assembly LDS-DMA (scalar base, M0 written by hand)
+                    const unsigned lds_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + (unsigned)((p * 4 + wave) * 64) * 16u;
+                    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(base), "s"(lds_addr) : "memory", "m0");
+                    continue;
+                }
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + voff),
                                                  (__attribute__((address_space(3))) void*)(smem + (size_t)((p * 4 + wave) * 64) * 16), 16, 0, 0);
                 if (V == 7) asm volatile("s_nop 7");
@@ -60,9 +71,11 @@ __device__ __forceinline__ void aggr_body(const unsigned char* __restrict__ src,
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((i & 1) ? a1 : a0, (i & 2) ? b1 : b0, acc[i], 0, 0, 0);
             }
         }
+        if (V >= 11) priv[(it + pieces) % 5] += it;
         if (V != 6) __syncthreads();
     }
     float s = 0.f;
+    if (V >= 11) s += (float)priv[pieces % 5];
     for (int i = 0; i < 8; ++i)
         for (int r = 0; r < 16; ++r) s += acc[i][r];
     if (s == 123.456f) sink[0] = s;
@@ -83,6 +96,9 @@ AGGR_KERNEL(7, __launch_bounds__(256, 1))
 AGGR_KERNEL(8, __launch_bounds__(256, 1))
 AGGR_KERNEL(9, __launch_bounds__(256, 1))
 AGGR_KERNEL(10, __launch_bounds__(256, 1))
+AGGR_KERNEL(11, __launch_bounds__(256, 1))
+AGGR_KERNEL(12, __launch_bounds__(256, 1))
+AGGR_KERNEL(13, __launch_bounds__(256, 1))
 
 extern "C" int hz_aggr_launch(int variant, const void* src, void* sink, int iters, void* stream) {
     const int pieces = 24, nblk = 256;
@@ -90,7 +106,7 @@ extern "C" int hz_aggr_launch(int variant, const void* src, void* sink, int iter
 #define CASE(V) case V: { auto k = aggr##V; hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(k, dim3(nblk), dim3(256), lds, (hipStream_t)stream, (const unsigned char*)src, (float*)sink, iters, pieces); break; }
     switch (variant) {
-        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+        CASE(0) CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10) CASE(11) CASE(12) CASE(13)
         default: return -1;
     }
     return (int)hipGetLastError();
@@ -103,7 +119,8 @@ extern "C" int hz_aggr_registers(int variant, int* arch_plus_acc) {
         case 0: f = (const void*)aggr0; break; case 1: f = (const void*)aggr1; break; case 2: f = (const void*)aggr2; break;
         case 3: f = (const void*)aggr3; break; case 4: f = (const void*)aggr4; break; case 5: f = (const void*)aggr5; break;
         case 6: f = (const void*)aggr6; break; case 7: f = (const void*)aggr7; break; case 8: f = (const void*)aggr8; break;
-        case 9: f = (const void*)aggr9; break; case 10: f = (const void*)aggr10; break; default: return -1;
+        case 9: f = (const void*)aggr9; break; case 10: f = (const void*)aggr10; break; case 11: f = (const void*)aggr11; break;
+        case 12: f = (const void*)aggr12; break; case 13: f = (const void*)aggr13; break; default: return -1;
     }
     if (hipFuncGetAttributes(&a, f) != hipSuccess) return -2;
     *arch_plus_acc = a.numRegs;

@@ -90,11 +90,19 @@ def a_synth(v):
 
 AGGR = {'conv3x3 (conv_bf16x3)': a_conv, 'wgrad3x3 (wgrad_bf16x3)': a_wgrad, 'gemm_bf16 (rocBLAS, control)': lambda: ma @ ma}
 for v, note in ((0, '128 + 128 regs'), (8, '136 + 128'), (9, '144 + 128'), (10, '152 + 128'), (1, '160 + 128'), (2, '192 + 128'),
-                (4, 'waves_per_eu(1,1)'), (5, 'LDS-DMA only'), (6, 'MFMA only'), (7, 's_nop 7 after each DMA piece')):
+                (4, 'waves_per_eu(1,1)'), (5, 'LDS-DMA only'), (6, 'MFMA only'), (7, 's_nop 7 after each DMA piece'),
+                (11, 'builtin DMA + MFMA + indexed private array'), (12, 'raw-asm DMA + MFMA + indexed private array'),
+                (13, 'as 11, 160 arch VGPRs')):
     n = ctypes.c_int(0)
     HZ.hz_aggr_registers(v, ctypes.byref(n))
     AGGR['synth:%d (%s; numRegs %d)' % (v, note, n.value)] = a_synth(v)
 
+only_v = os.environ.get('VICTIMS')
+only_a = os.environ.get('AGGRESSORS')
+if only_v:
+    VICTIMS = {k: v for k, v in VICTIMS.items() if k in only_v.split(',')}
+if only_a:
+    AGGR = {k: v for k, v in AGGR.items() if any(k.startswith(a) for a in only_a.split(','))}
 rows = []
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
 for vn, vf in VICTIMS.items():
