@@ -712,17 +712,18 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
             }
         };
         // ---- FNORM: out = act((conv - mean) * rstd) [+ residual], mean / rstd over the whole (n, c) plane.  The plane is
-        // spread over p.fn_group tiles held by as many workgroups that run CONCURRENTLY (the host checks that all tiles of a group
-        // fall into one round of one XCD's workgroups): each writes its per-channel partial to p.stats, bumps the group's
-        // counter and waits for the others -- once for the sums, once for the squares centred on the mean (the two-pass
-        // variance: no E[x^2] - E[x]^2 cancellation, whatever the plane's mean).  The accumulators stay in registers
-        // meanwhile; the result leaves as the split-bf16 copy the next convolution stages and / or as channel-octet fp32
-        // (the residual stream).  MFMA C/D layout: lane (half, l32) holds couts (r & 3) + 8 (r >> 2) + 4 half of pixel column l32,
-        // i.e. 4 consecutive channels per register quad: 8-byte bf16 half-slots, 16-byte fp32 octet halves.
+        // spread over tiles_y * tiles_x tiles held by as many workgroups that run CONCURRENTLY (the host checks that all tiles of
+        // an image fall into one round of one XCD's workgroups).  Each workgroup forms its tile's own per-channel mean and centred
+        // sum of squares from the accumulators (two passes over registers, no cancellation), publishes the pair in p.stats, bumps
+        // the group's counter and waits for the others -- ONE exchange; the pairs combine by Chan's formula
+        // (M2 = sum M2_i + n_i sum (mean_i - mean)^2), in fixed order and fp64, to the same bits in every workgroup.  The
+        // accumulators stay in registers meanwhile; the result leaves as the split-bf16 copy the next convolution stages and / or
+        // as channel-octet fp32 (the residual stream).  MFMA C/D layout: lane (half, l32) holds couts (r & 3) + 8 (r >> 2) + 4 half
+        // of pixel column l32, i.e. 4 consecutive channels per register quad: 8-byte bf16 half-slots, 16-byte fp32 octet halves.
         auto fused_norm_epilogue = [&]() __attribute__((always_inline)) {
             float* const epi = reinterpret_cast<float*>(smem + pl * STAGE);
-            float* const sred = epi;                          // [WPX][CO_TILE]
-            float* const smean = epi + C::WPX * CO_TILE;      // [CO_TILE]
+            float* const sred = epi;                          // [WPX][CO_TILE] row sums; later the [group <= 32][CO_TILE] float2 table
+            float* const smean = epi + 32 * CO_TILE * 2;      // [CO_TILE]
             float* const srstd = smean + CO_TILE;             // [CO_TILE]
             const int n = cur.n, cot = cur.cot;
             const int co_base = cot * CO_TILE;
@@ -744,47 +745,24 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
             };
             const int rr = ((l32 >> 4) & 1) * 8 + ((l32 >> 3) & 1) * 4 + ((l32 >> 2) & 1) * 2 + ((l32 >> 1) & 1);
             const int my_row = (rr & 3) + 8 * (rr >> 2) + 4 * half;       // the row this lane's fold result belongs to
-            // one exchange round: per-lane values -> per-workgroup channel totals -> global partial `which` -> all tiles' total
-            auto exchange = [&](float (&part)[MT], int which, float (&total)[1]) __attribute__((always_inline)) {
+            // per-workgroup channel totals of per-lane values (fold over the half-wave's pixels, then over the four waves' rows)
+            auto wg_total = [&](float (&part)[MT]) -> float {
                 if ((l32 & 1) == 0) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m) sred[wpx * CO_TILE + m * 32 + my_row] = part[m];
                 }
                 __syncthreads();
+                float t = 0.f;
                 if (tid < CO_TILE) {
-                    float t = 0.f;
 #pragma unroll
                     for (int w = 0; w < C::WPX; ++w) t += sred[w * CO_TILE + tid];
-                    float* slot = p.stats + (((long long)n * p.Cout + co_base + tid) * p.stat_tiles + tile_in_plane) * 2 + which;
-                    __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __threadfence();
-                __syncthreads();
-                if (tid == 0) {
-                    __hip_atomic_fetch_add(ctr + which, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    // bounded wait (~0.2 s): if the group's other workgroups never arrive -- the device is shared with work that
-                    // keeps them from being scheduled -- give up, raise the launch's error flag and let the host fail loudly
-                    unsigned spins = 0;
-                    while (__hip_atomic_load(ctr + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < group) {
-                        __builtin_amdgcn_s_sleep(2);
-                        if (++spins > (1u << 22)) {
-                            __hip_atomic_store(p.fn_counters + (long long)p.N * p.co_tiles * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                    }
                 }
                 __syncthreads();
-                total[0] = 0.f;
-                if (tid < CO_TILE) {
-                    const float* slot = p.stats + ((long long)n * p.Cout + co_base + tid) * p.stat_tiles * 2 + which;
-                    double t = 0.0;                                        // fixed order over the tiles: every workgroup of the
-                    for (unsigned k = 0; k < group; ++k)                     // group computes the same bits
-                        t += (double)__hip_atomic_load(slot + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    total[0] = (float)(t * p.fn_inv_count);
-                }
+                return t;                                                   // valid in threads tid < CO_TILE
             };
-            // ---- round 0: mean
-            float part[MT], tot[1];
+            constexpr float kTilePix = (float)(C::TH * 32);
+            // ---- this tile's own mean and centred sum of squares (no exchange yet: Chan's pairwise form combines them later)
+            float part[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float v[16];
@@ -796,10 +774,9 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 }
                 part[m] = fold(v);
             }
-            exchange(part, 0, tot);
-            if (tid < CO_TILE) smean[tid] = tot[0];
+            const float lsum = wg_total(part);
+            if (tid < CO_TILE) smean[tid] = lsum * (1.0f / kTilePix);
             __syncthreads();
-            // ---- round 1: variance from the squares centred on the mean
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float v[16];
@@ -815,17 +792,65 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 }
                 part[m] = fold(v);
             }
-            exchange(part, 1, tot);
-            if (tid < CO_TILE) {
-                const float rs = 1.0f / sqrtf(tot[0] + p.fn_eps);
-                srstd[tid] = rs;
-                if (tile_in_plane == 0) {                                  // the finished statistics, for whoever reads them later
-                    p.fn_mean[(long long)n * p.Cout + co_base + tid] = smean[tid];
-                    p.fn_rstd[(long long)n * p.Cout + co_base + tid] = rs;
+            const float lm2 = wg_total(part);
+            // ---- ONE exchange: (mean_i, M2_i) of every tile of the plane
+            // Memory ordering WITHOUT agent-scope fences: on gfx950 a release / acquire at agent scope writes back / invalidates the
+            // XCD's whole L2 (buffer_wbl2 / buffer_inv sc1) -- with megabytes of dirty output lines in it that cost ~35 us per
+            // tile (first version: 292 us per launch).  Instead every access to the exchange data is itself an agent-scope
+            // RELAXED atomic (sc1: performed at the coherence point, no cache maintenance), and program order is kept by waiting
+            // for the stores' acknowledgement (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the counter bump.
+            float* const slots = p.stats;
+            if (tid < CO_TILE && !(p.fn_debug & 4)) {
+                float* sl = slots + (((long long)n * p.Cout + co_base + tid) * p.stat_tiles + tile_in_plane) * 2;
+                __hip_atomic_store(sl, smean[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sl + 1, lm2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0 && !(p.fn_debug & 5)) {
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // bounded wait (~0.2 s): if the group's other workgroups never arrive -- the device is shared with work that
+                // keeps them from being scheduled -- give up, raise the launch's error flag and let the host fail loudly
+                unsigned spins = 0;
+                while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < group) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > (1u << 22)) {
+                        __hip_atomic_store(p.fn_counters + (long long)p.N * p.co_tiles * 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
                 }
             }
             __syncthreads();
+            // all 256 threads fetch the group's pairs (thread = channel x tile residue, loads independent), LDS table, then
+            // channel threads combine in fixed tile order and fp64: every workgroup of the group computes the same bits
+            float2* const tab = reinterpret_cast<float2*>(sred);              // [group <= 32][CO_TILE]
+            {
+                const int c = tid & (CO_TILE - 1);
+                const float* src = slots + ((long long)n * p.Cout + co_base + c) * p.stat_tiles * 2;
+                for (unsigned k = tid / CO_TILE; k < group && !(p.fn_debug & 4); k += 256 / CO_TILE)
+                    tab[k * CO_TILE + c] = make_float2(__hip_atomic_load(src + 2 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                       __hip_atomic_load(src + 2 * k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            __syncthreads();
+            if (tid < CO_TILE) {
+                double ms = 0.0, m2 = 0.0;
+                for (unsigned k = 0; k < group; ++k) ms += (double)tab[k * CO_TILE + tid].x;
+                const double mean = ms / (double)group;
+                for (unsigned k = 0; k < group; ++k) {
+                    const double dm = (double)tab[k * CO_TILE + tid].x - mean;
+                    m2 += (double)tab[k * CO_TILE + tid].y + (double)kTilePix * dm * dm;
+                }
+                const float mu = (float)mean, rs = (float)(1.0 / sqrt(m2 * p.fn_inv_count + (double)p.fn_eps));
+                if (tile_in_plane == 0) {                                  // the finished statistics, for whoever reads them later
+                    p.fn_mean[(long long)n * p.Cout + co_base + tid] = mu;
+                    p.fn_rstd[(long long)n * p.Cout + co_base + tid] = rs;
+                }
+                smean[tid] = mu;      // (smean / srstd lie behind the table)
+                srstd[tid] = rs;
+            }
+            __syncthreads();
             // ---- output
+            const float slope = p.fn_act == 1 ? 0.f : (p.fn_act == 2 ? 0.2f : 1.f);
             const long long ohw = (long long)p.OH * p.OW;
             const int CG = p.Cout >> 3;
             const int ox = cur.tx * 32 + l32;
@@ -851,8 +876,11 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             v[j] = (acc[m][q][g * 4 + j] - mu[j]) * rs[j];
-                            if (p.fn_act == 1) v[j] = fmaxf(v[j], 0.f);
-                            else if (p.fn_act == 2) v[j] = v[j] > 0.f ? v[j] : 0.2f * v[j];
+                            v[j] = fmaxf(v[j], slope * v[j]);              // slope 1 / 0 / 0.2: none / ReLU / LeakyReLU, branch-free
+                        }
+                        if (p.fn_debug & 2) {                                  // (timing experiments only: no loads / stores)
+                            if (v[0] == 123.456f) p.fn_mean[0] = v[1] + v[2] + v[3];
+                            continue;
                         }
                         if (p.fn_res_oct != nullptr) {
                             const float4 rv = *reinterpret_cast<const float4*>(p.fn_res_oct + (obase + pix) * 8 + 4 * half);

@@ -846,6 +846,7 @@ static bool fnorm_plan_ok(const ap_conv_desc* d, const Plan& pl) {
     const Bf3Kernel* k = pl.bk;
     if (!k || k->S != 1 || k->K != 3 || k->ROW || k->TH != 16 || k->CO_TILE != 64) return false;
     if ((d->Cout % 64) || (pl.Hout % 16) || (pl.Wout % 32)) return false;           // whole tiles only: every lane holds real pixels
+    if ((pl.Hout / 16) * (pl.Wout / 32) > 32) return false;                          // the exchange table holds 32 tiles per plane
     const Launch& L = pl.launches[0];
     const long long per_image = (long long)L.tiles_y * L.tiles_x * pl.co_tiles, ntl = d->N * per_image;
     const long long G = ntl < num_cus() ? ntl : num_cus();
@@ -1067,6 +1068,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 p.fn_act = fn->act; p.fn_eps = fn->eps; p.fn_inv_count = 1.0 / ((double)pl.Hout * pl.Wout);
                 p.fn_res_oct = fn->res_oct; p.fn_res_nchw = fn->res_nchw; p.fn_y_oct = fn->y_oct; p.fn_xs = fn->xs;
                 p.fn_mean = fn->mean; p.fn_rstd = fn->rstd; p.fn_counters = fn->counters;
+                p.fn_debug = env_int("APAMD_FNORM_DEBUG", 0);
             }
             const size_t lds = kern->lds(d->precision, p.ntaps);
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);

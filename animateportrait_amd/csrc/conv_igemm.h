@@ -87,6 +87,7 @@ struct ConvKParams {
     void* fn_xs;              // split-bf16 copy of the result (or null)
     float* fn_mean;           // [N * Cout] finished statistics
     float* fn_rstd;
+    int fn_debug;             // APAMD_FNORM_DEBUG (timing experiments, WRONG results): 1 no waiting for the group, 2 no output traffic
     unsigned* fn_counters;    // [N * co_tiles * 2], zero at launch: arrivals of a group's workgroups (stats is the exchange buffer)
 };
 

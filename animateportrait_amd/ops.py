@@ -559,9 +559,30 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
 _FNORM_FLAGS = []          # counter buffers of recent ap_conv2d_fwd_norm launches (their last element is the kernel's error flag)
 
 
+_COUNTER_POOL = {}         # device -> [zero-initialised int32 pool, next free offset]
+
+
+def _zero_counters(n, device):
+    """n zero int32 counters for one ap_conv2d_fwd_norm launch, cut from a pool that is zeroed once (a torch.zeros per launch was
+    a 5 us fill kernel in front of each of the 21 trunk convolutions).  A slice is used by exactly one launch."""
+    pool = _COUNTER_POOL.get(device)
+    if pool is None or pool[1] + n > pool[0].numel():
+        pool = _COUNTER_POOL[device] = [torch.zeros(1 << 20, dtype=torch.int32, device=device), 0]
+    out = pool[0][pool[1]:pool[1] + n]
+    pool[1] += (n + 3) & ~3
+    return out
+
+
+# Convolution + InstanceNorm in one launch (ap_conv2d_fwd_norm) for the trunk of the generators in inference: OPT-IN.  Measured at
+# B = 16 it removes the 18 norm_split passes of a forward (0.6 ms) and gives the time back in its own epilogue -- every workgroup
+# bursts its (larger) output at the same moment and the matrix pipe idles meanwhile: 2131 vs 2110 and 2207 vs 2204 frames/s on two
+# boxes (DESIGN.md section 3.11).  Not worth a kernel that waits on its peers by default.
+FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
+
+
 def fused_norm_ok(spec, srcs):
-    """Can this layer, at this shape, normalise its own output in the epilogue (ap_conv2d_fwd_norm)?"""
-    if spec.precision != PRECISION_BF16X3 or DEFAULT_PRECISION != PRECISION_BF16X3:
+    """Can this layer, at this shape, normalise its own output in the epilogue (ap_conv2d_fwd_norm), and is that form switched on?"""
+    if not FUSED_NORM or spec.precision != PRECISION_BF16X3 or DEFAULT_PRECISION != PRECISION_BF16X3:
         return False
     n, _, h, w = srcs[0].data.shape
     d = spec.desc(n, h, w, None, ACT_NONE)
@@ -591,7 +612,7 @@ def conv2d_norm(spec, srcs, packed, act=ACT_NONE, residual=None, want_oct=False,
     fn = C.ApFusedNorm()
     fn.act, fn.eps = act, EPS
     partial = torch.empty((n * cout, tiles, 2), dtype=torch.float32, device=dev)
-    counters = torch.zeros(nctr, dtype=torch.int32, device=dev)
+    counters = _zero_counters(nctr, dev)
     mean = torch.empty(n * cout, dtype=torch.float32, device=dev)
     rstd = torch.empty_like(mean)
     fn.partials, fn.counters, fn.mean, fn.rstd = partial.data_ptr(), counters.data_ptr(), mean.data_ptr(), rstd.data_ptr()

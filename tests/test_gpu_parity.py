@@ -215,8 +215,8 @@ def test_generator_ngf64_headline_tolerance(dev, golden):
     assert torch.equal(y1, y[:1]), 'samples must be independent (InstanceNorm): B=1 == B=2[0] bitwise'
 
 
-@pytest.mark.parametrize('batch', [16, 8, 5])
-def test_generator_ngf64_at_the_reported_batch(dev, batch):
+@pytest.mark.parametrize('batch,fused', [(16, False), (16, True), (8, True), (5, True), (5, False)])
+def test_generator_ngf64_at_the_reported_batch(dev, batch, fused, monkeypatch):
     """The configuration bench.py reports (BASELINE configs[1]: ngf=64, B=16, seed 1234) against the oracle's forward of the
     SAME batch (networks.py:1315-1340 restated in oracle/generator.py; a few seconds of host time): at B=16 the plan takes
     the 16-row 3x3 tile -- the kernel that is most of the timed step and that the B=2 golden test never runs -- and B=5 gives
@@ -224,6 +224,7 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch):
     from animateportrait_amd import networks as N, ops
     from animateportrait_amd.synthetic import make_generator_inputs, generator_args
     from oracle import generator as og
+    monkeypatch.setattr(ops, 'FUSED_NORM', fused)           # the opt-in convolution + InstanceNorm launches (APAMD_FUSED_NORM=1)
     args = generator_args(make_generator_inputs(batch, seed=1234))
     sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=1234)
     G = N.define_G(3, 1, 64, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
@@ -243,7 +244,7 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch):
     assert 'Bf3Cfg<1,3,1,2,4,4>' in names, names      # the 16-row tile of the 3x3 stride-1 kernel
     # B = 16 / 8: every image's tiles fall into one round of the persistent grid, so the trunk convolutions normalise in their
     # epilogues (ap_conv2d_fwd_norm); B = 5 does not qualify and takes the conv + norm_split path
-    assert ('Bf3Cfg<1,3,1,2,4,4>+IN' in names) == (batch in (16, 8)), names
+    assert ('Bf3Cfg<1,3,1,2,4,4>+IN' in names) == (fused and batch in (16, 8)), names
     ops.check_fused_norm()
     assert err < 1e-3
     # the batch is sample-independent: the first frame alone gives the same bits
@@ -1196,12 +1197,13 @@ def test_warp_quad_gather_variant_is_bitwise_the_lane_gather(dev, monkeypatch):
 
 
 @pytest.mark.parametrize('n,act,res', [(8, 1, None), (8, 0, 'oct'), (16, 0, 'nchw'), (8, 2, 'oct')])
-def test_conv_with_in_kernel_instancenorm(dev, n, act, res):
+def test_conv_with_in_kernel_instancenorm(dev, n, act, res, monkeypatch):
     """ap_conv2d_fwd_norm (the convolution normalises its own output: per-channel sums exchanged between the workgroups of a
     plane, two rounds) against conv + InstanceNorm + activation + residual in fp64: both output forms -- the split-bf16 copy and
     the channel-octet fp32 tensor -- and the finished statistics; and against the unfused product path."""
     from animateportrait_amd import ops
     from animateportrait_amd.networks import ConvLayer
+    monkeypatch.setattr(ops, 'FUSED_NORM', True)
     g = torch.Generator().manual_seed(10 * n + act)
     layer = ConvLayer([256], 256, 3, 1, 1, ops.PAD_REFLECT).to(dev)
     with torch.no_grad():
