@@ -219,6 +219,9 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
         unsigned xdst, wdst;       // LDS byte addresses of the stage's activation / weight images (this wave's lane 0)
         bool real;                 // false: the padding chunk of an odd count -- its weights are zero, the activation
                                    // image keeps whatever finite data the buffer held two stages ago
+        unsigned wmask;            // S2D3: taps of the chunk's input phase -- the weight pieces of the others are not staged (the
+                                   // stage never reads them).  With the fragment reads of absent taps gone the kernel is bound by
+                                   // the LDS-DMA (1.15 MB per CU against 27 k MFMA cycles, profiles/r04p_pmc_*): 19 % fewer bytes
     };
     constexpr int NWP = (W_SLOTS / 64 + 3) / 4, NPIECE = PARTS * NIT + NWP;
     unsigned woff[NWP];            // byte offset of this lane's slot in weight piece j
@@ -237,6 +240,8 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
         d.xdst = lds0 + (buf * STAGE + W_SLOTS + wave * 64) * 16;
         d.wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
         d.wdst = lds0 + (buf * STAGE + wave * 64) * 16;
+        d.wmask = 0xFu;
+        if constexpr (C::S2D3) d.wmask = p.s2d_mask[chunk_ / p.s2d_div < 3 ? chunk_ / p.s2d_div : 3];
         return d;
     };
     auto dma_piece = [&](const DmaCtx& d, const int (&goff)[NIT], int j) __attribute__((always_inline)) {
@@ -247,7 +252,10 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 glds16_sv(part ? d.xl : d.xh, (unsigned)goff[k], d.xdst + (part * XP + k * 256) * 16);
         } else {
             const int jj = j - PARTS * NIT;
-            if (jj * 4 + 3 < W_SLOTS / 64 || jj * 4 + wave < W_SLOTS / 64) glds16_sv(d.wsrc, woff[jj], d.wdst + jj * 4096);
+            bool want = jj * 4 + 3 < W_SLOTS / 64 || jj * 4 + wave < W_SLOTS / 64;
+            // weight image [part][tap][k-group][CO_TILE] in 64-slot pieces: piece -> tap (wave-uniform)
+            if constexpr (C::S2D3) want = want && ((d.wmask >> (((jj * 4 + wave) % (T * 2 * CO_TILE / 64)) / (2 * CO_TILE / 64))) & 1u);
+            if (want) glds16_sv(d.wsrc, woff[jj], d.wdst + jj * 4096);
         }
     };
     auto issue = [&](const Bf3Tile& t, const int (&goff)[NIT], int chunk_, int buf) __attribute__((always_inline)) {

@@ -128,6 +128,53 @@ def oracle_reference_output(sd):
         return og.generator_forward(sd, *generator_args(make_generator_inputs(BATCH, seed=1234)), div=3, disp=3)
 
 
+def train_parity_gate(dev):
+    """The train-step composition against the golden made by the REFERENCE's own model class (tests/golden/train_step.npz:
+    GeomGMIFWForeModel.forward / backward_G / backward_D_* at ngf = ndf = 8, b = 1, README flags, stand-in aux nets): one
+    product step on the golden's batch and weights, all sixteen loss values within 1 % (+ the reference's own fp32-vs-fp64
+    distance) -- the fp32 TPS solve is the only ill-conditioned piece.  The train legs are not reported if this fails."""
+    import contextlib
+    import io
+    from animateportrait_amd import networks as _nets, standins
+    from animateportrait_amd.data.synthetic_dataset import make_train_batch
+    from animateportrait_amd.models import create_model
+    from animateportrait_amd.options.base_options import TrainOptions
+    from oracle import generator as og, discriminator as od          # (checker side: the seeded weights the golden was made with)
+    z = np.load(os.path.join(ROOT, 'tests', 'golden', 'train_step.npz'))
+    w = int(z['width'])
+    argv = ['--model', 'geomgm_ifw_fore', '--netG', 'resnet_9blocks_rcatland32_full_ifw', '--dataset_mode', 'synthetic',
+            '--output_nc', '1', '--ngf', str(w), '--ndf', str(w), '--netg_resb_div', '3', '--netg_resb_disp', '3', '--lr', '0.00005',
+            '--lambda_geom', '50', '--lambda_geom_lipline', '50', '--more_weight_for_lip', '2', '--lambda_face', '3.0',
+            '--lambda_warp_inter', '10', '--blendbg', '1', '--batch_size', '1', '--gpu_ids', str(dev.index), '--precision', 'bf16x3']
+    dnames = ['D_A', 'D_A_l', 'D_A_le', 'D_A_ll', 'D_A_coh']
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = create_model(TrainOptions().parse(argv))
+        model.netG_A.load_state_dict(og.init_params(og.generator_param_shapes(3, 1, w, 9, 3, 3), seed=int(z['g_seed'])), strict=True)
+        for i, n in enumerate(dnames):
+            getattr(model, 'net' + n).load_state_dict(
+                og.init_params(od.patchgan_param_shapes(1 if n == 'D_A' else 2, w), seed=int(z['d_seed0']) + i), strict=True)
+        model.aux['landmarks'] = standins.StandinLandmarkNet().to(dev)
+        model.aux['faceloss'] = _nets.FaceLoss(standins.StandinFaceNet().to(dev))
+        model.aux['netF'] = standins.StandinFlowNet().to(dev)
+        model.aux['modnet'] = standins.StandinMatteNet().to(dev)
+        batch = make_train_batch(1, seed=int(z['batch_seed']))
+        for k in ('winA', 'winB', 'winB2', 'winBr'):
+            batch[k] = torch.from_numpy(np.asarray(z[k])).view(1, 4)
+        model.set_input(batch)
+        model.optimize_parameters()
+        got = model.get_current_losses()
+    worst, worst_k = 0.0, None
+    for k in ['G_A', 'G_A_l', 'G_A_le', 'G_A_ll', 'G_A_coh', 'geom_B', 'geom_B_lipline', 'warp_B', 'warp_inter1', 'iden_B', 'G'] + dnames:
+        ref, f32 = float(z['loss_' + k]), float(z['loss_' + k + '_f32'])
+        err = abs(got[k] - ref) / abs(ref)
+        if err > worst:
+            worst, worst_k = err, k
+        if abs(got[k] - ref) > 3.0 * abs(f32 - ref) + 1e-2 * abs(ref):
+            raise SystemExit('bench.py: train-step parity gate FAILED -- loss %s = %.6f, the reference class gives %.6f' % (k, got[k], ref))
+    return {'max_rel_loss_diff_vs_reference_class_golden': round(worst, 6), 'worst_term': worst_k, 'terms': 16,
+            'golden': 'tests/golden/train_step.npz (reference GeomGMIFWForeModel, ngf = ndf = 8, b = 1, fp64)'}
+
+
 PARITY_BUDGET = 1e-3      # BASELINE.md: every reported number needs the generator output within 1e-3 L-inf (fp32, outputs in [-1, 1])
 
 
@@ -528,6 +575,7 @@ def main():
         del G, args, y
         torch.cuda.empty_cache()
         old = ops.DEFAULT_PRECISION
+        train_gate = train_parity_gate(dev) if (rank == 0 and not a.no_parity_gate) else None
         try:
             train = train_step_ms(dev, rank, world, dist, a.train_steps, 'bf16x3')
             torch.cuda.empty_cache()
@@ -572,6 +620,7 @@ def main():
             out['exact_fp32'] = exact
             out['plain_bf16_inference'] = plain
         if train is not None:
+            train['parity_gate'] = train_gate if train_gate is not None else 'SKIPPED (--no-parity-gate)'
             out['train_step'] = train
         if train_bf16 is not None:
             if train is not None:
