@@ -370,6 +370,46 @@ def load_sphere20a(path, device, fold=True):
     return _frozen(net, device, fold)
 
 
+class GraphedFrozen(nn.Module):
+    """A frozen network whose forward + backward (w.r.t. its input) replay as hipGraphs, one pair per input shape
+    (torch.cuda.make_graphed_callables).  MobileFaceNet is ~600 small kernels per forward + backward at the train step's shapes:
+    6.2 ms eager, 4.5 ms as a graph; Sphere20a 4.2 -> 3.2 ms (tools/aux_bench.py).  ``pick`` selects the outputs the caller uses
+    (every graphed output needs a gradient in backward).  Calls whose input needs no gradient, CPU tensors and autocast / no_grad
+    contexts run eagerly.  The graphs are captured after a device synchronisation: capture warms up on a side stream, and no
+    kernel of this package may run beside another stream's."""
+
+    def __init__(self, net, pick=None):
+        super().__init__()
+        self.net = net
+        self.pick = pick
+        self._graphs = {}
+
+    def _eager(self, x):
+        out = self.net(x)
+        return out if self.pick is None else self.pick(out)
+
+    def forward(self, x):
+        if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) or os.environ.get('APAMD_NO_AUX_GRAPHS'):
+            return self._eager(x)
+        key = (tuple(x.shape), x.dtype)
+        g = self._graphs.get(key)
+        if g is None:
+            outer = self
+
+            class _Fn(nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.net = outer.net
+
+                def forward(self, t):
+                    return outer._eager(t)
+            torch.cuda.synchronize()
+            sample = torch.zeros_like(x).requires_grad_(True)
+            g = self._graphs[key] = torch.cuda.make_graphed_callables(_Fn(), (sample,))
+            torch.cuda.synchronize()
+        return g(x.contiguous())
+
+
 def attach_aux_networks(model, checkpoints_dir='checkpoints', verbose=True):
     """What the reference models do in ``__init__`` with hard-coded paths: load whichever of the frozen nets has its checkpoint
     under ``checkpoints_dir`` (and ``opt.face_recog_model`` for Sphere20a) into the model's ``aux`` slots that are still empty.
@@ -388,13 +428,13 @@ def attach_aux_networks(model, checkpoints_dir='checkpoints', verbose=True):
     if getattr(model, 'isTrain', False):
         p = os.path.join(checkpoints_dir, MOBILEFACENET_CKPT)
         if 'landmarks' in aux and aux['landmarks'] is None and os.path.exists(p):
-            aux['landmarks'] = load_mobilefacenet(p, dev)
+            aux['landmarks'] = GraphedFrozen(load_mobilefacenet(p, dev), pick=lambda o: o[0])
             done.append('landmarks')
         p = getattr(opt, 'face_recog_model', None)
         if 'faceloss' in aux and aux['faceloss'] is None and getattr(opt, 'identity_loss', 0) and p and os.path.exists(p):
             if 'senet' in p:
                 raise NotImplementedError('--face_recog_model: only the Sphere20a checkpoint is supported (FaceLoss, networks.py:2862-2871)')
-            aux['faceloss'] = networks.FaceLoss(load_sphere20a(p, dev))
+            aux['faceloss'] = networks.FaceLoss(GraphedFrozen(load_sphere20a(p, dev), pick=tuple))
             done.append('faceloss')
     for n in done:
         say('[aux] attached frozen network: %s' % n)

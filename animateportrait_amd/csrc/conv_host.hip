@@ -7,6 +7,7 @@
 #include "conv_registry.h"
 #include "conv_direct.h"
 #include "conv_bf16x3.h"
+#include "conv_bf16x3_sb.h"
 #include "conv_ph4.h"
 #include "conv_small.h"
 #include "conv_head.h"
@@ -1070,7 +1071,19 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 p.fn_mean = fn->mean; p.fn_rstd = fn->rstd; p.fn_counters = fn->counters;
                 p.fn_debug = env_int("APAMD_FNORM_DEBUG", 0);
             }
-            const size_t lds = kern->lds(d->precision, p.ntaps);
+            size_t lds = kern->lds(d->precision, p.ntaps);
+            bool sb = false;
+            if (!fn && !view && !octet && kern->K == 3 && kern->S == 1 && kern->TH == 16 && !kern->ROW && d->precision != AP_PRECISION_BF16 &&
+                p.osx == 1 && p.osy == 1 && p.oy_off == 0 && p.ox_off == 0 && env_int("APAMD_CONV_SB", 0)) {
+                // experiment (conv_bf16x3_sb.h): one LDS stage per workgroup, two workgroups per CU
+                using CS = Bf3Cfg<1, 3, 1, 2, 4, 4, 0, 0, 2>;
+                kfn = reinterpret_cast<const void*>(&conv_bf16x3_sb<CS>);
+                rc = ensure_lds_attr(kfn);
+                if (rc) return rc;
+                lds = (size_t)(CS::X_SLOTS + CS::w_slots(9)) * 16;
+                p.fn_debug = env_int("APAMD_CONV_SB_SKEW", 0);
+                sb = true;
+            }
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
             if (p.nchunks < 2) return fail(AP_ERR_UNSUPPORTED, "bf16x3 pipeline needs >= 32 input channels");
             if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes
@@ -1078,7 +1091,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             // persistent workgroups: one per CU (the two LDS stages fill a CU), each walks its share of the tiles
             long long nblk = (long long)d->N * p.tiles_y * p.tiles_x * p.co_tiles;
             // (two per CU when two stage sets fit its 160 KB of LDS)
-            int cus = num_cus() * (2 * lds <= 160 * 1024 ? 2 : 1);
+            int cus = num_cus() * ((2 * lds <= 160 * 1024 || sb) ? 2 : 1);
             if (const int forced = env_int("APAMD_BF3_BLOCKS", 0)) {      // tuning / test knob: never silent
                 static bool told = false;
                 if (!told) fprintf(stderr, "libapamd: APAMD_BF3_BLOCKS=%d overrides the persistent workgroup count\n", forced);

@@ -210,8 +210,9 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3', aux_kind='r
         else:
             torch.manual_seed(4321)
             frozen = lambda net: aux_nets._frozen(net, dev)                                       # noqa: E731
-            model.aux['landmarks'] = frozen(aux_nets.MobileFaceNet((112, 112), 136))              # geomgm_ifw_fore_model.py:362
-            model.aux['faceloss'] = _nets.FaceLoss(frozen(aux_nets.Sphere20a()))                  # :374-376
+            # (as attach_aux_networks builds them: forward + backward of the two differentiated nets replay as hipGraphs)
+            model.aux['landmarks'] = aux_nets.GraphedFrozen(frozen(aux_nets.MobileFaceNet((112, 112), 136)), pick=lambda o: o[0])   # geomgm_ifw_fore_model.py:362
+            model.aux['faceloss'] = _nets.FaceLoss(aux_nets.GraphedFrozen(frozen(aux_nets.Sphere20a()), pick=tuple))            # :374-376
             model.aux['modnet'] = frozen(aux_nets.MODNet())                                       # :369-373, called in forward :519
         parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
         drift0 = parallel.replica_drift(model)

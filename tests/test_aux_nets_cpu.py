@@ -101,8 +101,8 @@ def test_checkpoint_loaders_and_auto_attach(tmp_path):
     opt = types.SimpleNamespace(face_recog_model=str(tmp_path / 'sphere20a_20171020.pth'), identity_loss=2)
     model = types.SimpleNamespace(aux={'modnet': None, 'landmarks': None, 'faceloss': None, 'netF': None}, opt=opt, device=dev, isTrain=True)
     assert aux_nets.attach_aux_networks(model, str(tmp_path), verbose=False) == ['modnet', 'landmarks', 'faceloss']
-    assert isinstance(model.aux['modnet'], aux_nets.MODNet) and isinstance(model.aux['landmarks'], aux_nets.MobileFaceNet)
-    assert isinstance(model.aux['faceloss'].net, aux_nets.Sphere20a) and model.aux['netF'] is None
+    assert isinstance(model.aux['modnet'], aux_nets.MODNet) and isinstance(model.aux['landmarks'].net, aux_nets.MobileFaceNet)
+    assert isinstance(model.aux['faceloss'].net.net, aux_nets.Sphere20a) and model.aux['netF'] is None
     assert aux_nets.attach_aux_networks(model, str(tmp_path), verbose=False) == []        # slots already filled
     test_model = types.SimpleNamespace(aux={'modnet': None, 'netF': None}, opt=opt, device=dev, isTrain=False)
     assert aux_nets.attach_aux_networks(test_model, str(tmp_path), verbose=False) == ['modnet']

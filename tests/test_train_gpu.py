@@ -619,8 +619,8 @@ def test_train_step_with_reference_aux_architectures(dev, tmp_path, monkeypatch)
     opt = TrainOptions().parse(argv)
     model = create_model(opt)
     model.setup(opt)
-    assert isinstance(model.aux['modnet'], aux_nets.MODNet) and isinstance(model.aux['landmarks'], aux_nets.MobileFaceNet)
-    assert isinstance(model.aux['faceloss'], N.FaceLoss) and isinstance(model.aux['faceloss'].net, aux_nets.Sphere20a)
+    assert isinstance(model.aux['modnet'], aux_nets.MODNet) and isinstance(model.aux['landmarks'].net, aux_nets.MobileFaceNet)
+    assert isinstance(model.aux['faceloss'], N.FaceLoss) and isinstance(model.aux['faceloss'].net.net, aux_nets.Sphere20a)
     batch = make_train_batch(2, seed=9)
     del batch['mask']                                   # the matte must come from MODNet now
     model.set_input(batch)
@@ -631,3 +631,28 @@ def test_train_step_with_reference_aux_architectures(dev, tmp_path, monkeypatch)
     losses = model.get_current_losses()
     assert all(np.isfinite(v) for v in losses.values()) and losses['geom_B'] > 0 and losses['iden_B'] > 0, losses
     assert float(model.optimizer_G.flat_grad.abs().max()) > 0 if hasattr(model.optimizer_G, 'flat_grad') else True
+
+
+def test_graphed_frozen_nets_match_eager(dev, monkeypatch):
+    """aux_nets.GraphedFrozen (forward + backward of a frozen aux net as hipGraphs) == the eager module: outputs and the
+    gradient w.r.t. the input, on fresh inputs after the capture (the graph reads its static buffers, not stale data).  MIOpen may
+    pick different convolution algorithms inside and outside a capture (one of three runs of round 4 differed beyond 1e-5), so
+    the bars are those of fp32 rounding through ~50 layers; stale inputs would be off by O(1)."""
+    from animateportrait_amd import aux_nets
+    torch.manual_seed(1)
+    for net, shape, pick in ((aux_nets.MobileFaceNet(), (4, 3, 112, 112), lambda o: o[0]), (aux_nets.Sphere20a(), (2, 3, 112, 96), tuple)):
+        net = aux_nets._frozen(net, dev)
+        g = aux_nets.GraphedFrozen(net, pick=pick)
+        for it in range(3):
+            x = torch.rand(shape, device=dev, generator=None)
+            xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            oa, ob = g(xa), pick(net(xb))
+            la = oa.sum() if torch.is_tensor(oa) else sum(t.abs().mean() for t in oa)
+            lb = ob.sum() if torch.is_tensor(ob) else sum(t.abs().mean() for t in ob)
+            la.backward(); lb.backward()
+            assert abs(float(la.detach()) - float(lb.detach())) <= 1e-4 * abs(float(lb.detach())) + 1e-6, it
+            assert linf(xa.grad, xb.grad) <= 2e-3 * float(xb.grad.abs().max()) + 1e-9, it
+        assert len(g._graphs) == 1
+        with torch.no_grad():                       # no gradient wanted: eager path, same values
+            o = g(x)
+        assert torch.is_tensor(o) or len(o) == 5
