@@ -143,14 +143,52 @@ def _dgrad_spec_geometry(layer, seg_c):
     return ConvSpec([s.cout], seg_c, k, 2, s.pad, PAD_ZERO, True, 1 if k == 3 else 0, W_IOHW, False), 0
 
 
+def _split_backward_plan(tape, layer, srcs, out, contribs):
+    """Can the InstanceNorm backward of ``out`` write the operands of its consumers itself (ops.instnorm_bwd_split)?  Yes when every
+    consumer of the gradient is a bf16 matrix kernel: the weight gradient takes a prepared M-role operand (ops.wgrad_gt_dims) and
+    each data gradient stages split copies.  Returns (reduced contributions, gt_dims, want_xs, want_strip) or None."""
+    s = layer.spec
+    if s.transposed or s.precision == ops.PRECISION_FP32 or ops.DEFAULT_PRECISION == ops.PRECISION_FP32:
+        return None
+    n, c, h, w = out.data.shape
+    pads = sorted(p for _, p in contribs if p > 0)
+    if (pads and pads[-1] > 1) or not ops.instnorm_bwd_split_ok(out, 1 if pads else 0):
+        return None
+    gt_dims = None
+    if layer.weight.requires_grad:
+        gt_dims = ops.wgrad_gt_dims(s.k, s.stride, s.pad, s.pad_mode, (n, c, h, w), srcs, s.precision)
+        if gt_dims is None:
+            return None
+    want_xs = want_strip = False
+    probe = Feat(out.data)                 # a plain feature of the gradient's shape
+    for i, f in enumerate(srcs):
+        if tape.tracked(f):
+            spec, fold_pad = _dgrad_spec(layer, s.cin_segments[i])
+            if not ops.takes_split(spec, n, h, w):
+                return None
+            want_xs = True
+            want_strip = want_strip or bool(fold_pad and ops.dgrad_strip_eligible(spec, probe))
+    if gt_dims is None and not want_xs:
+        return None
+    return ops._split_contribs(contribs), gt_dims, want_xs, want_strip
+
+
 def conv_backward(tape, layer, srcs, out, norm, act):
     """out: Feat produced by layer.run(srcs).  Consumes out's gradient contributions."""
     contribs = tape.take(out)
     if not contribs:
         return
-    dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
     s = layer.spec
-    gfeat = Feat(dy)
+    gt = strip = None
+    plan = _split_backward_plan(tape, layer, srcs, out, contribs) if norm else None
+    if plan is not None:
+        # the gradient only feeds the bf16 matrix kernels: its producer writes their operands, no fp32 dy (ops.instnorm_bwd_split)
+        red, gt_dims, want_xs, want_strip = plan
+        gfeat, gt, strip = ops.instnorm_bwd_split(red, out, gt_dims, want_xs, want_strip)
+        dy = None
+    else:
+        dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
+        gfeat = Feat(dy)
     # ---- weight gradient
     if layer.weight.requires_grad:
         if s.transposed:
@@ -159,7 +197,7 @@ def conv_backward(tape, layer, srcs, out, norm, act):
                            out=tape.slot(layer.weight))
         else:
             dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape, precision=s.precision,
-                           out=tape.slot(layer.weight))
+                           out=tape.slot(layer.weight), g_t=gt)
         tape.add_param(layer.weight, dw)
     if layer.bias.requires_grad:
         # a bias in front of InstanceNorm has an exactly-zero gradient (it is removed by the mean subtraction)
@@ -181,7 +219,7 @@ def conv_backward(tape, layer, srcs, out, norm, act):
             if fold_pad and ops.dgrad_strip_eligible(spec, gfeat):
                 # 66-column padded gradient: two whole tile columns + a transposed 2-column strip (ops.conv2d_dgrad_strip)
                 packed_t = layer.packed_dgrad((i, 'T'), spec, w.transpose(2, 3))
-                g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t)
+                g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t, strip)
             else:
                 g = ops.conv2d(spec, [gfeat], packed, None).data
             tape.add(f, g, fold_pad)

@@ -12,6 +12,7 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace apamd {
 
@@ -283,6 +284,209 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_fused_kernel(const float* __r
             const int i = k * NT + tid;
             if (i < HW) out[i] = r * (gv[k] - a1 - xh[k] * a2);
         }
+    }
+}
+
+// ---- instnorm_bwd_split: the InstanceNorm backward of a layer whose gradient goes straight into the bf16 matrix kernels.
+// The fp32 gradient dy of such a layer was written once (4 B / element) and read twice -- by the split pass in front of the
+// data-gradient convolution and by the transposition in front of the weight gradient -- to be rounded to bf16 head (+ tail)
+// planes both times.  Here a workgroup owns the EIGHT channels of a channel octet of one image (a thread: 4 consecutive pixels
+// of each), so after the plane reductions it holds whole slots of both operand layouts and writes them itself:
+//   xs  [n][part][C / 8][HW + 1][8 channels]      the split copy conv_bf16x3 stages (conv_bf16x3.h), zero slot included;
+//   gt  [n][part][GHp * GX8][Mp][8 pixels]        the M-role operand of wgrad_bf16x3 (wgrad_bf16x3.h): a lane pair holds the two
+//                                                 quads of a pixel octet and swaps channel halves (8 shuffles per part);
+//   strip [n][c][2][H]  fp32                      columns W - 2, W - 1 transposed: the operand of ops.conv2d_dgrad_strip.
+// dy itself is written only on request.  2 reads + (1/2 + 1/2 | 1 + 1) writes per element instead of 4 + (2 | 3).
+// grid: min(N * C / 8, resident workgroups), persistent; NT threads >= H * W / 4; needs W % 8 == 0, H >= 3.
+struct InBwdSplitParams {
+    const float* g1;
+    const float* g2;
+    const float* y;
+    const float* mean;
+    const float* rstd;
+    int p1, act, N, C, H, W;
+    uint4* xs;
+    uint4* gt;
+    int GHp, GX8, Mp;
+    float* strip;
+    float* dy;
+    int heads_only;
+};
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    const __bf16 ha = (__bf16)a, hb = (__bf16)b;
+    return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float bf16_tail(float v) { return v - (float)(__bf16)v; }
+
+template <int NT>
+__global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplitParams p) {
+    constexpr int NW = NT / 64;
+    __shared__ float red[16][NW];
+    __shared__ float tot[16];
+    const int tid0 = threadIdx.x;
+    const int H = p.H, W = p.W, HW = H * W, W4 = W >> 2;
+    const bool live = tid0 < HW / 4;
+    const bool fold1 = p.p1 == 1;
+    const int CG = p.C >> 3, items = p.N * CG;
+    // A workgroup holds one (image, channel octet) in registers -- a CU has room for one such workgroup -- so it walks several of
+    // them: the loads of the next item are issued right behind the stores of the current one (which are not waited for), so reads
+    // and writes of a CU overlap and there is no drain + dispatch gap between items (first version, one item per workgroup:
+    // 2.7 TB/s, profiles/r04x_train_bf16_bygrid.md; an explicit prefetch in front of the stores spilled 150-300 registers).
+    for (int item = blockIdx.x; item < items; item += (int)gridDim.x) {
+    const int n = item / CG, cg = item - n * CG, c0 = cg * 8;
+    // (per-lane addresses are recomputed in every iteration from an opaque copy of the lane id: hoisted out of the loop they
+    // occupied registers across it)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int row = tid / W4, x4 = (tid - row * W4) * 4;
+    float xh[32], gv[32];
+    {
+        float4 yv[8], gq[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const long long nc = (long long)n * p.C + c0 + c;
+            yv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                yv[c] = reinterpret_cast<const float4*>(p.y + nc * HW)[tid];
+                if (fold1) {         // the padded row itself; its reflected border terms follow
+                    const float4u t = *reinterpret_cast<const float4u*>(p.g1 + nc * (H + 2) * (W + 2) + (row + 1) * (W + 2) + x4 + 1);
+                    gq[c] = make_float4(t.x, t.y, t.z, t.w);
+                } else {
+                    gq[c] = reinterpret_cast<const float4*>(p.g1 + nc * HW)[tid];
+                }
+            }
+        }
+        if (fold1 && live) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float* gp = p.g1 + ((long long)n * p.C + c0 + c) * (H + 2) * (W + 2);
+                const float* rp = gp + (row + 1) * (W + 2);
+                if (x4 == 0) gq[c].y += rp[0];
+                if (x4 == W - 4) gq[c].z += rp[W + 1];
+                if (row == 1) { const float4 t = fold1_row4(gp, W, 0, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
+                if (row == H - 2) { const float4 t = fold1_row4(gp, W, H + 1, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
+            }
+        }
+        if (p.g2 != nullptr && live) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 t = reinterpret_cast<const float4*>(p.g2 + ((long long)n * p.C + c0 + c) * HW)[tid];
+                gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float m = p.mean[n * p.C + c0 + c], r = p.rstd[n * p.C + c0 + c];
+            const float yy[4] = {yv[c].x, yv[c].y, yv[c].z, yv[c].w}, gg[4] = {gq[c].x, gq[c].y, gq[c].z, gq[c].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = live ? (yy[j] - m) * r : 0.f;
+                xh[c * 4 + j] = x;
+                gv[c * 4 + j] = gg[j] * act_grad_from_xhat(x, p.act);
+            }
+        }
+    }
+    // plane sums of g and g * xhat, per channel: wave butterflies, then a fixed-order sum over the waves
+    {
+        float s[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            s[c] = (gv[c * 4] + gv[c * 4 + 1]) + (gv[c * 4 + 2] + gv[c * 4 + 3]);
+            s[8 + c] = (gv[c * 4] * xh[c * 4] + gv[c * 4 + 1] * xh[c * 4 + 1]) + (gv[c * 4 + 2] * xh[c * 4 + 2] + gv[c * 4 + 3] * xh[c * 4 + 3]);
+        }
+        // 16 values per lane -> wave totals by halving (common.h: wave_sums_to_lds): at lane bits 32, 16, 8, 4 a lane keeps one half
+        // of its values and receives the partner's sums of that half, then two plain steps: 17 exchanges instead of 96
+        const int lane = tid & 63;
+        int cnt = 16;
+#pragma unroll
+        for (int bit = 32; bit >= 4; bit >>= 1) {
+            const int hcnt = cnt >> 1;
+            const bool up = (lane & bit) != 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < hcnt) {
+                    const float keep = up ? s[hcnt + j] : s[j], give = up ? s[j] : s[hcnt + j];
+                    s[j] = keep + __shfl_xor(give, bit, 64);
+                }
+            cnt = hcnt;
+        }
+        s[0] += __shfl_xor(s[0], 2, 64);
+        s[0] += __shfl_xor(s[0], 1, 64);
+        if ((lane & 3) == 0) red[((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)][tid >> 6] = s[0];
+        __syncthreads();
+        if (tid < 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += red[tid][w];
+            tot[tid] = t * (1.f / (float)HW);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float r = p.rstd[n * p.C + c0 + c], a1 = tot[c], a2 = tot[8 + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) gv[c * 4 + j] = r * (gv[c * 4 + j] - a1 - xh[c * 4 + j] * a2);
+    }
+    const int nparts = p.heads_only ? 1 : 2;
+    if (p.dy != nullptr && live) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            reinterpret_cast<float4*>(p.dy + ((long long)n * p.C + c0 + c) * HW)[tid] =
+                make_float4(gv[c * 4], gv[c * 4 + 1], gv[c * 4 + 2], gv[c * 4 + 3]);
+    }
+    if (p.strip != nullptr && live && x4 == W - 4) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float* d = p.strip + (((long long)n * p.C + c0 + c) * 2) * H + row;
+            d[0] = gv[c * 4 + 2];
+            d[H] = gv[c * 4 + 3];
+        }
+    }
+    if (p.xs != nullptr) {
+        const int CG = p.C >> 3;
+        for (int part = 0; part < nparts; ++part) {
+            uint4* plane = p.xs + ((long long)(n * 2 + part) * CG + cg) * (HW + 1);
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] = part ? bf16_tail(gv[c * 4 + j]) : gv[c * 4 + j];
+                    plane[tid * 4 + j] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                    pack_bf16x2(v[6], v[7]));
+                }
+            }
+            if (tid == 0) plane[HW] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (p.gt != nullptr) {
+        const bool odd = tid & 1;                  // the high quad of the pixel octet (W % 8 == 0: the pair shares a row)
+        const long long noct = (long long)p.GHp * p.GX8;
+        const long long oct = (long long)row * p.GX8 + (x4 >> 3);
+        for (int part = 0; part < nparts; ++part) {
+            unsigned lo[8], hi[8];                 // per channel: pixels (0, 1), (2, 3) of this lane's quad
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = part ? bf16_tail(gv[c * 4 + j]) : gv[c * 4 + j];
+                lo[c] = pack_bf16x2(v[0], v[1]);
+                hi[c] = pack_bf16x2(v[2], v[3]);
+            }
+            uint4* dst = p.gt + ((long long)(n * 2 + part) * noct + oct) * p.Mp + c0 + (odd ? 4 : 0);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // the even lane keeps channels 0..3 and gives 4..7, the odd lane the other way round
+                const unsigned give_lo = odd ? lo[k] : lo[4 + k], give_hi = odd ? hi[k] : hi[4 + k];
+                const unsigned keep_lo = odd ? lo[4 + k] : lo[k], keep_hi = odd ? hi[4 + k] : hi[k];
+                const unsigned got_lo = (unsigned)__shfl_xor((int)give_lo, 1, 64), got_hi = (unsigned)__shfl_xor((int)give_hi, 1, 64);
+                if (live) dst[k] = odd ? make_uint4(got_lo, got_hi, keep_lo, keep_hi) : make_uint4(keep_lo, keep_hi, got_lo, got_hi);
+            }
+        }
+    }
     }
 }
 
@@ -565,6 +769,52 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
     hipLaunchKernelGGL(instnorm_bwd_apply_kernel, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, y,
                        mean, rstd, act, H, W, sums_ws, dy);
     return check_launch("instnorm_bwd_apply_kernel");
+}
+
+int ap_instnorm_bwd_split_ok(int32_t C, int32_t H, int32_t W, int32_t g1_pad) {
+    const char* off = getenv("APAMD_NO_INBWD_SPLIT");      // (read per call: tests and A/B runs flip it inside one process)
+    return !(off && atoi(off)) && C >= 8 && C % 8 == 0 && H >= 3 && W >= 8 && W % 8 == 0 && H * W <= 4096 && (g1_pad == 0 || g1_pad == 1) ? 1 : 0;
+}
+
+int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean, const float* rstd,
+                          int32_t act, int32_t N, int32_t C, int32_t H, int32_t W, void* xs, void* gt, const int32_t* gt_dims,
+                          float* strip, float* dy, int32_t heads_only, ap_stream_t stream) {
+    int rc = fold_args_ok(g1, g1_pad, H, W, "instnorm_bwd_split");
+    if (rc) return rc;
+    if (!y || !mean || !rstd) return fail(AP_ERR_INVALID, "instnorm_bwd_split: null pointer");
+    if (!xs && !gt && !dy) return fail(AP_ERR_INVALID, "instnorm_bwd_split: no output requested");
+    if (act < 0 || act > 2) return fail(AP_ERR_INVALID, "instnorm_bwd_split: act %d", act);
+    if (!ap_instnorm_bwd_split_ok(C, H, W, g1_pad))
+        return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd_split: C=%d %dx%d fold %d (needs C %% 8 == 0, W %% 8 == 0, H >= 3, H*W <= 4096)", C, H, W, g1_pad);
+    if (N < 1 || N > 65535) return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd_split: N=%d", N);
+    InBwdSplitParams p;
+    memset(&p, 0, sizeof(p));
+    p.g1 = g1; p.g2 = g2; p.y = y; p.mean = mean; p.rstd = rstd;
+    p.p1 = g1_pad; p.act = act; p.C = C; p.H = H; p.W = W;
+    p.xs = reinterpret_cast<uint4*>(xs);
+    p.gt = reinterpret_cast<uint4*>(gt);
+    if (gt) {
+        if (!gt_dims) return fail(AP_ERR_INVALID, "instnorm_bwd_split: gt without its dimensions");
+        p.GHp = gt_dims[0]; p.GX8 = gt_dims[1]; p.Mp = gt_dims[2];
+        if (p.GHp < H || p.GX8 * 8 < W || p.Mp < C)
+            return fail(AP_ERR_INVALID, "instnorm_bwd_split: operand %d x %d x %d smaller than the gradient", p.GHp, p.GX8, p.Mp);
+    }
+    p.strip = strip; p.dy = dy; p.heads_only = heads_only ? 1 : 0;
+    p.N = N;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(AP_ERR_LAUNCH, "instnorm_bwd_split: no device");
+        cus = prop.multiProcessorCount;
+    }
+    const int items = N * (C / 8);
+    const bool small = H * W / 4 <= 256;
+    const int slots = cus * (small ? 4 : 1);          // resident workgroups: registers hold one 1024-thread item per CU, four of 256
+    const dim3 grid(items < slots ? items : slots);
+    if (small) hipLaunchKernelGGL(instnorm_bwd_split_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(instnorm_bwd_split_kernel<1024>, grid, dim3(1024), 0, (hipStream_t)stream, p);
+    return check_launch("instnorm_bwd_split_kernel");
 }
 
 int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,

@@ -398,12 +398,27 @@ int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {
     return pl.a_floats + pl.g_floats + pl.part_floats;
 }
 
-int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream_) {
+int ap_conv2d_wgrad_gt_dims(const ap_wgrad_desc* d, int32_t* dims) {
+    WgradPlan pl;
+    int rc = make_wgrad_plan(d, pl);
+    if (rc) return rc;
+    if (!dims) return fail(AP_ERR_INVALID, "wgrad_gt_dims: null pointer");
+    if (!pl.bf3) return 0;
+    dims[0] = pl.GHp; dims[1] = pl.GX8; dims[2] = pl.Mp;
+    return 1;
+}
+
+}  // extern "C"
+
+// g_t: the M-role operand already in the kernel's layout (ap_conv2d_wgrad_gt_dims), written by its producer
+// (ap_instnorm_bwd_split) -- the transposition pass over d->g is skipped and d->g.data is not read
+static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace, float* dw, ap_stream_t stream_) {
     WgradPlan pl;
     int rc = make_wgrad_plan(d, pl);
     if (rc) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    if (!workspace || !dw || !d->g.data) return fail(AP_ERR_INVALID, "wgrad: null pointer");
+    if (g_t && !pl.bf3) return fail(AP_ERR_UNSUPPORTED, "wgrad: a prepared operand needs the bf16 matrix plan (ap_conv2d_wgrad_gt_dims)");
+    if (!workspace || !dw || (!d->g.data && !g_t)) return fail(AP_ERR_INVALID, "wgrad: null pointer");
     if ((d->g.mean == nullptr) != (d->g.rstd == nullptr)) return fail(AP_ERR_INVALID, "wgrad: g mean/rstd mismatch");
     for (int s = 0; s < d->nsrc; ++s) {
         if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
@@ -446,10 +461,14 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
         rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
                                     pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16);
         if (rc) return rc;
-        ap_src g = d->g;
-        g.C = d->M;
-        rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream, 0, d->precision == AP_PRECISION_BF16);
-        if (rc) return rc;
+        if (g_t) {
+            gt = reinterpret_cast<uint4*>(const_cast<void*>(g_t));
+        } else {
+            ap_src g = d->g;
+            g.C = d->M;
+            rc = launch_split_transpose(&g, 1, d->N, d->M, d->GH, d->GW, 0, AP_PAD_ZERO, pl.GHp, pl.GX8, pl.Mp, gt, stream, 0, d->precision == AP_PRECISION_BF16);
+            if (rc) return rc;
+        }
         WgradBf3Params p;
         memset(&p, 0, sizeof(p));
         p.gt = gt; p.at = at;
@@ -511,6 +530,17 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
     const long long n = (long long)d->M * pl.Q;
     launch_wgrad_reduce(stream, partial, pl.P, n, dw);
     return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" {
+
+int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stream_t stream) {
+    return wgrad_impl(d, nullptr, workspace, dw, stream);
+}
+
+int ap_conv2d_wgrad_pre(const ap_wgrad_desc* d, const void* g_t, float* workspace, float* dw, ap_stream_t stream) {
+    if (!g_t) return fail(AP_ERR_INVALID, "wgrad_pre: null operand");
+    return wgrad_impl(d, g_t, workspace, dw, stream);
 }
 
 }  // extern "C"

@@ -689,7 +689,7 @@ def dgrad_strip_eligible(spec, g):
     return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
 
 
-def conv2d_dgrad_strip(spec, g, packed, packed_t):
+def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None):
     """Padded-coordinate data gradient (N, Cin, H+2, W+2) of a reflection-padded 3x3 layer in two launches instead of a
     three-tile-column one: W+2 = 32 m + 2, so the last tile column of a plain launch would hold 2 of 32 columns.
     * the two last padded columns depend on the two last gradient columns only: the same operator on their
@@ -699,7 +699,7 @@ def conv2d_dgrad_strip(spec, g, packed, packed_t):
     n, c, h, w = g.data.shape
     hp, wp = h + 2, w + 2
     out = torch.empty((n, spec.cout, hp, wp), dtype=torch.float32, device=g.data.device)
-    t = Feat(g.data[:, :, :, w - 2:].transpose(2, 3).contiguous())
+    t = strip if strip is not None else Feat(g.data[:, :, :, w - 2:].transpose(2, 3).contiguous())   # strip: (N, C, 2, H) from instnorm_bwd_split
     v = C.ApOutView()
     v.nstride, v.cstride = spec.cout * hp * wp, hp * wp
     v.rstride, v.xstride, v.y_off, v.x_off, v.OH, v.OW = 1, wp, w - 2, 0, 4, hp
@@ -826,11 +826,12 @@ def _grad_out(out, shape, device):
     return out
 
 
-def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None):
+def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None, g_t=None):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
     srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW): ``out`` when given
     (the layer's slot in the network's contiguous gradient block), else a new tensor.
-    precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers)."""
+    precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers).
+    g_t: the M-role operand as instnorm_bwd_split wrote it (wgrad_gt_dims); ``g`` then only carries the shape."""
     n, m, gh, gw = g.data.shape
     cin = sum(f.data.shape[1] for f in srcs)
     if (m == 1 and k == 4 and stride == 1 and len(srcs) == 1 and cin >= 64 and not g.virtual and g.act == ACT_NONE and
@@ -868,29 +869,54 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
         dw = _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
         return dw if out is None else out.copy_(dw)
+    d = _wgrad_desc(k, stride, pad, pad_mode, (n, m, gh, gw), None if g_t is not None else g, srcs, precision)
+    lib = C.lib()
+    nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
+    ws = torch.empty(nws, dtype=torch.float32, device=srcs[0].data.device)
+    dw = _grad_out(out, out_shape, srcs[0].data.device)
+    assert dw.numel() == m * cin * k * k
+    if g_t is not None:
+        C.check(lib.ap_conv2d_wgrad_pre(ctypes.byref(d), _ptr(g_t), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad_pre')
+    else:
+        C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
+    return dw
+
+
+def _wgrad_desc(k, stride, pad, pad_mode, g_shape, g, srcs, precision):
+    """ap_wgrad_desc of a layer; g None: the M-role operand comes prepared (ap_conv2d_wgrad_pre) and its pointers stay empty."""
+    n, m, gh, gw = g_shape
     d = C.ApWgradDesc()
     d.N, d.M, d.GH, d.GW = n, m, gh, gw
     d.H, d.W = srcs[0].data.shape[2], srcs[0].data.shape[3]
     d.K, d.stride, d.pad, d.pad_mode = k, stride, pad, pad_mode
     d.nsrc = len(srcs)
     d.precision = DEFAULT_PRECISION if precision is None else precision
-    d.g.data = g.data.data_ptr()
-    d.g.mean = g.mean.data_ptr() if g.mean is not None else None
-    d.g.rstd = g.rstd.data_ptr() if g.rstd is not None else None
-    d.g.C, d.g.act = m, g.act
+    d.g.C, d.g.act = m, ACT_NONE
+    if g is not None:
+        _require_device(g.data, 'wgrad gradient')
+        d.g.data = g.data.data_ptr()
+        d.g.mean = g.mean.data_ptr() if g.mean is not None else None
+        d.g.rstd = g.rstd.data_ptr() if g.rstd is not None else None
+        d.g.act = g.act
     for i, f in enumerate(srcs):
         _require_device(f.data, 'wgrad source')
         d.src[i].data = f.data.data_ptr()
         d.src[i].mean = f.mean.data_ptr() if f.mean is not None else None
         d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
         d.src[i].C, d.src[i].act = f.data.shape[1], f.act
-    lib = C.lib()
-    nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
-    ws = torch.empty(nws, dtype=torch.float32, device=g.data.device)
-    dw = _grad_out(out, out_shape, g.data.device)
-    assert dw.numel() == m * cin * k * k
-    C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
-    return dw
+    return d
+
+
+def wgrad_gt_dims(k, stride, pad, pad_mode, g_shape, srcs, precision=None):
+    """(rows, pixel octets per row, padded channels) of the M-role operand when this weight gradient runs on the bf16 matrix kernel
+    and therefore takes the operand prepared by its producer (instnorm_bwd_split -> wgrad(..., g_t=)); None when it does not."""
+    if g_shape[1] <= 4:
+        return None          # the narrow-output special cases of wgrad()
+    d = _wgrad_desc(k, stride, pad, pad_mode, g_shape, None, srcs, precision)
+    dims = (ctypes.c_int32 * 3)()
+    if C.check(C.lib().ap_conv2d_wgrad_gt_dims(ctypes.byref(d), dims), 'wgrad_gt_dims') != 1:
+        return None
+    return tuple(dims)
 
 
 def pad_materialize(srcs, pad, pad_mode, hp=None, wp=None):
@@ -966,6 +992,41 @@ def instnorm_bwd(contribs, f):
     C.check(C.lib().ap_instnorm_bwd(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act,
                                     n * c, h, w, _ptr(ws), _ptr(dy), _stream()), 'instnorm_bwd')
     return dy
+
+
+def instnorm_bwd_split_ok(f, pad):
+    n, c, h, w = f.data.shape
+    return C.lib().ap_instnorm_bwd_split_ok(c, h, w, pad) == 1
+
+
+def instnorm_bwd_split(red, f, gt_dims=None, want_xs=True, want_strip=False, want_dy=False):
+    """instnorm_bwd for a layer whose gradient only feeds the bf16 matrix kernels (ap_instnorm_bwd_split): no fp32 dy; the kernel
+    writes the split copy the data-gradient convolution stages, the weight gradient's M-role operand (gt_dims from wgrad_gt_dims)
+    and, for conv2d_dgrad_strip, the transposed two-column strip.  red = _split_contribs(contribs).
+    Returns (gradient Feat that exists as its split copy, gt or None, strip Feat or None)."""
+    g1, pad, g2 = red
+    n, c, h, w = f.data.shape
+    dev = f.data.device
+    heads_only = DEFAULT_PRECISION == PRECISION_BF16
+    xs = _alloc_xs(f.data) if want_xs else None
+    gt = dims = None
+    if gt_dims is not None:
+        ghp, gx8, mp = gt_dims
+        alloc = torch.empty if (ghp == h and gx8 * 8 == w and mp == c) else torch.zeros
+        gt = alloc(n * 2 * ghp * gx8 * mp * 16, dtype=torch.uint8, device=dev)
+        dims = (ctypes.c_int32 * 3)(ghp, gx8, mp)
+    strip = torch.empty((n, c, 2, h), dtype=torch.float32, device=dev) if want_strip else None
+    dy = torch.empty_like(f.data) if want_dy else None
+    C.check(C.lib().ap_instnorm_bwd_split(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act, n, c, h, w,
+                                          _ptr(xs), _ptr(gt), dims, _ptr(strip), _ptr(dy), 1 if heads_only else 0, _stream()),
+            'instnorm_bwd_split')
+    if dy is not None:
+        gf = Feat(dy)
+        gf.xs = xs
+    else:
+        gf = Feat.split_only((n, c, h, w), xs)
+    gf.xs_heads_only = heads_only
+    return gf, gt, (Feat(strip) if strip is not None else None)
 
 
 def act_bwd(contribs, out, act):

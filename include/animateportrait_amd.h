@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 7
+#define AP_ABI_VERSION 8
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -352,6 +352,26 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
 int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean,
                     const float* rstd, int32_t act, int32_t NC, int32_t H, int32_t W, float* sums_ws, float* dy,
                     ap_stream_t stream);
+/* The same backward for a layer whose gradient is only ever read by the bf16 matrix kernels (round 4): instead of the fp32 dy the
+ * kernel writes the operands those kernels stage -- what ap_split_prepass and the weight gradient's own transposition would make
+ * of dy in two more passes over it (autograd of networks.py:2329-2421 through nn.InstanceNorm2d / nn.ReLU):
+ *   xs    the split-bf16 copy (ap_split_prepass layout and size; what the data-gradient ap_conv2d_fwd takes with desc.presplit), or NULL;
+ *   gt    the M-role operand of ap_conv2d_wgrad_pre, gt_dims = {GHp, GX8, Mp} from ap_conv2d_wgrad_gt_dims; slots outside the
+ *         H x W x C gradient must be zero on entry (they are not written), or NULL;
+ *   strip fp32 [N][C][2][H]: dy[:, :, :, W-2:] transposed (the small second operand of a reflection-padded layer's data gradient), or NULL;
+ *   dy    the fp32 gradient itself, or NULL.
+ * heads_only: the consumers multiply head parts only (AP_PRECISION_BF16): tail planes are not written.
+ * ap_instnorm_bwd_split_ok: 1 when the shape is served (C % 8 == 0, W % 8 == 0, H >= 3, H * W <= 4096, fold 0 or 1). */
+int ap_instnorm_bwd_split_ok(int32_t C, int32_t H, int32_t W, int32_t g1_pad);
+int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean, const float* rstd,
+                          int32_t act, int32_t N, int32_t C, int32_t H, int32_t W, void* xs, void* gt, const int32_t* gt_dims,
+                          float* strip, float* dy, int32_t heads_only, ap_stream_t stream);
+/* ap_conv2d_wgrad with its M-role operand g prepared by the producer (ap_instnorm_bwd_split): ap_conv2d_wgrad_gt_dims returns 1
+ * and the operand's {rows, pixel octets per row, padded channels} when the descriptor runs on the bf16 matrix kernel (the
+ * operand is N * 2 * rows * octets * channels 16-byte slots), 0 when it does not (then only ap_conv2d_wgrad serves it);
+ * d->g.data is not read by ap_conv2d_wgrad_pre. */
+int ap_conv2d_wgrad_gt_dims(const ap_wgrad_desc* d, int32_t* dims);
+int ap_conv2d_wgrad_pre(const ap_wgrad_desc* d, const void* g_t, float* workspace, float* dw, ap_stream_t stream);
 /* dy = (fold(g1) + g2) * act'(out) for layers without normalisation; act = NONE makes it a fold-and-add
  * (out may then be NULL).  AP_ACT_TANH: 1 - out^2; RELU / LRELU: from the sign of the activated output. */
 int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,

@@ -647,8 +647,13 @@ def test_graphed_frozen_nets_match_eager(dev, monkeypatch):
             x = torch.rand(shape, device=dev, generator=None)
             xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
             oa, ob = g(xa), pick(net(xb))
-            la = oa.sum() if torch.is_tensor(oa) else sum(t.abs().mean() for t in oa)
-            lb = ob.sum() if torch.is_tensor(ob) else sum(t.abs().mean() for t in ob)
+            ta, tb = ([oa], [ob]) if torch.is_tensor(oa) else (list(oa), list(ob))
+            # a LINEAR functional of the outputs (fixed weights): with |t| the gradient carries sign(t), and an output within
+            # rounding of zero flips it between two runs -- 2.6 % of the largest gradient element in one of four runs of round 4
+            ws = [torch.randn(t.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(11 + i)) / t.numel() ** 0.5
+                  for i, t in enumerate(tb)]
+            la = sum((t * w).sum() for t, w in zip(ta, ws))
+            lb = sum((t * w).sum() for t, w in zip(tb, ws))
             la.backward(); lb.backward()
             assert abs(float(la.detach()) - float(lb.detach())) <= 1e-4 * abs(float(lb.detach())) + 1e-6, it
             assert linf(xa.grad, xb.grad) <= 2e-3 * float(xb.grad.abs().max()) + 1e-9, it
