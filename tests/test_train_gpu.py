@@ -635,9 +635,8 @@ def test_train_step_with_reference_aux_architectures(dev, tmp_path, monkeypatch)
 
 def test_graphed_frozen_nets_match_eager(dev, monkeypatch):
     """aux_nets.GraphedFrozen (forward + backward of a frozen aux net as hipGraphs) == the eager module: outputs and the
-    gradient w.r.t. the input, on fresh inputs after the capture (the graph reads its static buffers, not stale data).  MIOpen may
-    pick different convolution algorithms inside and outside a capture (one of three runs of round 4 differed beyond 1e-5), so
-    the bars are those of fp32 rounding through ~50 layers; stale inputs would be off by O(1)."""
+    gradient w.r.t. the input, on fresh inputs after the capture (the graph reads its static buffers, not stale data: those
+    would be off by O(1))."""
     from animateportrait_amd import aux_nets
     torch.manual_seed(1)
     for net, shape, pick in ((aux_nets.MobileFaceNet(), (4, 3, 112, 112), lambda o: o[0]), (aux_nets.Sphere20a(), (2, 3, 112, 96), tuple)):
@@ -656,7 +655,13 @@ def test_graphed_frozen_nets_match_eager(dev, monkeypatch):
             lb = sum((t * w).sum() for t, w in zip(tb, ws))
             la.backward(); lb.backward()
             assert abs(float(la.detach()) - float(lb.detach())) <= 1e-4 * abs(float(lb.detach())) + 1e-6, it
-            assert linf(xa.grad, xb.grad) <= 2e-3 * float(xb.grad.abs().max()) + 1e-9, it
+            # MIOpen picks its algorithms by timing them, so eager and captured runs (and two processes) round differently; a
+            # PReLU / ReLU input within that rounding of zero then switches slope in one run only and moves the input gradient
+            # in its receptive field (seen: 0.9 % of the largest element, 2 of 6 runs).  Sparse by nature: bound the L2 error
+            # tightly and the largest element loosely.
+            d = (xa.grad - xb.grad).double()
+            assert float(d.norm()) <= 2e-3 * float(xb.grad.double().norm()), it
+            assert float(d.abs().max()) <= 5e-2 * float(xb.grad.abs().max()), it
         assert len(g._graphs) == 1
         with torch.no_grad():                       # no gradient wanted: eager path, same values
             o = g(x)
