@@ -41,8 +41,26 @@ PRECISION_BY_NAME = {'fp32': PRECISION_FP32, 'bf16x3': PRECISION_BF16X3, 'bf16':
 DEFAULT_PRECISION = PRECISION_BY_NAME.get(os.environ.get('APAMD_PRECISION', 'bf16x3'), PRECISION_BF16X3)
 
 
+_LAST_STREAM = {}          # device index -> torch stream of this package's previous launch
+_STREAM_FENCE = os.environ.get('APAMD_NO_STREAM_FENCE', '0') != '1'
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The stream a launch goes to (torch's current one) -- and the fence of DESIGN.md section 3.9: no two kernels of this library
+    may share compute units, or the second one can compute wrong values.  Callers that move between streams (graph capture warm-ups,
+    user side streams) are therefore serialised HERE: when the current stream differs from the one of the previous launch on this
+    device, it first waits for an event recorded behind that launch.  Costs nothing while the stream stays the same; inside a
+    stream capture no foreign event may be waited for, so captures start from a synchronised device (flow_unet_hip, aux_nets)."""
+    s = torch.cuda.current_stream()
+    if _STREAM_FENCE:
+        dev = s.device.index
+        last = _LAST_STREAM.get(dev)
+        if last is not None and last.cuda_stream != s.cuda_stream and not torch.cuda.is_current_stream_capturing():
+            ev = torch.cuda.Event()
+            ev.record(last)
+            s.wait_event(ev)
+        _LAST_STREAM[dev] = s
+    return ctypes.c_void_p(s.cuda_stream)
 
 
 def _ptr(t):

@@ -1237,3 +1237,29 @@ def test_conv_with_in_kernel_instancenorm(dev, n, act, res, monkeypatch):
     raw = layer.run(src, norm_act=act)
     old = ops.materialize(raw, residual=ops.Feat(r.to(dev)) if r is not None else None)
     assert linf(got, old.data) < 2e-5 * scale
+
+
+def test_launches_on_different_streams_are_fenced(dev):
+    """ops._stream(): a launch on another stream than the previous one waits for it (kernels of this
+    library must not share compute units).  A chain of convolutions issued on stream A and consumed on stream B WITHOUT any wait
+    by the caller must therefore give the serial result, bit for bit."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    torch.manual_seed(3)
+    layers = [ConvLayer([64], 64, 3, 1, 1, ops.PAD_REFLECT, False, 0).to(dev) for _ in range(4)]
+    x = torch.randn(8, 64, 64, 64, device=dev)
+
+    def chain(f, ls):
+        for l in ls:
+            f = l.run([f], norm_act=ops.ACT_RELU)
+        return f
+    ref = ops.materialize(chain(ops.Feat(x), layers)).data.clone()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    for _ in range(5):
+        with torch.cuda.stream(a):
+            mid = chain(ops.Feat(x), layers[:3])
+        with torch.cuda.stream(b):                 # no wait_stream / event here: the package fences its own launches
+            out = ops.materialize(chain(mid, layers[3:])).data
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
