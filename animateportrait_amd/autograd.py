@@ -238,7 +238,7 @@ def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE, out_octet=False
 
 
 def materialize_forward(tape, f, residual=None):
-    out = ops.materialize(f, residual=residual)
+    out = ops.materialize(f, residual=residual, keep_fp32=tape is not None)
     if tape is not None:
         tape.track(out)
 

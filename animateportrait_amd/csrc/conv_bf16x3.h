@@ -961,6 +961,8 @@ struct NormSplitParams {
     const float* res;         // residual [N, C, HW] or null
     const float* res_mean;    // its statistics or null (plain residual)
     const float* res_rstd;
+    const uint4* res_xs;      // or: the residual as its split copy (head + tail planes; inference keeps the residual stream of
+                              // the ResNet trunk only in that form, 2^-17 relative per block) -- then res is null
     float* y;                 // fp32 output or null
     uint4* xs;                // split output or null
     int heads_only;           // 1: only the head planes of xs are written (consumers in AP_PRECISION_BF16 never read tails)
@@ -1084,6 +1086,24 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
             }
         }
     }
+    if (p.res_xs != nullptr && live) {
+        const uint4* rh = p.res_xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1) + pix;
+        const uint4* rl = p.res_xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1) + pix;
+        uint4 hq[VEC], lq[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { hq[j] = rh[j]; lq[j] = rl[j]; }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const unsigned hw_[4] = {hq[j].x, hq[j].y, hq[j].z, hq[j].w}, lw_[4] = {lq[j].x, lq[j].y, lq[j].z, lq[j].w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                // a bf16 is the upper half of the fp32 with the same value
+                const unsigned hb = (c & 1) ? (hw_[c >> 1] & 0xffff0000u) : (hw_[c >> 1] << 16);
+                const unsigned lb = (c & 1) ? (lw_[c >> 1] & 0xffff0000u) : (lw_[c >> 1] << 16);
+                rv[c][j] = __uint_as_float(hb) + __uint_as_float(lb);
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         if (!live) continue;
@@ -1093,7 +1113,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
         for (int j = 0; j < VEC; ++j) {
             float t = normed ? (v[c][j] - m) * r : v[c][j];
             t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-            if (p.res != nullptr) t += (rv[c][j] - rm[c]) * rr[c];
+            if (p.res != nullptr || p.res_xs != nullptr) t += (rv[c][j] - rm[c]) * rr[c];
             v[c][j] = t;
         }
         if (p.y != nullptr) {

@@ -634,6 +634,11 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
     p.mean_out = mean_out; p.rstd_out = rstd_out;
     p.act = src->act;
     if (residual) { p.res = residual->data; p.res_mean = residual->mean; p.res_rstd = residual->rstd; }
+    if (flags & 4) {            // the residual is handed over as its split copy (head + tail planes)
+        if (!residual || residual->mean) return fail(AP_ERR_INVALID, "norm_apply_split: a split-copy residual must be a plain feature");
+        p.res_xs = reinterpret_cast<const uint4*>(residual->data);
+        p.res = nullptr;
+    }
     p.y = y; p.xs = reinterpret_cast<uint4*>(xs);
     p.heads_only = (flags & 1) ? 1 : 0;
     p.xs_relu = (flags & 2) ? 1 : 0;

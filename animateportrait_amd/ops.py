@@ -470,20 +470,29 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
     elif f._mean is not None:
         s.mean, s.rstd = f._mean.data_ptr(), f._rstd.data_ptr()
     r = None
+    res_flag = 0
     if residual is not None:
         if residual.act != ACT_NONE and residual.virtual:
             raise ValueError('a normalised residual cannot carry an activation')
         if residual.data.shape != x.shape:
             raise ValueError('residual shape mismatch')
         r = C.ApSrc()
-        r.data, r.C, r.act = residual.data.data_ptr(), c, ACT_NONE
-        if residual.virtual:
-            r.mean, r.rstd = residual.mean.data_ptr(), residual.rstd.data_ptr()
+        r.C, r.act = c, ACT_NONE
+        if residual.is_split_only:
+            # the residual exists only as its split copy (materialize(keep_fp32=False) of the previous block): head + tail
+            if residual.xs is None or residual.xs_heads_only:
+                raise RuntimeError('a split-only residual needs both planes of its split copy')
+            r.data = residual.xs.data_ptr()
+            res_flag = 4
+        else:
+            r.data = residual.data.data_ptr()
+            if residual.virtual:
+                r.mean, r.rstd = residual.mean.data_ptr(), residual.rstd.data_ptr()
     y = torch.empty_like(x) if want_y else None
     xs = _alloc_xs(x) if want_xs else None
     # plain-bf16 mode: no kernel reads tail planes, so they are not written (the package-wide mode decides: split
     # copies are shared by every consumer of a feature)
-    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0)
+    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0) | res_flag
     C.check(C.lib().ap_norm_apply_split_ex(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
                                            ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
                                            flags, _stream()), 'norm_apply_split')
@@ -596,6 +605,11 @@ def _zero_counters(n, device):
 # bursts its (larger) output at the same moment and the matrix pipe idles meanwhile: 2131 vs 2110 and 2207 vs 2204 frames/s on two
 # boxes.  Not worth a kernel that waits on its peers by default.
 FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
+
+
+# Inference: the ResNet trunk's residual stream kept only as split copies (materialize keep_fp32=False).  APAMD_RESIDUAL_FP32=1
+# restores the fp32 stream (A/B).
+RESIDUAL_AS_SPLIT = os.environ.get('APAMD_RESIDUAL_FP32', '0') != '1'
 
 
 def fused_norm_ok(spec, srcs):
@@ -729,18 +743,23 @@ def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None):
     return out
 
 
-def materialize(f, residual=None, emit_xs=None):
+def materialize(f, residual=None, emit_xs=None, keep_fp32=True):
     """out = act(IN(f.data)) [+ residual]; residual may itself be a virtual Feat (act must be NONE).
     emit_xs: also write the split-bf16 copy of ``out`` in the same pass (default: when a split-bf16 convolution
-    can consume it)."""
+    can consume it).  keep_fp32=False (inference, fp32-class mode): when the split copy is written the fp32 tensor is not --
+    the result exists only as its split copy (head + tail, 2^-17 relative), which is also what the next block's residual add
+    reads (RESIDUAL_AS_SPLIT; the trunk's nine fp32 writes of 67 MB each at B = 16 disappear)."""
     if not f.virtual:
         raise ValueError('materialize: feature is already plain')
     n, c, h, w = f.data.shape
     if emit_xs is None:
         emit_xs = wants_split(c)
     if c % 8 == 0:
-        y, xs = _norm_apply_split(f, residual, want_y=True, want_xs=bool(emit_xs))
-        out = Feat(y)
+        split_only = bool(emit_xs) and not keep_fp32 and RESIDUAL_AS_SPLIT and DEFAULT_PRECISION == PRECISION_BF16X3
+        if residual is not None and residual.is_split_only and not split_only and residual.xs_heads_only:
+            raise RuntimeError('materialize: the residual exists only as a head-only split copy')
+        y, xs = _norm_apply_split(f, residual, want_y=not split_only, want_xs=bool(emit_xs))
+        out = Feat.split_only((n, c, h, w), xs) if split_only else Feat(y)
         out.xs = xs
         out.xs_heads_only = xs is not None and DEFAULT_PRECISION == PRECISION_BF16
         return out

@@ -230,7 +230,10 @@ int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t t
                         ap_stream_t stream);
 /* ... with flags: bit 0 = write the head planes of xs only (every consumer runs in AP_PRECISION_BF16 and never reads the
  * tails: a quarter of the pass's HBM traffic); bit 1 = xs holds relu(v) while y holds v (the `activation -> conv` input of the
- * next layer of a pre-activation residual stream: ResidualBlock of intrinsic_flow_models/networks.py:26-60) */
+ * next layer of a pre-activation residual stream: ResidualBlock of intrinsic_flow_models/networks.py:26-60); bit 2 =
+ * residual->data is the residual's SPLIT COPY (head + tail planes, ap_split_prepass layout; mean / rstd must be NULL): in
+ * inference the residual stream of the ResNet trunk (x + conv_block(x), networks.py:2358-2360) then lives only in the form the
+ * next convolution stages, and the fp32 output y is not needed (pass NULL) */
 int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
                            float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
                            int32_t flags, ap_stream_t stream);

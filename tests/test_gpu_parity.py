@@ -1263,3 +1263,35 @@ def test_launches_on_different_streams_are_fenced(dev):
             out = ops.materialize(chain(mid, layers[3:])).data
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+def test_residual_stream_as_split_copies(dev):
+    """Inference keeps the ResNet trunk's residual stream only as split copies (ops.materialize keep_fp32=False; the next block's
+    residual add reads head + tail: ap_norm_apply_split_ex flags bit 2).  Three blocks chained that way against the same blocks
+    with the fp32 stream: the split representation costs 2^-17 relative per block, nothing else."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ResnetBlock
+    torch.manual_seed(11)
+    blocks = [ResnetBlock(64).to(dev) for _ in range(3)]
+    x0 = torch.randn(3, 64, 40, 36, device=dev)
+
+    def run(as_split):
+        old = ops.RESIDUAL_AS_SPLIT
+        ops.RESIDUAL_AS_SPLIT = as_split
+        try:
+            x = ops.Feat(x0.clone())
+            for b in blocks:
+                x = b.run(x, None)
+            return x
+        finally:
+            ops.RESIDUAL_AS_SPLIT = old
+    a, b = run(True), run(False)
+    assert a.is_split_only and not b.is_split_only
+    # compare through the split copies (what the next convolution stages): heads + tails back to fp32
+    def unsplit(f):
+        n, c, h, w = f.data.shape
+        t = f.xs.view(torch.bfloat16).view(n, 2, c // 8, h * w + 1, 8)[:, :, :, :h * w].float()
+        return (t[:, 0] + t[:, 1]).permute(0, 1, 3, 2).reshape(n, c, h, w)
+    ya, yb = unsplit(a), unsplit(b)
+    assert linf(yb, b.data) <= 2 ** -16 * float(b.data.abs().max())
+    assert linf(ya, yb) <= 3e-5 * float(yb.abs().max())
