@@ -324,7 +324,6 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
     constexpr int NW = NT / 64;
     __shared__ float red[16][NW];
     __shared__ float tot[16];
-    extern __shared__ __attribute__((aligned(16))) uint4 stage[];     // [2][4][NT + 4]: store staging, see below
     const int tid0 = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W, W4 = W >> 2;
     const bool live = tid0 < HW / 4;
@@ -334,6 +333,9 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
     // them: the loads of the next item are issued right behind the stores of the current one (which are not waited for), so reads
     // and writes of a CU overlap and there is no drain + dispatch gap between items (first version, one item per workgroup:
     // 2.7 TB/s, profiles/r04x_train_bf16_bygrid.md; an explicit prefetch in front of the stores spilled 150-300 registers).
+    // Also tried: the slots staged through LDS so that every store instruction writes whole lines (as norm_split_kernel does for
+    // its 64-byte lane stride) -- 84.6 -> 95.2 us per launch (gpurun_out/r04ag_call.log): with ONE workgroup per CU the two extra
+    // barriers and 130 KB of LDS traffic cost more than the four-piece line writes, which the L2 merges anyway.
     for (int item = blockIdx.x; item < items; item += (int)gridDim.x) {
     const int n = item / CG, cg = item - n * CG, c0 = cg * 8;
     // (per-lane addresses are recomputed in every iteration from an opaque copy of the lane id: hoisted out of the loop they
@@ -446,67 +448,45 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
             d[H] = gv[c * 4 + 3];
         }
     }
-    // Stores.  A thread's slots are 4 consecutive ones of the item's span in either layout (xs: pixels 4 tid .. 4 tid + 3; gt: linear
-    // (octet, channel) index 4 tid .. 4 tid + 3 after the lane pair's exchange), i.e. a 64-byte lane stride -- stored directly,
-    // every cache line is written in four pieces by four instructions (3.5 TB/s).  As norm_split_kernel does, the slots go
-    // through LDS so that store k of lane T lands on slot k * NT + T: 1 KiB contiguous per wave, whole 128-byte lines of gt.
-    // Staging position of (thread i, slot j) = j * (NT + 4) + i: conflict-free both ways.
-    {
-        constexpr int LP = NT + 4;
-        uint4* const st_xs = stage;
-        uint4* const st_gt = stage + 4 * LP;
-        const int CG = p.C >> 3, W8 = W >> 3;
-        const bool odd = tid & 1;                  // the high quad of the pixel octet (W % 8 == 0: the pair shares a row)
-        const long long noct = (long long)p.GHp * p.GX8;
+    if (p.xs != nullptr) {
+        const int CG = p.C >> 3;
         for (int part = 0; part < nparts; ++part) {
-            if (part) __syncthreads();             // the head planes have left the staging buffers
-            if (p.xs != nullptr) {
+            uint4* plane = p.xs + ((long long)(n * 2 + part) * CG + cg) * (HW + 1);
+            if (live) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) v[c] = part ? bf16_tail(gv[c * 4 + j]) : gv[c * 4 + j];
-                    st_xs[j * LP + tid] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
-                                                     pack_bf16x2(v[6], v[7]));
+                    plane[tid * 4 + j] = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]),
+                                                    pack_bf16x2(v[6], v[7]));
                 }
             }
-            if (p.gt != nullptr) {
+            if (tid == 0) plane[HW] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+    if (p.gt != nullptr) {
+        const bool odd = tid & 1;                  // the high quad of the pixel octet (W % 8 == 0: the pair shares a row)
+        const long long noct = (long long)p.GHp * p.GX8;
+        const long long oct = (long long)row * p.GX8 + (x4 >> 3);
+        for (int part = 0; part < nparts; ++part) {
+            unsigned lo[8], hi[8];                 // per channel: pixels (0, 1), (2, 3) of this lane's quad
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    // channels k and 4 + k of this lane's quad, pixels (0, 1) and (2, 3) packed; the even lane keeps channels
-                    // 0..3 and gives 4..7, the odd lane the other way round
-                    float va[4], vb[4];
+            for (int c = 0; c < 8; ++c) {
+                float v[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        va[j] = part ? bf16_tail(gv[k * 4 + j]) : gv[k * 4 + j];
-                        vb[j] = part ? bf16_tail(gv[(4 + k) * 4 + j]) : gv[(4 + k) * 4 + j];
-                    }
-                    const unsigned lo_a = pack_bf16x2(va[0], va[1]), hi_a = pack_bf16x2(va[2], va[3]);
-                    const unsigned lo_b = pack_bf16x2(vb[0], vb[1]), hi_b = pack_bf16x2(vb[2], vb[3]);
-                    const unsigned give_lo = odd ? lo_a : lo_b, give_hi = odd ? hi_a : hi_b;
-                    const unsigned keep_lo = odd ? lo_b : lo_a, keep_hi = odd ? hi_b : hi_a;
-                    const unsigned got_lo = (unsigned)__shfl_xor((int)give_lo, 1, 64), got_hi = (unsigned)__shfl_xor((int)give_hi, 1, 64);
-                    st_gt[k * LP + tid] = odd ? make_uint4(got_lo, got_hi, keep_lo, keep_hi) : make_uint4(keep_lo, keep_hi, got_lo, got_hi);
-                }
+                for (int j = 0; j < 4; ++j) v[j] = part ? bf16_tail(gv[c * 4 + j]) : gv[c * 4 + j];
+                lo[c] = pack_bf16x2(v[0], v[1]);
+                hi[c] = pack_bf16x2(v[2], v[3]);
             }
-            __syncthreads();
-            if (p.xs != nullptr) {
-                uint4* plane = p.xs + ((long long)(n * 2 + part) * CG + cg) * (HW + 1);
+            uint4* dst = p.gt + ((long long)(n * 2 + part) * noct + oct) * p.Mp + c0 + (odd ? 4 : 0);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int g = k * NT + tid;                        // pixel of the plane
-                    if (g < HW) plane[g] = st_xs[(g & 3) * LP + (g >> 2)];
-                }
-                if (tid == 0) plane[HW] = make_uint4(0u, 0u, 0u, 0u);
-            }
-            if (p.gt != nullptr) {
-                uint4* base = p.gt + (long long)(n * 2 + part) * noct * p.Mp + c0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int g = k * NT + tid;                        // (pixel octet of the plane, channel of the group)
-                    const int o = g >> 3, r8 = o / W8, x8 = o - r8 * W8;
-                    if (g < HW) base[((long long)r8 * p.GX8 + x8) * p.Mp + (g & 7)] = st_gt[(g & 3) * LP + (g >> 2)];
-                }
+            for (int k = 0; k < 4; ++k) {
+                // the even lane keeps channels 0..3 and gives 4..7, the odd lane the other way round
+                const unsigned give_lo = odd ? lo[k] : lo[4 + k], give_hi = odd ? hi[k] : hi[4 + k];
+                const unsigned keep_lo = odd ? lo[4 + k] : lo[k], keep_hi = odd ? hi[4 + k] : hi[k];
+                const unsigned got_lo = (unsigned)__shfl_xor((int)give_lo, 1, 64), got_hi = (unsigned)__shfl_xor((int)give_hi, 1, 64);
+                if (live) dst[k] = odd ? make_uint4(got_lo, got_hi, keep_lo, keep_hi) : make_uint4(keep_lo, keep_hi, got_lo, got_hi);
             }
         }
     }
@@ -835,16 +815,8 @@ int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, cons
     const bool small = H * W / 4 <= 256;
     const int slots = cus * (small ? 4 : 1);          // resident workgroups: registers hold one 1024-thread item per CU, four of 256
     const dim3 grid(items < slots ? items : slots);
-    const size_t lds = (size_t)2 * 4 * ((small ? 256 : 1024) + 4) * sizeof(uint4);
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_split_kernel<1024>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 4 * 1028 * sizeof(uint4)));
-        if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr = true;
-    }
-    if (small) hipLaunchKernelGGL(instnorm_bwd_split_kernel<256>, grid, dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(instnorm_bwd_split_kernel<1024>, grid, dim3(1024), lds, (hipStream_t)stream, p);
+    if (small) hipLaunchKernelGGL(instnorm_bwd_split_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(instnorm_bwd_split_kernel<1024>, grid, dim3(1024), 0, (hipStream_t)stream, p);
     return check_launch("instnorm_bwd_split_kernel");
 }
 

@@ -276,7 +276,9 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     // Used for the 4x4 layers (MT = 1: 22 instead of 40 ds_read_b128 per tap column, 196 -> 170..185 us on the
     // PatchGAN's 256 -> 512 layer); the 3x3 kernel (MT = 2: 72 instead of 108 per chunk) measured no faster with it --
     // its fragment reads already hide under the MFMAs -- and keeps the plain tap order.
-    constexpr bool WIN = K == 4 && !C::ROW && S == 1;
+    // ... with ONE product per tap (plain bf16, PARTS = 1) it is the other way round: 6 fragment reads per 8 MFMAs and 8 waves on
+    // a CU's LDS port keep that port ~75 % busy, so the head-only 3x3 kernel takes the window too (36 instead of 54 reads per chunk).
+    constexpr bool WIN = (K == 4 || (K == 3 && C::PARTS == 1 && NT > 1)) && !C::ROW && S == 1;
     constexpr int WR = WIN ? NT + K - 1 : 1;
     bf16x8 wh[2][WR], wl[2][WR];                                   // [kx parity][window row]
     auto fetch_a = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {
