@@ -304,6 +304,15 @@ class MODNet(nn.Module):
     def forward(self, img, inference=True):
         if self.fast_layout and img.is_cuda:
             img = img.contiguous(memory_format=torch.channels_last)
+            # ... and MIOpen may TIME its algorithms for this net's shapes once instead of taking its immediate-mode pick
+            # (8.8 -> 7.1 ms at B = 16, tools/aux_find_bench.py; MobileFaceNet / Sphere20a do not move).  Scoped to this call.
+            bk = torch.backends.cudnn
+            with bk.flags(enabled=bk.enabled, benchmark=not os.environ.get('APAMD_NO_MIOPEN_FIND'),
+                          deterministic=bk.deterministic, allow_tf32=bk.allow_tf32):
+                return self._forward(img, inference)
+        return self._forward(img, inference)
+
+    def _forward(self, img, inference):
         sem, lr8x, enc2x, enc4x = self.lr_branch(img, inference)
         detail, hr2x = self.hr_branch(img, enc2x, enc4x, lr8x, inference)
         return sem, detail, self.f_branch(img, lr8x, hr2x).contiguous()
