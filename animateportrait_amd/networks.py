@@ -129,7 +129,7 @@ class ResnetBlock(nn.Module):
 
     def run(self, x, tape=None):
         c1, c5 = self.conv_block['1'], self.conv_block['5']
-        if tape is None and not x.virtual and c1.fused_norm_ok(x):
+        if tape is None and not x.virtual and not x.is_split_only and c1.fused_norm_ok(x):
             # inference: each convolution normalises its own output in the epilogue (ap_conv2d_fwd_norm) -- no raw fp32 output,
             # no norm_split pass; the block's result lives as the split copy (next convolution) + channel-octet fp32 (next residual)
             y = c1.run_norm(x, act=ACT_RELU)

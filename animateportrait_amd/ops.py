@@ -755,7 +755,9 @@ def materialize(f, residual=None, emit_xs=None, keep_fp32=True):
     if emit_xs is None:
         emit_xs = wants_split(c)
     if c % 8 == 0:
-        split_only = bool(emit_xs) and not keep_fp32 and RESIDUAL_AS_SPLIT and DEFAULT_PRECISION == PRECISION_BF16X3
+        # (with the opt-in in-kernel InstanceNorm the next block's fused epilogue reads its residual as fp32: keep it)
+        split_only = (bool(emit_xs) and not keep_fp32 and RESIDUAL_AS_SPLIT and not FUSED_NORM and
+                      DEFAULT_PRECISION == PRECISION_BF16X3)
         if residual is not None and residual.is_split_only and not split_only and residual.xs_heads_only:
             raise RuntimeError('materialize: the residual exists only as a head-only split copy')
         y, xs = _norm_apply_split(f, residual, want_y=not split_only, want_xs=bool(emit_xs))

@@ -1247,6 +1247,8 @@ def test_launches_on_different_streams_are_fenced(dev):
     from animateportrait_amd.networks import ConvLayer
     torch.manual_seed(3)
     layers = [ConvLayer([64], 64, 3, 1, 1, ops.PAD_REFLECT, False, 0).to(dev) for _ in range(4)]
+    for l in layers:                                     # (ConvLayer weights are torch.empty until init_net runs)
+        torch.nn.init.normal_(l.weight, 0.0, 0.05)
     x = torch.randn(8, 64, 64, 64, device=dev)
 
     def chain(f, ls):
@@ -1273,6 +1275,9 @@ def test_residual_stream_as_split_copies(dev):
     from animateportrait_amd.networks import ResnetBlock
     torch.manual_seed(11)
     blocks = [ResnetBlock(64).to(dev) for _ in range(3)]
+    for blk in blocks:                                   # (ConvLayer parameters are uninitialised until init_net runs)
+        for p_ in blk.parameters():
+            torch.nn.init.normal_(p_, 0.0, 0.05)
     x0 = torch.randn(3, 64, 40, 36, device=dev)
 
     def run(as_split):
