@@ -7,6 +7,8 @@ backward replays it in reverse, launching the data-gradient (the forward conv ke
 roles), weight-gradient, InstanceNorm/activation-backward and warp-backward kernels of libapamd.so.
 PyTorch only carries the resulting tensors to the optimiser / the collective.
 """
+import os
+
 import torch
 
 from . import ops
@@ -152,7 +154,25 @@ def _split_backward_plan(tape, layer, srcs, out, contribs):
         return None
     n, c, h, w = out.data.shape
     pads = sorted(p for _, p in contribs if p > 0)
-    if (pads and pads[-1] > 1) or not ops.instnorm_bwd_split_ok(out, 1 if pads else 0):
+    if pads and pads[-1] > 1:
+        return None
+    # the decision depends on shapes and on who wants a gradient, not on values: kept per layer (a handful of C-side plan queries
+    # per layer and step otherwise)
+    key = (n, c, h, w, bool(pads), layer.weight.requires_grad, tuple(tape.tracked(f) for f in srcs),
+           tuple(tuple(f.data.shape) for f in srcs), s.precision, ops.DEFAULT_PRECISION, os.environ.get('APAMD_NO_INBWD_SPLIT'))
+    cache = layer.__dict__.setdefault('_split_bwd_plans', {})
+    if key not in cache:
+        cache[key] = _split_backward_decision(tape, layer, srcs, out, bool(pads))
+    dec = cache[key]
+    if dec is None:
+        return None
+    return (ops._split_contribs(contribs),) + dec
+
+
+def _split_backward_decision(tape, layer, srcs, out, folded):
+    s = layer.spec
+    n, c, h, w = out.data.shape
+    if not ops.instnorm_bwd_split_ok(out, 1 if folded else 0):
         return None
     gt_dims = None
     if layer.weight.requires_grad:
@@ -170,7 +190,7 @@ def _split_backward_plan(tape, layer, srcs, out, contribs):
             want_strip = want_strip or bool(fold_pad and ops.dgrad_strip_eligible(spec, probe))
     if gt_dims is None and not want_xs:
         return None
-    return ops._split_contribs(contribs), gt_dims, want_xs, want_strip
+    return gt_dims, want_xs, want_strip
 
 
 def conv_backward(tape, layer, srcs, out, norm, act):
