@@ -25,6 +25,7 @@
 //   * epilogue identical to the fp32 kernel (bias, activation, InstanceNorm partial statistics).
 #pragma once
 #include <type_traits>
+#include <utility>
 
 #include "conv_igemm.h"
 
@@ -109,7 +110,24 @@ __device__ __forceinline__ void glds16_sv(const void* sbase, unsigned voff, unsi
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_addr)
                  : "memory", "m0");
 }
+// The same with the LDS address as scalar base + compile-time offset: one s_add into M0 per piece.  (Passing each piece's
+// LDS address as a value kept 19 scalars alive per stage; with ~100 SGPRs in use the compiler spilled them into VGPR lanes
+// and read them back with v_readlane in front of every piece: profiles/r05_dominant_cycle_account.md.)
+template <int IMM>
+__device__ __forceinline__ void glds16_si(const void* sbase, unsigned voff, unsigned lds_base) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM)
+                 : "memory", "m0", "scc");
+}
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <class F, int... J>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, J...>) {
+    (f(std::integral_constant<int, J>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 // seg[s].data of the bf16x3 kernel points to an XS tensor (see split_prepass_kernel); seg[s].C = channels.
 // Launch with min(#tiles, #CUs) workgroups of 256 threads; needs nchunks >= 2.
@@ -138,6 +156,50 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     uint4* const wbuf = smem;                                  // + b * STAGE
     uint4* const xbuf = smem + W_SLOTS;                        // + b * STAGE
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+
+#ifdef APAMD_ABLATION
+    // ---- cycle account (experiment build; tools/cycle_account.py): lane 0 of every wave records (code, s_memtime) pairs in LDS.
+    // code = kind | chunk << 8 | tile ordinal << 16.  An s_memtime result is awaited with lgkmcnt(0) inside the same asm
+    // statement (the compiler does not know the instruction is a scalar memory read).
+    const bool stamping = p.stamps != nullptr;
+    unsigned* const stamp_lds = reinterpret_cast<unsigned*>(smem_raw + p.stamp_lds_off) + wave * p.stamp_words;
+    int stamp_n = 0, stamp_tile = 0;
+    auto stamp_put = [&](unsigned kind, int c, unsigned long long t) __attribute__((always_inline)) {
+        if (lane == 0 && stamp_n + 2 <= p.stamp_words) {
+            stamp_lds[stamp_n] = kind | ((unsigned)c << 8) | ((unsigned)stamp_tile << 16);
+            stamp_lds[stamp_n + 1] = (unsigned)t;
+        }
+        stamp_n += 2;
+    };
+    auto stamp_now = [&](unsigned kind, int c) __attribute__((always_inline)) {
+        if (!stamping) return;
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        stamp_put(kind, c, t);
+    };
+    // the stage's one synchronisation point, stamped: arrival (0), DMA of the next stage landed (1), barrier passed (2)
+    auto stage_sync = [&](int c) __attribute__((always_inline)) {
+        if (!stamping) {
+            dma_wait_all();
+            if (!AP_ABLATE(p, 2)) __syncthreads();
+            return;
+        }
+        unsigned long long ta, tb, tc;
+        asm volatile("s_memtime %0\n\ts_waitcnt vmcnt(0)\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"
+                     "s_memtime %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(ta), "=&s"(tb), "=&s"(tc)::"memory");
+        stamp_put(0, c, ta);
+        stamp_put(1, c, tb);
+        stamp_put(2, c, tc);
+    };
+#define AP_STAMP(kind, c) stamp_now(kind, c)
+#else
+    auto stage_sync = [&](int) __attribute__((always_inline)) {
+        dma_wait_all();
+        __syncthreads();
+    };
+#define AP_STAMP(kind, c) ((void)0)
+#endif
 
     // ---- this workgroup's tiles.  Workgroup b runs on XCD b % 8; each XCD owns a contiguous range of the tile
     // list (cout tile fastest, so the workgroups of an XCD share activation tiles through its L2) and its
@@ -217,8 +279,6 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
         const unsigned char* xl;   // ... and tail plane
         const unsigned char* wsrc; // the (cout tile, chunk) weight block (scalar)
         unsigned xdst, wdst;       // LDS byte addresses of the stage's activation / weight images (this wave's lane 0)
-        bool real;                 // false: the padding chunk of an odd count -- its weights are zero, the activation
-                                   // image keeps whatever finite data the buffer held two stages ago
         unsigned wmask;            // S2D3: taps of the chunk's input phase -- the weight pieces of the others are not staged (the
                                    // stage never reads them).  With the fragment reads of absent taps gone the kernel is bound by
                                    // the LDS-DMA (1.15 MB per CU against 27 k MFMA cycles, profiles/r04p_pmc_*): 19 % fewer bytes
@@ -227,41 +287,48 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     unsigned woff[NWP];            // byte offset of this lane's slot in weight piece j
 #pragma unroll
     for (int j = 0; j < NWP; ++j) woff[j] = ((j * 4 + wave) * 64 + lane) * 16;
+    // The scalar part of a stage's addresses, computed ONCE per stage and pinned in SGPRs (the empty asm): left to itself the
+    // compiler re-derived the 64-bit plane address in front of every piece (ten scalar multiplies / adds per piece).
+    // The padding chunk of an odd count (chunk_ >= nreal: its weights are all zero) stages the last real chunk's activations
+    // again -- finite data, so the products are exact zeros -- instead of skipping its pieces under a per-piece branch.
     auto dma_setup = [&](int n, int cot, int chunk_, int buf) __attribute__((always_inline)) {
-        DmaCtx d;
-        d.real = chunk_ < nreal;
-        const int chunk = d.real ? chunk_ : nreal - 1;
+        const int chunk = chunk_ < nreal ? chunk_ : nreal - 1;
         const int s = seg_of(chunk);
         const int cg0 = (chunk - p.seg[s].chunk_begin) * 2;          // first channel group of the chunk
         const int CG = p.seg[s].C >> 3;
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
-        d.xh = xs + ((long long)(n * 2 + 0) * CG + cg0) * (HW + 1) * 16;
-        d.xl = xs + ((long long)(n * 2 + 1) * CG + cg0) * (HW + 1) * 16;
-        d.xdst = lds0 + (buf * STAGE + W_SLOTS + wave * 64) * 16;
-        d.wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
-        d.wdst = lds0 + (buf * STAGE + wave * 64) * 16;
-        d.wmask = 0xFu;
-        if constexpr (C::S2D3) d.wmask = p.s2d_mask[chunk_ / p.s2d_div < 3 ? chunk_ / p.s2d_div : 3];
-        return d;
+        const unsigned char* xh = xs + ((long long)(n * 2 + 0) * CG + cg0) * (HW + 1) * 16;
+        const unsigned char* xl = xs + ((long long)(n * 2 + 1) * CG + cg0) * (HW + 1) * 16;
+        unsigned xdst = lds0 + (buf * STAGE + W_SLOTS + wave * 64) * 16;
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
+        unsigned wdst = lds0 + (buf * STAGE + wave * 64) * 16;
+        unsigned wmask = 0xFu;
+        if constexpr (C::S2D3) wmask = p.s2d_mask[chunk_ / p.s2d_div < 3 ? chunk_ / p.s2d_div : 3];
+        asm volatile("" : "+s"(xh), "+s"(xl), "+s"(wsrc), "+s"(xdst), "+s"(wdst));
+        return DmaCtx{xh, xl, wsrc, xdst, wdst, wmask};
     };
-    auto dma_piece = [&](const DmaCtx& d, const int (&goff)[NIT], int j) __attribute__((always_inline)) {
-        if (j < PARTS * NIT) {
-            const int part = j / NIT, k = j % NIT;
-            // wave-uniform conditions: a real chunk, and the whole piece inside the part
-            if (d.real && (k * 256 + 3 * 64 < XP || k * 256 + wave * 64 < XP))
-                glds16_sv(part ? d.xl : d.xh, (unsigned)goff[k], d.xdst + (part * XP + k * 256) * 16);
+    // piece j (a compile-time index): {s_add m0; global_load_lds v_off, s[base]} -- nothing else
+    // (alt / use_alt: the tile's tail stage takes the NEXT tile's offsets; selected here, per piece, on registers -- a
+    // selected copy of the array was kept in scratch memory)
+    auto dma_piece = [&](const DmaCtx& d, const int (&goff)[NIT], const int (&alt)[NIT], bool use_alt, auto jt) __attribute__((always_inline)) {
+        constexpr int j = decltype(jt)::value;
+        if constexpr (j < PARTS * NIT) {
+            constexpr int part = j / NIT, k = j % NIT;
+            constexpr bool whole = k * 256 + 3 * 64 < XP;           // every wave's slice of the piece lies inside the part
+            if (whole || k * 256 + wave * 64 < XP)                  // (wave-uniform)
+                glds16_si<(part * XP + k * 256) * 16>(part ? d.xl : d.xh, (unsigned)(use_alt ? alt[k] : goff[k]), d.xdst);
         } else {
-            const int jj = j - PARTS * NIT;
-            bool want = jj * 4 + 3 < W_SLOTS / 64 || jj * 4 + wave < W_SLOTS / 64;
+            constexpr int jj = j - PARTS * NIT;
+            constexpr bool whole = jj * 4 + 3 < W_SLOTS / 64;
+            bool want = whole || jj * 4 + wave < W_SLOTS / 64;
             // weight image [part][tap][k-group][CO_TILE] in 64-slot pieces: piece -> tap (wave-uniform)
             if constexpr (C::S2D3) want = want && ((d.wmask >> (((jj * 4 + wave) % (T * 2 * CO_TILE / 64)) / (2 * CO_TILE / 64))) & 1u);
-            if (want) glds16_sv(d.wsrc, woff[jj], d.wdst + jj * 4096);
+            if (want) glds16_si<jj * 4096>(d.wsrc, woff[jj], d.wdst);
         }
     };
     auto issue = [&](const Bf3Tile& t, const int (&goff)[NIT], int chunk_, int buf) __attribute__((always_inline)) {
         const DmaCtx d = dma_setup(t.n, t.cot, chunk_, buf);
-#pragma unroll
-        for (int j = 0; j < NPIECE; ++j) dma_piece(d, goff, j);
+        static_for<NPIECE>([&](auto jt) __attribute__((always_inline)) { dma_piece(d, goff, goff, false, jt); });
     };
 
     // fragment addresses (16-byte slots)
@@ -349,10 +416,12 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     Bf3Tile cur, nxt;
     int cgoff[NIT], ngoff[NIT];
     locate(tile, cur, cgoff);
+    AP_STAMP(7, 0);                                                // kernel entry (tile geometry done)
     issue(cur, cgoff, 0, 0);
     issue(cur, cgoff, 1, 1);
     dma_wait_all();
     __syncthreads();
+    AP_STAMP(8, 0);                                                // first two stages landed
 
     // taps of the 2 x 2 window that exist for the current tile (fused sub-pixel phases; wave-uniform)
     auto tapmask_of = [&](const Bf3Tile& t) -> unsigned {
@@ -463,37 +532,46 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     // next stage (issued one stage ago) has landed once everybody is past the barrier.  The DMA
                     // pieces of stage c+2 (past the tile's end: chunk 0 of the next tile) and the fragment reads of
                     // the next stage's tap 0 are issued one per MFMA slot, so the matrix pipe keeps running.
-                    const bool do_fetch = c + 1 < nchunks;
+                    // The last stage of a tile issues nothing (its buffer becomes the epilogue's patch area); the last but one
+                    // stages chunk 0 of the NEXT tile -- without a next tile this tile's own chunk 0 again, which nobody reads:
+                    // an unconditional issue keeps the pieces free of branches.  What a piece may cost is decided here:
+                    // the scalar addresses are pinned in SGPRs by dma_setup, the per-lane offset is one select,
+                    // and the `more` test in front of a piece is a bare scalar branch.  (Before, the compiler put the branch, the
+                    // offset select and the re-derivation of the 64-bit source address -- ten scalar multiplies / adds and a
+                    // v_readlane of a spilled LDS address -- in front of EVERY piece: 74 cycles per MFMA slot of this tap
+                    // instead of 32, ~1000 cycles per stage, profiles/r05_dominant_cycle_account.md.)
+                    const bool more = c + 1 < nchunks;
                     const bool tail = c + 2 >= nchunks;
-                    const bool do_dma = do_fetch && !AP_ABLATE(p, 1) && (!tail || has_next);
-                    int ig[NIT];
-#pragma unroll
-                    for (int k = 0; k < NIT; ++k) ig[k] = tail ? ngoff[k] : cgoff[k];
                     const DmaCtx d = dma_setup(tail ? nxt.n : cur.n, tail ? nxt.cot : cur.cot, tail ? 0 : c + 2, P);
-                    dma_wait_all();
-                    if (!AP_ABLATE(p, 2)) __syncthreads();
+                    stage_sync(c);
                     constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
                     constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
                     constexpr int R0 = NM - (NRD + RPS - 1) / RPS;              // first slot that carries reads
                     const bool real_tap = K != 0 || ((tm >> tp) & 1u);
-#pragma unroll
-                    for (int i = 0; i < NM; ++i) {
+                    // (the MFMAs stay in straight-line code: with them inside the two arms of a branch the accumulators became phi
+                    // nodes and the allocator moved all 128 between AGPRs and VGPRs every stage)
+                    const bool dma = more && !AP_ABLATE(p, 1);
+                    static_for<NM>([&](auto it) __attribute__((always_inline)) {
+                        constexpr int i = decltype(it)::value;
                         if (real_tap) mfma_one(i);
-                        if (do_dma) {
+                        static_for<PPS>([&](auto ppt) __attribute__((always_inline)) {
+                            constexpr int j = i * PPS + decltype(ppt)::value;
+                            if constexpr (j < NPIECE) {
+                                if (dma) dma_piece(d, cgoff, ngoff, tail, std::integral_constant<int, j>{});
+                            }
+                        });
+                        if constexpr (XPF && i >= R0) {
+                            if (more) {
 #pragma unroll
-                            for (int pp = 0; pp < PPS; ++pp)
-                                if (i * PPS + pp < NPIECE) dma_piece(d, ig, i * PPS + pp);
-                        }
-                        if (XPF && do_fetch && i >= R0) {
-#pragma unroll
-                            for (int rr = 0; rr < RPS; ++rr)
-                                if ((i - R0) * RPS + rr < NRD) {
-                                    if constexpr (WIN) fetch_one_win(P ^ 1, cb ^ 1, ((K & 1) ? (P ^ 1) : 0) & 1, (i - R0) * RPS + rr);
-                                    else fetch_one(P ^ 1, 0, cb ^ 1, (i - R0) * RPS + rr);
-                                }
+                                for (int rr = 0; rr < RPS; ++rr)
+                                    if ((i - R0) * RPS + rr < NRD) {
+                                        if constexpr (WIN) fetch_one_win(P ^ 1, cb ^ 1, ((K & 1) ? (P ^ 1) : 0) & 1, (i - R0) * RPS + rr);
+                                        else fetch_one(P ^ 1, 0, cb ^ 1, (i - R0) * RPS + rr);
+                                    }
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                    }
+                    });
                 }
             }
         };
@@ -528,6 +606,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 stage(P1{}, std::integral_constant<unsigned, 0u>{}, c + 1);
             }
         }
+        AP_STAMP(3, 0);                                            // last MFMA issued
         constexpr int pl = 1;                                      // stage buffer of the last chunk: free now; the
                                                                    // next tile's chunk 0 sits in buffer 0 again
 
@@ -704,6 +783,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 }
             }
             }   // !octet
+            AP_STAMP(9, 0);                                        // rows transposed, stored, row sums formed
             if (want_stats) {
                 __syncthreads();
                 if (tid < CO_TILE) {
@@ -928,15 +1008,32 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
         } else {
             epilogue(std::integral_constant<int, -1>{});
         }
+        AP_STAMP(4, 0);                                            // epilogue done: every output store issued
         if (!has_next) break;
         __syncthreads();                                           // patches and statistics consumed: refill that stage
+        AP_STAMP(5, 0);
         if (!AP_ABLATE(p, 1)) issue(nxt, ngoff, 1, pl);
+        AP_STAMP(6, 0);                                            // the next tile's chunk 1 is on its way
+#ifdef APAMD_ABLATION
+        ++stamp_tile;
+#endif
         cur = nxt;
         tmask = tapmask_of(cur);
 #pragma unroll
         for (int k = 0; k < NIT; ++k) cgoff[k] = ngoff[k];
         tile += tile_step;
     }
+    dma_wait_all();                                                // (the last tile's tail stage staged a chunk nobody reads)
+#ifdef APAMD_ABLATION
+    if (stamping) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        AP_STAMP(10, 0);                                           // every store acknowledged
+        __syncthreads();
+        const unsigned* src = reinterpret_cast<const unsigned*>(smem_raw + p.stamp_lds_off);
+        for (int i = tid; i < 4 * p.stamp_words; i += 256) p.stamps[(long long)blockIdx.x * 4 * p.stamp_words + i] = src[i];
+    }
+#endif
+#undef AP_STAMP
 }
 
 // ---- activation pre-pass: XS[n][part][cg][HW + 1] (16-byte slots of 8 bf16) = split(act((x - mean) * rstd));

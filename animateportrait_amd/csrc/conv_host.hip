@@ -6,9 +6,7 @@
 #include "common.h"
 #include "conv_registry.h"
 #include "conv_direct.h"
-#include "conv_bf16x3.h"
-#include "conv_bf16x3_sb.h"
-#include "conv_ph4.h"
+#include "conv_bf3_registry.h"
 #include "conv_small.h"
 #include "conv_head.h"
 #include "conv_tsmall.h"
@@ -19,6 +17,10 @@
 #include <vector>
 
 namespace apamd {
+
+#ifdef APAMD_VARIANTS
+const void* bf3_sb_kernel(size_t* lds_bytes);     // tools/variants/conv_bf3_sb.hip
+#endif
 
 static thread_local char g_err[512];
 char* last_error_buf() { return g_err; }
@@ -50,61 +52,21 @@ static const ConvKernelInfo* find_kernel(int CI, int S, int K, int CO_TILE) {
     return nullptr;
 }
 
-// split-bf16 kernels (conv_bf16x3.h)
-struct Bf3Kernel {
-    int S, K, CO_TILE, TH, TMAX, ROW;
-    const void* fn;              // split-bf16 arithmetic (AP_PRECISION_BF16X3): head + tail staged, 3 MFMAs per product
-    int (*wfloats)(int);
-    size_t (*lds_bytes)(int);
-    const char* name;
-    const void* fn1;             // plain bf16 arithmetic (AP_PRECISION_BF16): the same tile with head parts only
-    size_t (*lds_bytes1)(int);
-    const void* fn_s2d3 = nullptr;    // the same tile with the compile-time tap sets of a space-to-depth 3x3 layer (Bf3Cfg::S2D3)
-    const void* fn1_s2d3 = nullptr;
-    const void* kernel(int precision) const { return precision == AP_PRECISION_BF16 ? fn1 : fn; }
-    const void* kernel_s2d3(int precision) const { return precision == AP_PRECISION_BF16 ? fn1_s2d3 : fn_s2d3; }
-    size_t lds(int precision, int ntaps) const { return precision == AP_PRECISION_BF16 ? lds_bytes1(ntaps) : lds_bytes(ntaps); }
-};
-template <int S, int K, int WCO, int MT, int WPX, int NT, int NTAP = 0, int ROW = 0>
-static Bf3Kernel bk2(const char* name) {
-    using C = Bf3Cfg<S, K, WCO, MT, WPX, NT, NTAP, ROW, 2>;
-    using C1 = Bf3Cfg<S, K, WCO, MT, WPX, NT, NTAP, ROW, 1>;
-    return Bf3Kernel{C::S, C::K, C::CO_TILE, C::TH, C::TMAX, C::ROW, reinterpret_cast<const void*>(&conv_bf16x3<C>),
-                     &C::wfloats, &C::lds_bytes, name, reinterpret_cast<const void*>(&conv_bf16x3<C1>), &C1::lds_bytes};
-}
-// the four phases of a stride-2 transposed layer in one tile (conv_ph4.h): 32 couts x 8 rows x 4 phases
-template <int KK>
-static const Bf3Kernel* ph4_kernel() {
-    using C = Ph4Cfg<KK, 2>;
-    using C1 = Ph4Cfg<KK, 1>;
-    static const Bf3Kernel k{1, 0, C::CO_TILE, C::TH, 4, 0, reinterpret_cast<const void*>(&conv_ph4<C>), &C::wfloats, &C::lds_bytes,
-                             KK == 3 ? "Ph4Cfg<3>" : "Ph4Cfg<4>", reinterpret_cast<const void*>(&conv_ph4<C1>), &C1::lds_bytes};
-    return &k;
-}
+// split-bf16 kernels (conv_bf16x3.h, conv_ph4.h): instantiated per tile family in conv_bf3_inst_*.hip / conv_ph4_inst.hip
 static const std::vector<Bf3Kernel>& bf3_registry() {
-    static std::vector<Bf3Kernel> v = {
-        bk2<1, 3, 1, 2, 4, 1>("Bf3Cfg<1, 3, 1, 2, 4, 1>"),      // 3x3 s1, small batches: 64 couts x 4 rows
-        bk2<1, 3, 1, 2, 4, 4>("Bf3Cfg<1, 3, 1, 2, 4, 4>"),      // 3x3 s1: 64 couts x 16 rows
-        bk2<2, 3, 2, 1, 2, 2>("Bf3Cfg<2, 3, 2, 1, 2, 2>"),      // 3x3 s2: 64 couts x 4 rows
-        bk2<1, 4, 1, 1, 4, 4>("Bf3Cfg<1, 4, 1, 1, 4, 4>"),      // 4x4 s1 (PatchGAN): 16 taps -> 32-cout tiles
-        bk2<1, 7, 1, 2, 4, 4, 0, 1>("Bf3Cfg<1, 7, 1, 2, 4, 4, 0, 1>"),   // 1x7 over row channels (7x7 stems)
-        // ... and its half-size tile (32 couts x 8 rows, 70 KB of LDS): two workgroups per CU, so that the output
-        // burst of one tile's epilogue runs under the other workgroup's MFMAs (the stems are write-bound: 2 chunks of K)
-        bk2<1, 7, 1, 1, 4, 2, 0, 1>("Bf3Cfg<1, 7, 1, 1, 4, 2, 0, 1>"),
-        // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan keeps the last)
-        bk2<1, 0, 1, 2, 4, 4, 1>("Bf3Cfg<1, 0, 1, 2, 4, 4, 1>"),
-        bk2<1, 0, 1, 2, 4, 4, 2>("Bf3Cfg<1, 0, 1, 2, 4, 4, 2>"),
-        bk2<1, 0, 1, 2, 4, 4, 4>("Bf3Cfg<1, 0, 1, 2, 4, 4, 4>"),
-        // the 4-tap form with a half-height tile (64 couts x 8 rows, 74 KB of LDS): two workgroups per CU for the
-        // launches whose tiles are short in K and heavy in output (fused phases, space-to-depth layers)
-        bk2<1, 0, 1, 2, 4, 2, 4>("Bf3Cfg<1, 0, 1, 2, 4, 2, 4>"),
-    };
-    static bool once = [&] {
-        v.back().fn_s2d3 = reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 0, 1, 2, 4, 2, 4, 0, 2, 1>>);
-        v.back().fn1_s2d3 = reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 0, 1, 2, 4, 2, 4, 0, 1, 1>>);
-        return true;
-    }();
-    (void)once;
+    static std::vector<Bf3Kernel> v;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        bf3_register_k3_short(v);
+        bf3_register_k3_tall(v);
+        bf3_register_s2k3(v);
+        bf3_register_k4(v);
+        bf3_register_row_tall(v);
+        bf3_register_row_half(v);
+        bf3_register_taps12(v);        // sub-pixel phases of ConvTranspose2d(s=2): 1, 2 or 4 taps (same tile geometry; the plan
+        bf3_register_taps4(v);         // keeps the last)
+        bf3_register_taps4_half(v);
+    });
     return v;
 }
 // the kernel of one launch: K == 0 kernels are instantiated per tap count
@@ -283,7 +245,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
                 if (d->transposed && (K == 3 || K == 4) && d->pad == 1 && d->stride == 2 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 &&
                     !env_int("APAMD_NO_FUSED_PHASES", 0) && !env_int("APAMD_NO_PH4", 0)) {
                     pl.ph4 = K;
-                    pl.bk = K == 3 ? ph4_kernel<3>() : ph4_kernel<4>();
+                    pl.bk = ph4_kernel(K);
                 }
             }
             if (tall && small != tall && KT != 0) {
@@ -844,7 +806,6 @@ int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float*
 // The workgroups holding the tiles of one (image, cout tile) wait for each other inside the kernel, so they must all be running
 // at the same time: the persistent grid puts at most one workgroup on a CU and walks the tile list in rounds (workgroup b of an XCD
 // takes tiles base + idx, base + idx + step, ...); every group has to lie inside ONE round of ONE XCD's range.
-static const void* fnorm_kernel() { return reinterpret_cast<const void*>(&conv_bf16x3<Bf3Cfg<1, 3, 1, 2, 4, 4, 0, 0, 2, 0, 1>>); }
 static bool fnorm_plan_ok(const ap_conv_desc* d, const Plan& pl) {
     if (!pl.bf3 || pl.fused_phases || pl.ph4 || pl.launches.size() != 1 || d->transposed || d->precision != AP_PRECISION_BF16X3 ||
         env_int("APAMD_NO_FUSED_NORM", 0))
@@ -995,9 +956,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             p.cin_pad = pl.cin_pad;
             p.wfloats = pl.bk->wfloats(p.ntaps);
 #ifdef APAMD_ABLATION
-    #ifdef APAMD_ABLATION
-        p.ablate = env_int("APAMD_ABLATE", 0);
-#endif
+            p.ablate = env_int("APAMD_ABLATE", 0);
 #endif
             p.o_octet = octet ? 1 : 0;
             if (view) {
@@ -1068,7 +1027,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 if (rc) return rc;
             }
             if (fn) {
-                kfn = fnorm_kernel();
+                kfn = bf3_fnorm_kernel();
                 rc = ensure_lds_attr(kfn);
                 if (rc) return rc;
                 p.fn_act = fn->act; p.fn_eps = fn->eps; p.fn_inv_count = 1.0 / ((double)pl.Hout * pl.Wout);
@@ -1078,17 +1037,31 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
             }
             size_t lds = kern->lds(d->precision, p.ntaps);
             bool sb = false;
+#ifdef APAMD_VARIANTS
             if (!fn && !view && !octet && kern->K == 3 && kern->S == 1 && kern->TH == 16 && !kern->ROW && d->precision != AP_PRECISION_BF16 &&
                 p.osx == 1 && p.osy == 1 && p.oy_off == 0 && p.ox_off == 0 && env_int("APAMD_CONV_SB", 0)) {
-                // experiment (conv_bf16x3_sb.h): one LDS stage per workgroup, two workgroups per CU
-                using CS = Bf3Cfg<1, 3, 1, 2, 4, 4, 0, 0, 2>;
-                kfn = reinterpret_cast<const void*>(&conv_bf16x3_sb<CS>);
+                // rejected experiment kept for A/B (tools/variants/conv_bf16x3_sb.h, `make variants`): one LDS stage per
+                // workgroup, two workgroups per CU
+                kfn = bf3_sb_kernel(&lds);
                 rc = ensure_lds_attr(kfn);
                 if (rc) return rc;
-                lds = (size_t)(CS::X_SLOTS + CS::w_slots(9)) * 16;
                 p.fn_debug = env_int("APAMD_CONV_SB_SKEW", 0);
                 sb = true;
             }
+#endif
+#ifdef APAMD_ABLATION
+            // cycle account (tools/cycle_account.py): APAMD_STAMP_BUF = device address of the stamp buffer, APAMD_STAMP_WORDS =
+            // dwords per wave; the stamps live in LDS behind the stage buffers, so only kernels that leave that room take them
+            if (const char* sb_ = getenv("APAMD_STAMP_BUF")) {
+                const int words = env_int("APAMD_STAMP_WORDS", 512);
+                if (!pl.ph4 && lds + (size_t)16 * words <= 160 * 1024) {
+                    p.stamps = reinterpret_cast<unsigned*>(strtoull(sb_, nullptr, 0));
+                    p.stamp_lds_off = (int)lds;
+                    p.stamp_words = words;
+                    lds += (size_t)16 * words;
+                }
+            }
+#endif
             if (lds > 160 * 1024) return fail(AP_ERR_UNSUPPORTED, "bf16x3 LDS tile of %zu bytes does not fit", lds);
             if (p.nchunks < 2) return fail(AP_ERR_UNSUPPORTED, "bf16x3 pipeline needs >= 32 input channels");
             if (((long long)d->H * d->W + 1) * 32 >= (1LL << 31))   // per-lane DMA offsets span two channel-group planes

@@ -89,6 +89,10 @@ struct ConvKParams {
     float* fn_rstd;
     int fn_debug;             // APAMD_FNORM_DEBUG (timing experiments, WRONG results): 1 no waiting for the group, 2 no output traffic
     unsigned* fn_counters;    // [N * co_tiles * 2], zero at launch: arrivals of a group's workgroups (stats is the exchange buffer)
+    // experiment build only (-DAPAMD_ABLATION, tools/cycle_account.py): s_memtime stamps of every wave, kept in `stamp_words`
+    // dwords of LDS per wave behind the stage buffers (byte offset stamp_lds_off) and copied to stamps[workgroup][wave][...] at exit
+    unsigned* stamps;
+    int stamp_lds_off, stamp_words;
 };
 
 // K_ > 0: dense K x K taps at compile-time offsets (tap t = ky*K + kx).  K_ == 0: up to four taps inside a

@@ -74,15 +74,6 @@ struct Ph4Cfg {
     }
 };
 
-template <class F, int... J>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, J...>) {
-    (f(std::integral_constant<int, J>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
-}
-
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
     constexpr int PARTS = C::PARTS, NT = C::NT, IW = C::IW, PLANE = C::PLANE, XP = C::XP, NXP = C::NXP, WB = C::WB;

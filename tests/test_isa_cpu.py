@@ -4,8 +4,8 @@ The LDS-DMA primitive of the matrix kernels (csrc/conv_bf16x3.h ``glds16_sv``, w
 inline assembly and lists it as clobbered; hipcc warns that a clobber of a reserved register "may lead to undefined behaviour"
 because its register allocator does not model M0.  That is only a hazard if the COMPILER ever keeps a value of its own in M0
 across such a statement or emits an instruction that reads M0 implicitly.  This test makes the assumption a checked one: in
-the whole library every instruction that names M0 is the assembly's own ``s_mov_b32 m0, sN`` directly in front of its
-``global_load_lds_dwordx4``, and no instruction with an implicit M0 operand (movrel, sendmsg, GWS, LDS-param loads) exists."""
+the whole library every instruction that names M0 is the assembly's own ``s_mov_b32 m0, sN`` / ``s_add_u32 m0, sN, imm`` directly
+in front of its ``global_load_lds_dwordx4``, and no instruction with an implicit M0 operand (movrel, sendmsg, GWS, LDS-param loads) exists."""
 import os
 import re
 import subprocess
@@ -83,6 +83,8 @@ def test_m0_is_touched_only_by_the_lds_dma_assembly(tmp_path):
     """Per kernel: M0 is written either ONLY by the raw assembly (scalar-base form ``global_load_lds_dwordx4 vN, s[a:b]``, its
     ``s_mov_b32 m0`` directly in front, nothing but s_nop between) or ONLY by the compiler for its own builtin LDS-DMA (vector
     address form) -- never both in one kernel, where a compiler-held M0 value could straddle an assembly statement."""
+    # the two forms the assembly uses: a copy of a scalar, or scalar base + literal offset (conv_bf16x3.h glds16_sv / glds16_si)
+    M0_WRITE = re.compile(r'(s_mov_b32 m0, s\d+|s_add_u32 m0, s\d+, (0x[0-9a-f]+|\d+))$')
     implicit = re.compile(r'^\s*(s_movrel|v_movrel|s_sendmsg|ds_gws|ds_param_load|ds_direct_load|v_interp|s_ttrace)')
     n_raw = n_builtin = 0
     for text in _disassembly(tmp_path):
@@ -99,12 +101,12 @@ def test_m0_is_touched_only_by_the_lds_dma_assembly(tmp_path):
         for k, (kern, i) in enumerate(ins):
             assert not implicit.match(i), 'instruction with an implicit M0 operand in %s: %s' % (kern, i)
             if re.search(r'\bm0\b', i):
-                assert re.match(r's_mov_b32 m0, s\d+$', i), 'M0 used other than as an LDS-DMA address in %s: %s' % (kern, i)
+                assert M0_WRITE.match(i), 'M0 used other than as an LDS-DMA address in %s: %s' % (kern, i)
             if i.startswith('global_load_lds'):
                 if re.match(r'global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]', i):
                     raw[kern] = raw.get(kern, 0) + 1
                     prev = [j for kk, j in ins[max(0, k - 3):k] if kk == kern and not j.startswith('s_nop')]
-                    assert prev and re.match(r's_mov_b32 m0, s\d+$', prev[-1]), ('raw LDS-DMA without its M0 write directly in front', kern, prev)
+                    assert prev and M0_WRITE.match(prev[-1]), ('raw LDS-DMA without its M0 write directly in front', kern, prev)
                 else:
                     builtin[kern] = builtin.get(kern, 0) + 1
         both = set(raw) & set(builtin)
