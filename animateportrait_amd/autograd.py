@@ -159,7 +159,8 @@ def _split_backward_plan(tape, layer, srcs, out, contribs):
     # the decision depends on shapes and on who wants a gradient, not on values: kept per layer (a handful of C-side plan queries
     # per layer and step otherwise)
     key = (n, c, h, w, bool(pads), layer.weight.requires_grad, tuple(tape.tracked(f) for f in srcs),
-           tuple(tuple(f.data.shape) for f in srcs), s.precision, ops.DEFAULT_PRECISION, os.environ.get('APAMD_NO_INBWD_SPLIT'))
+           tuple(tuple(f.data.shape) for f in srcs), s.precision, ops.DEFAULT_PRECISION,
+           tuple(os.environ.get(v) for v in ('APAMD_NO_INBWD_SPLIT', 'APAMD_NO_DGRAD_STRIP', 'APAMD_NO_BF16X3', 'APAMD_NO_S2D')))
     cache = layer.__dict__.setdefault('_split_bwd_plans', {})
     if key not in cache:
         cache[key] = _split_backward_decision(tape, layer, srcs, out, bool(pads))
@@ -257,8 +258,11 @@ def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE, out_octet=False
     return out
 
 
-def materialize_forward(tape, f, residual=None):
-    out = ops.materialize(f, residual=residual, keep_fp32=tape is not None)
+def materialize_forward(tape, f, residual=None, consumer=None):
+    """consumer: a ConvLayer that reads the result and is not a c -> c trunk layer; the fp32 tensor is dropped (inference)
+    only if that layer, too, stages split copies (at ngf = 16 the first up-convolution, 64 -> 32, reads fp32)."""
+    keep = tape is not None or (consumer is not None and not consumer.stages_split(f.data.shape))
+    out = ops.materialize(f, residual=residual, keep_fp32=keep)
     if tape is not None:
         tape.track(out)
 

@@ -384,7 +384,9 @@ class GraphedFrozen(nn.Module):
     (torch.cuda.make_graphed_callables).  MobileFaceNet is ~600 small kernels per forward + backward at the train step's shapes:
     6.2 ms eager, 4.5 ms as a graph; Sphere20a 4.2 -> 3.2 ms (tools/aux_bench.py).  ``pick`` selects the outputs the caller uses
     (every graphed output needs a gradient in backward).  Calls whose input needs no gradient, CPU tensors and autocast / no_grad
-    contexts run eagerly.  The graphs are captured after a device synchronisation: capture warms up on a side stream, and no
+    contexts run eagerly.  A graph's outputs and saved activations are STATIC buffers: one call per shape may be in flight
+    between forward and backward -- a second grad-requiring call of the same shape before the first one's backward (which would
+    overwrite them) is detected and runs eagerly.  The graphs are captured after a device synchronisation: capture warms up on a side stream, and no
     kernel of this package may run beside another stream's."""
 
     def __init__(self, net, pick=None):
@@ -392,15 +394,19 @@ class GraphedFrozen(nn.Module):
         self.net = net
         self.pick = pick
         self._graphs = {}
+        self._in_flight = set()       # shapes whose graph ran forward and has not yet run backward
 
     def _eager(self, x):
         out = self.net(x)
         return out if self.pick is None else self.pick(out)
 
     def forward(self, x):
-        if not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) or os.environ.get('APAMD_NO_AUX_GRAPHS'):
+        if (not (x.is_cuda and x.requires_grad and torch.is_grad_enabled()) or torch.is_autocast_enabled() or
+                os.environ.get('APAMD_NO_AUX_GRAPHS')):
             return self._eager(x)
         key = (tuple(x.shape), x.dtype)
+        if key in self._in_flight:
+            return self._eager(x)
         g = self._graphs.get(key)
         if g is None:
             outer = self
@@ -416,7 +422,26 @@ class GraphedFrozen(nn.Module):
             sample = torch.zeros_like(x).requires_grad_(True)
             g = self._graphs[key] = torch.cuda.make_graphed_callables(_Fn(), (sample,))
             torch.cuda.synchronize()
-        return g(x.contiguous())
+        xin = x.contiguous()
+        if not xin.requires_grad:
+            return self._eager(x)
+        self._in_flight.add(key)
+        xin = _ReleaseOnBackward.apply(xin, self._in_flight, key)     # its backward runs after the graph's: the buffers are free again
+        return g(xin)
+
+
+class _ReleaseOnBackward(torch.autograd.Function):
+    """Identity in front of a graphed callable; when the gradient comes back through it the graph's backward has run."""
+
+    @staticmethod
+    def forward(ctx, x, in_flight, key):
+        ctx.in_flight, ctx.key = in_flight, key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.in_flight.discard(ctx.key)
+        return g, None, None
 
 
 def attach_aux_networks(model, checkpoints_dir='checkpoints', verbose=True):

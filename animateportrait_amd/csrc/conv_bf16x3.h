@@ -911,6 +911,14 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                         break;
                     }
                 }
+                // The launch leaves its counters as it found them (zero): the second word of the pair counts departures, and the
+                // workgroup that leaves last -- everybody is past the wait by then -- clears both.  A replay of a captured HIP
+                // graph runs this launch again on the SAME counters; with arrivals left at `group` its wait passed at once and
+                // the workgroups combined stale pairs.
+                if (__hip_atomic_fetch_add(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == group - 1) {
+                    __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
             __syncthreads();
             // all 256 threads fetch the group's pairs (thread = channel x tile residue, loads independent), LDS table, then

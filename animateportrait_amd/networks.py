@@ -85,6 +85,14 @@ class ConvLayer(nn.Module):
             return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act, out_octet=out_octet)
         return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act, out_octet=out_octet)
 
+    def stages_split(self, shape):
+        """Whether this layer reads a source of ``shape`` (N, C, H, W) as its split-bf16 copy (then the producer may
+        leave out the fp32 tensor in inference: ops.materialize keep_fp32=False)."""
+        n, _, h, w = shape
+        if ops.stem_rows_eligible(self.spec) or ops.s2d_eligible(self.spec, h, w):
+            return False
+        return ops.takes_split(self.spec, n, h, w)
+
     def fused_norm_ok(self, srcs):
         """Inference only: can this layer produce act(IN(conv)) [+ residual] in one launch (ops.conv2d_norm)?"""
         if not isinstance(srcs, (list, tuple)):
@@ -127,16 +135,18 @@ class ResnetBlock(nn.Module):
         self.conv_block = _seq(_1=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT),
                                _5=ConvLayer([dim], dim, 3, 1, 1, PAD_REFLECT))
 
-    def run(self, x, tape=None):
+    def run(self, x, tape=None, consumer=None):
+        """consumer: the layer that reads the block's output when it is not another block of the trunk (the first
+        up-convolution) -- the output is kept as fp32 unless that layer stages split copies."""
         c1, c5 = self.conv_block['1'], self.conv_block['5']
-        if tape is None and not x.virtual and not x.is_split_only and c1.fused_norm_ok(x):
+        if tape is None and not x.virtual and (x.oct is not None or not x.is_split_only) and c1.fused_norm_ok(x):
             # inference: each convolution normalises its own output in the epilogue (ap_conv2d_fwd_norm) -- no raw fp32 output,
             # no norm_split pass; the block's result lives as the split copy (next convolution) + channel-octet fp32 (next residual)
             y = c1.run_norm(x, act=ACT_RELU)
             return c5.run_norm(y, act=ACT_NONE, residual=x, want_oct=True)
         y = conv_forward(tape, c1, x, norm_act=ACT_RELU)
         y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
-        return materialize_forward(tape, y, residual=x)
+        return materialize_forward(tape, y, residual=x, consumer=consumer)
 
 
 class ResnetBlock2(nn.Module):
@@ -148,7 +158,7 @@ class ResnetBlock2(nn.Module):
                                _5=ConvLayer([dim_out], dim_out, 3, 1, 1, PAD_REFLECT))
         self.shortcut = _seq(_0=ConvLayer(segs, dim_out, 3, 1, 1, PAD_ZERO))
 
-    def run(self, srcs, tape=None):
+    def run(self, srcs, tape=None, consumer=None):
         c1, c5, sc = self.conv_block['1'], self.conv_block['5'], self.shortcut['0']
         if tape is None and c1.fused_norm_ok(srcs):
             # inference (see ResnetBlock.run): the shortcut's IN(conv) is the residual of the main branch's second convolution
@@ -158,7 +168,7 @@ class ResnetBlock2(nn.Module):
         y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU)
         y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
         s = conv_forward(tape, sc, srcs, norm_act=ACT_NONE)
-        return materialize_forward(tape, y, residual=s)
+        return materialize_forward(tape, y, residual=s, consumer=consumer)
 
 
 class ResnetConditionTriGenerator32_full_ifw(nn.Module):
@@ -286,7 +296,8 @@ class ResnetConditionTriGenerator32_full_ifw(nn.Module):
         x = cf(tape, self.model_tri_merge, [x1, x2, x3])
         for i in range(self.n_blocks):
             blk = self.model2[str(i)]
-            x = blk.run([x, l1, l2], tape) if self.is_block2(i) else blk.run(x, tape)
+            nxt = self.model3['0'] if i == self.n_blocks - 1 else None
+            x = blk.run([x, l1, l2], tape, consumer=nxt) if self.is_block2(i) else blk.run(x, tape, consumer=nxt)
         x = cf(tape, self.model3['0'], x, norm_act=ACT_RELU)
         x = cf(tape, self.model3['3'], x, norm_act=ACT_RELU)
         return cf(tape, self.model3['7'], x, act=ACT_TANH)
@@ -332,9 +343,9 @@ class ResnetStyle2Generator(nn.Module):
             x = cf(None, self.model0['7'], x, norm_act=ACT_RELU)
             x = cf(None, self.model['0'], [x, Feat(input2.contiguous())], norm_act=ACT_RELU)
             x = materialize_forward(None, x)
-            for i in range(self.n_blocks):
-                x = self.model[str(3 + i)].run(x, None)
             j = 3 + self.n_blocks
+            for i in range(self.n_blocks):
+                x = self.model[str(3 + i)].run(x, None, consumer=self.model[str(j)] if i == self.n_blocks - 1 else None)
             x = cf(None, self.model[str(j)], x, norm_act=ACT_RELU)
             x = cf(None, self.model[str(j + 3)], x, norm_act=ACT_RELU)
             return cf(None, self.model[str(j + 7)], x, act=ACT_TANH).data

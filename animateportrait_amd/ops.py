@@ -107,7 +107,10 @@ class Feat:
 
     @property
     def is_split_only(self):
-        return (self.xs is not None or self.s2d is not None) and self.data.stride(0) == 0 and self.data.numel() > 1
+        """No fp32 NCHW tensor behind ``data`` (a storage-less stand-in): the feature lives as its split copy, its
+        space-to-depth copy and / or its channel-octet form only."""
+        return ((self.xs is not None or self.s2d is not None or self.oct is not None) and self.data.stride(0) == 0 and
+                self.data.numel() > 1)
 
     @property
     def virtual(self):
@@ -506,7 +509,8 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
 def wants_split(c):
     """Whether a materialised residual-trunk feature of ``c`` channels is going to be staged by a split-bf16
     convolution: its consumers are c -> c 3x3 layers, so this is the C library's eligibility rule (>= 48 outputs,
-    >= 32 inputs in 16-channel segments).  A wrong guess only costs the unused copy."""
+    >= 32 inputs in 16-channel segments).  A wrong guess costs the unused copy; where the fp32 tensor is dropped on the
+    strength of it (materialize keep_fp32=False) the caller checks the real consumer (autograd.materialize_forward)."""
     return DEFAULT_PRECISION != PRECISION_FP32 and c >= 48 and c % 16 == 0
 
 
@@ -731,6 +735,9 @@ def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None):
     n, c, h, w = g.data.shape
     hp, wp = h + 2, w + 2
     out = torch.empty((n, spec.cout, hp, wp), dtype=torch.float32, device=g.data.device)
+    if strip is None and g.is_split_only:
+        raise RuntimeError('conv2d_dgrad_strip: the gradient exists only as its split copy and no column strip was prepared '
+                           '(ap_instnorm_bwd_split writes it when the backward plan asks for one)')
     t = strip if strip is not None else Feat(g.data[:, :, :, w - 2:].transpose(2, 3).contiguous())   # strip: (N, C, 2, H) from instnorm_bwd_split
     v = C.ApOutView()
     v.nstride, v.cstride = spec.cout * hp * wp, hp * wp

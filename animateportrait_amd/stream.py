@@ -26,7 +26,7 @@ import time
 import numpy as np
 import torch
 
-from . import losses
+from . import losses, ops
 from .data.motion import cal_motion256
 
 
@@ -143,6 +143,8 @@ class ClipStreamer:
             out[lo:hi] = m.fake_B
             if profile:
                 self._tick('generator', t0)
+        if ops.FUSED_NORM:
+            ops.check_fused_norm()                   # opt-in in-kernel InstanceNorm: a timed-out exchange invalidates the clip
         return out
 
 

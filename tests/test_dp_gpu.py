@@ -49,3 +49,33 @@ def test_two_rank_optimize_parameters_matches_big_batch(tmp_path):
         assert r['losses_finite'] and r['n_losses'] >= 10, r
         assert r['G_norm'] > 0 and r['G_rel'] < 5e-5 and r['D_rel'] < 5e-5, r
         assert r['G_worst_tensor'] < 2e-4 and r['D_worst_tensor'] < 2e-4, r
+
+
+@pytest.mark.gpu
+def test_bench_with_eight_ranks_on_one_gpu():
+    """``bench.py --gpus 8`` end to end, the eight ranks sharing this box's one GPU over gloo (APAMD_BENCH_SHARE_GPU=1
+    APAMD_DIST_BACKEND=gloo: test plumbing, the JSON line says so): the launcher re-executes under torch.distributed.run, every
+    rank builds its replica, rank 0's weights are broadcast, the DP train step runs with its collectives, and rank 0 prints ONE
+    JSON line whose world size is 8 and whose replicas did not drift.  No scaling number is read off this -- the point is that the
+    first real 8-GPU run is not also the first 8-rank run."""
+    import json
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, APAMD_BENCH_SHARE_GPU='1', APAMD_DIST_BACKEND='gloo', MASTER_PORT=str(port), MASTER_ADDR='127.0.0.1',
+               HSA_ENABLE_IPC_MODE_LEGACY='0', APAMD_BENCH_NO_TRAFFIC='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--train-steps', '1',
+                        '--no-stream', '--no-exact-fp32', '--no-cpu-baseline'], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['rccl_world_size'] == 8 and d['ranks_share_one_gpu'] is True, d
+    assert d['collective_backend'] == 'gloo'
+    ts = d['train_step']
+    assert ts['replica_drift']['after_steps'] == 0.0 and ts['ms_per_step'] > 0, ts
+    assert d['value'] > 0 and d['scaling'] == 'weak'

@@ -253,6 +253,24 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch, fused, monkeypatch):
     assert linf(y1, ref[:1]) < 1e-3
 
 
+@pytest.mark.parametrize('ngf', [16, 20])
+def test_generator_width_whose_upconvolution_reads_fp32(dev, ngf):
+    """at 4 * ngf in {48, 64, 80} the trunk output qualifies for the split-only residual stream (c >= 48, c % 16 == 0)
+    but the first up-convolution (dim -> dim / 2 <= 40 outputs, < 128 inputs) stays on the fp32 kernel: the last block must
+    keep its fp32 tensor (autograd.materialize_forward consumer=...).  Inference raised a RuntimeError there."""
+    from animateportrait_amd import networks as N
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    from oracle import generator as og
+    args = generator_args(make_generator_inputs(2, seed=5))
+    sd = og.init_params(og.generator_param_shapes(3, 1, ngf, 9, 3, 3), seed=5)
+    G = N.define_G(3, 1, ngf, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
+    G.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        y = G(*[a.to(dev) for a in args])
+        ref = og.generator_forward(sd, *args, div=3, disp=3)
+    assert linf(y, ref) < 1e-3
+
+
 def test_static_generator(dev, golden):
     """resnet_style2_9blocks (networks.py:573-637) on the HIP path against the reference's
     outputs; cat[f1, style] is a two-segment source of model.0, never a tensor."""
@@ -1237,6 +1255,36 @@ def test_conv_with_in_kernel_instancenorm(dev, n, act, res, monkeypatch):
     raw = layer.run(src, norm_act=act)
     old = ops.materialize(raw, residual=ops.Feat(r.to(dev)) if r is not None else None)
     assert linf(got, old.data) < 2e-5 * scale
+
+
+def test_in_kernel_instancenorm_leaves_its_counters_zero(dev, monkeypatch):
+    """a replay of a captured HIP graph runs ap_conv2d_fwd_norm again on the SAME arrival counters.  The kernel's last
+    departing workgroup clears them, so a second launch on the same counters waits for its peers like the first one: same bits,
+    counters zero afterwards."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    monkeypatch.setattr(ops, 'FUSED_NORM', True)
+    torch.manual_seed(4)
+    layer = ConvLayer([256], 256, 3, 1, 1, ops.PAD_REFLECT).to(dev)
+    torch.nn.init.normal_(layer.weight, 0.0, 0.02)
+    src = ops.Feat(torch.randn(8, 256, 64, 64, device=dev))
+    handed = []
+    shared = torch.zeros(4096, dtype=torch.int32, device=dev)
+
+    def same_counters(n, device):
+        handed.append(n)
+        return shared[:n]
+    monkeypatch.setattr(ops, '_zero_counters', same_counters)
+    outs = []
+    for _ in range(3):
+        o = layer.run_norm(src, act=ops.ACT_RELU, want_oct=True, want_xs=True)
+        outs.append((o.oct.clone(), o.xs.clone()))
+        torch.cuda.synchronize()
+        assert int(shared.abs().max()) == 0
+    ops.check_fused_norm()
+    assert len(set(handed)) == 1
+    for oc, xs in outs[1:]:
+        assert torch.equal(oc, outs[0][0]) and torch.equal(xs, outs[0][1])
 
 
 def test_launches_on_different_streams_are_fenced(dev):

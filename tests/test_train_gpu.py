@@ -666,3 +666,16 @@ def test_graphed_frozen_nets_match_eager(dev, monkeypatch):
         with torch.no_grad():                       # no gradient wanted: eager path, same values
             o = g(x)
         assert torch.is_tensor(o) or len(o) == 5
+        # two grad-requiring calls of one shape BEFORE either backward: the second must not reuse the graph's static buffers
+        # (ADVICE r4): both gradients equal the eager ones
+        x1, x2 = torch.rand(shape, device=dev), torch.rand(shape, device=dev)
+        grads = []
+        for fn in (g, lambda t: pick(net(t))):
+            a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            o1, o2 = fn(a), fn(b)
+            first = lambda o: o if torch.is_tensor(o) else o[0]
+            (first(o1).sum() + 2 * first(o2).sum()).backward()
+            grads.append((a.grad, b.grad))
+        for u, v in zip(grads[0], grads[1]):
+            assert float((u - v).double().norm()) <= 2e-3 * float(v.double().norm())
+        assert not g._in_flight
