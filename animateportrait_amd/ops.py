@@ -203,6 +203,10 @@ class LaunchProfiler:
 
     def __init__(self):
         self.records = []   # (kernel name, flops, start event, end event)
+        self.calls = {}     # un-timed launches worth knowing about: name -> count (tests read which plans ran)
+
+    def note(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
 
     def summary(self):
         """Per kernel instantiation: launches, total ms, FLOPs.  A bracket far above its group's median (same kernel, same
@@ -922,6 +926,8 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
     dw = _grad_out(out, out_shape, srcs[0].data.device)
     assert dw.numel() == m * cin * k * k
     if g_t is not None:
+        if PROFILER is not None:
+            PROFILER.note('wgrad_bf16x3<%d> (prepared operand)' % k)  # only that kernel takes the operand instnorm_bwd_split wrote
         C.check(lib.ap_conv2d_wgrad_pre(ctypes.byref(d), _ptr(g_t), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad_pre')
     else:
         C.check(lib.ap_conv2d_wgrad(ctypes.byref(d), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad')
@@ -1063,6 +1069,8 @@ def instnorm_bwd_split(red, f, gt_dims=None, want_xs=True, want_strip=False, wan
         dims = (ctypes.c_int32 * 3)(ghp, gx8, mp)
     strip = torch.empty((n, c, 2, h), dtype=torch.float32, device=dev) if want_strip else None
     dy = torch.empty_like(f.data) if want_dy else None
+    if PROFILER is not None:
+        PROFILER.note('instnorm_bwd_split<%d>' % (h * w // 4))       # threads per (image, channel octet) item: 4 pixels each
     C.check(C.lib().ap_instnorm_bwd_split(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act, n, c, h, w,
                                           _ptr(xs), _ptr(gt), dims, _ptr(strip), _ptr(dy), 1 if heads_only else 0, _stream()),
             'instnorm_bwd_split')

@@ -214,6 +214,14 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3', aux_kind='r
             model.aux['landmarks'] = aux_nets.GraphedFrozen(frozen(aux_nets.MobileFaceNet((112, 112), 136)), pick=lambda o: o[0])   # geomgm_ifw_fore_model.py:362
             model.aux['faceloss'] = _nets.FaceLoss(aux_nets.GraphedFrozen(frozen(aux_nets.Sphere20a()), pick=tuple))            # :374-376
             model.aux['modnet'] = frozen(aux_nets.MODNet())                                       # :369-373, called in forward :519
+            # netF: set_input runs flow_network_warp twice per step (geomgm_ifw_fore_model.py:57-84, 503-505).  FlowUnet_v2 on the
+            # HIP kernels at the hyper-parameters the clip leg uses (class defaults nf 64 / max_nf 256 / 2 residual blocks, the 4
+            # scales a 224-px input admits; the reference's own live in an absent train_opt.json), random init, as one hipGraph
+            from animateportrait_amd import flow_unet, flow_unet_hip
+            netF_cpu = flow_unet.FlowUnetV2(136, nf=64, max_nf=256, start_scale=2, num_scales=4, n_residual_blocks=2, norm='batch').eval()
+            model.aux['netF'] = flow_unet_hip.FlowUnetV2Hip(netF_cpu).to(dev)
+            model.aux['netF'].heads_only = True
+            model.aux['netF'].use_graph = True
         parallel.broadcast_model(model)                  # all ranks start from rank 0's weights (no-op at N=1)
         drift0 = parallel.replica_drift(model)
         batch = {k: (v.to(dev) if torch.is_tensor(v) and not k.startswith('win') else v)
@@ -238,6 +246,23 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3', aux_kind='r
     from animateportrait_amd import parallel
     drift = parallel.replica_drift(model)                # identical updates on identical weights on every rank: 0.0
     losses = model.get_current_losses()
+    netF_ms = None
+    if model.aux.get('netF') is not None:
+        # what the two flow_network_warp calls of set_input cost inside the step: set_input alone, with and without netF
+        def _set_input_ms(n=5):
+            model.set_input(batch)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                model.set_input(batch)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+        with contextlib.redirect_stdout(io.StringIO()):
+            with_f = _set_input_ms()
+            keep, model.aux['netF'] = model.aux['netF'], None
+            without = _set_input_ms()
+            model.aux['netF'] = keep
+        netF_ms = round(with_f - without, 2)
     return {'ms_per_step': round(dt * 1e3, 2), 'samples_per_s': round(world * BATCH / dt, 2), 'steps': steps,
             'world_size': world, 'global_batch': world * BATCH,
             'replica_drift': {'after_broadcast': drift0, 'after_steps': drift},
@@ -252,10 +277,12 @@ def train_step_ms(dev, rank, world, dist, steps, precision='bf16x3', aux_kind='r
             'algorithmic_tflops': round(BATCH * 1.234 / dt, 1),
             'frac_algorithmic': round(BATCH * 1.234 / dt / PEAK_BF16_MFMA_TFLOPS, 4),
             'aux_nets': aux_kind,
+            'netF_ms_per_step': netF_ms,
             'note': 'geomgm_ifw_fore drawing config, all nine backward_G terms in the timed region; ' + (
                 'MODNet (matte), MobileFaceNet (geometry term) and Sphere20a (identity term) run at the reference architectures '
-                '(aux_nets.py, stock PyTorch-ROCm, random init: their checkpoints are absent from the reference tree); intrinsic '
-                'flow (netF: hyper-parameters in an absent train_opt.json, SURVEY 8a excludes it) is a synthetic batch input'
+                '(aux_nets.py, stock PyTorch-ROCm, random init: their checkpoints are absent from the reference tree); netF '
+                '(flow_network_warp twice per set_input) is FlowUnet_v2 on the HIP kernels at the class-default hyper-parameters '
+                '(the reference\'s are in an absent train_opt.json), random init: netF_ms_per_step'
                 if aux_kind != 'standin' else
                 'the frozen landmark / identity nets are the toy stand-ins of standins.py, matte / intrinsic flow are batch inputs')}
 

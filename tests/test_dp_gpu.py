@@ -57,7 +57,9 @@ def test_bench_with_eight_ranks_on_one_gpu():
     APAMD_DIST_BACKEND=gloo: test plumbing, the JSON line says so): the launcher re-executes under torch.distributed.run, every
     rank builds its replica, rank 0's weights are broadcast, the DP train step runs with its collectives, and rank 0 prints ONE
     JSON line whose world size is 8 and whose replicas did not drift.  No scaling number is read off this -- the point is that the
-    first real 8-GPU run is not also the first 8-rank run."""
+    first real 8-GPU run is not also the first 8-rank run.  ``--no-parity-gate``: eight PROCESSES on one device run their kernels
+    side by side on the same compute units, which is exactly the co-residency hazard of DESIGN.md section 3.9 (measured here: the
+    gate fails with 0.5 L-inf); on a real node every rank owns its GPU.  Plumbing only: values are not read."""
     import json
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
@@ -70,7 +72,7 @@ def test_bench_with_eight_ranks_on_one_gpu():
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1', '--train-steps', '1',
-                        '--no-stream', '--no-exact-fp32', '--no-cpu-baseline'], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+                        '--no-stream', '--no-exact-fp32', '--no-cpu-baseline', '--no-parity-gate'], env=env, cwd=root, capture_output=True, text=True, timeout=1500)
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
     assert p.returncode == 0 and len(lines) == 1, (p.returncode, p.stdout[-2000:], p.stderr[-3000:])
     d = json.loads(lines[0])
