@@ -173,13 +173,23 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     bf16x8 ah[2], al[2];                                               // by ks parity
     u32x4 rh[RB][2], rl[RB][2];                                        // by group index mod RB: [octet j]
     bf16x8 sh[2][K], sl[2][K];                                         // funnelled operands by group parity (odd shifts)
-    auto fetch_group = [&](int buf, int gidx) __attribute__((always_inline)) {
+    // live = false: the stage does not exist (the padding stage of an odd count, see the stage loop): its G fragments are
+    // forced to zero, so its products are exact zeros whatever finite data the buffer holds
+    auto fetch_group = [&](int buf, int gidx, bool live) __attribute__((always_inline)) {
         const int ks = gidx / K, ky = gidx % K, rb = gidx % RB;
         const int py = ks >> 1, xh = ks & 1;
         const uint4* S0 = smem + buf * STAGE;
         if (ky == 0) {
-            ah[ks & 1] = *reinterpret_cast<const bf16x8*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * 64);
-            if constexpr (PARTS == 2) al[ks & 1] = *reinterpret_cast<const bf16x8*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
+            u32x4 th = *reinterpret_cast<const u32x4*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * 64);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) th[d] = live ? th[d] : 0u;
+            ah[ks & 1] = __builtin_bit_cast(bf16x8, th);
+            if constexpr (PARTS == 2) {
+                u32x4 tl = *reinterpret_cast<const u32x4*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) tl[d] = live ? tl[d] : 0u;
+                al[ks & 1] = __builtin_bit_cast(bf16x8, tl);
+            }
         }
         const int row = py + ky;
 #pragma unroll
@@ -211,11 +221,18 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     auto stage = [&](auto ptag, int st) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;                       // stage buffer
         constexpr int NM = PROD * K, PPS = (NPW + 2 * NM - 1) / (2 * NM);  // DMA pieces per MFMA slot (last two groups)
-        const bool more = st + 1 < st1, dma = st + 2 < st1 && !AP_ABLATE(p, 1);
+        const bool live = st < st1, more = st + 1 < st1, dma = st + 2 < st1 && !AP_ABLATE(p, 1);
         if (st == st0) {
-            fetch_group(P, 0);
-            fetch_group(P, 1);
+            fetch_group(P, 0, true);
+            fetch_group(P, 1, true);
             shift_group(0);
+        }
+        if (!live) {                                                   // (the fragments of its first groups were not fetched)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = bf16x8{};
+                if constexpr (PARTS == 2) al[i] = bf16x8{};
+            }
         }
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
@@ -230,8 +247,8 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
             }
             // (no run-time conditions in the steady-state groups: a branch would split the basic block and the
             // compiler's wait-count bookkeeping turns conservative across blocks)
-            if (gi + 2 < NG) fetch_group(P, gi + 2);
-            else if (more) fetch_group(P ^ 1, gi + 2 - NG);
+            if (gi + 2 < NG) fetch_group(P, gi + 2, live);
+            else if (more) fetch_group(P ^ 1, gi + 2 - NG, true);
             if (gi + 1 < NG) shift_group(gi + 1);
             else if (more) shift_group(0);
 #pragma unroll
@@ -259,9 +276,19 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         }
         if (dma) advance();
     };
+    // Stages run in PAIRS, both halves unconditionally: with the second stage behind `if (st + 1 < st1)` its MFMAs sat in a
+    // conditional block, every accumulator became a phi node and the allocator moved them between AGPRs and VGPRs around it
+    // (K = 4: 998 v_accvgpr moves and 128-252 bytes of scratch for 128 MFMAs; round 5).  The padding stage of an odd count
+    // multiplies zeroed G fragments with whatever the buffer holds -- which must be FINITE: a workgroup with a single stage never
+    // fills buffer 1, so it is cleared here.
+    if (st0 + 1 == st1) {
+        uint4* z = reinterpret_cast<uint4*>(smem_raw) + STAGE;
+        for (int i = tid; i < STAGE; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+    }
     for (int st = st0; st < st1; st += 2) {
         stage(std::integral_constant<int, 0>{}, st);
-        if (st + 1 < st1) stage(std::integral_constant<int, 1>{}, st + 1);
+        stage(std::integral_constant<int, 1>{}, st + 1);
     }
 
     // Partial sums leave in the accumulators' own order, partial[split][tile = mt * c_tiles + ct][wave][tap][r][lane]:

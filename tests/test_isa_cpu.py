@@ -39,8 +39,8 @@ def test_no_kernel_keeps_its_working_set_in_scratch(tmp_path):
     """A register array indexed by something the compiler could not fold lands in scratch memory, and a matrix kernel whose
     fragment buffers live there runs several times slower without failing any parity test (round 4: conv_ph4<4> after a
     tap-order change -- 704 bytes of private segment, the train step 94 -> 210 ms).  Every kernel's private segment stays
-    small; the two known spillers (the 4x4 weight-gradient kernel: 16 tap accumulators) are listed by name."""
-    allowed = {'wgrad_bf16x3INS_11WgradBf3CfgILi4ELi2': 320, 'wgrad_bf16x3INS_11WgradBf3CfgILi4ELi1': 192}
+    small (no kernel is exempt)."""
+    allowed = {}          # (round 5: the 4x4 weight-gradient kernel lost its spills with the unconditional stage pairs)
     worst = []
     for co in _code_objects(tmp_path):
         text = subprocess.run([LLVM + '/llvm-readelf', '--notes', co], capture_output=True, text=True, check=True).stdout
