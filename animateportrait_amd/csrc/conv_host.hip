@@ -986,6 +986,9 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 if (pl.ph4) {
                     // conv_ph4 walks cout tiles only and derives the phase geometry from K: check the plan agrees
                     if (view) return fail(AP_ERR_UNSUPPORTED, "conv_ph4: output views are not supported");
+                    // (the kernel folds the phase into 32-bit per-lane byte offsets of the packed weights)
+                    if (3LL * pl.co_tiles * pl.nchunks * p.wfloats * 4 >= (1LL << 31))
+                        return fail(AP_ERR_UNSUPPORTED, "conv_ph4: packed phase blocks of %d cout tiles x %d chunks are too large", pl.co_tiles, pl.nchunks);
                     p.co_tiles = pl.co_tiles;
                     const int base = pl.ph4 == 3 ? 0 : -1;
                     for (int ph = 0; ph < 4; ++ph) {

@@ -74,6 +74,23 @@ struct Ph4Cfg {
     }
 };
 
+// 16 per-lane values summed over the 32 lanes of a half-wave as a transpose-reduce: at every step a lane hands half of its
+// values to the partner and keeps the sums of the other half (8 + 4 + 2 + 1 exchanges, then one plain step): 16 shuffles per
+// quantity instead of 16 x 5.  Lanes with even l32 end up with the total of value index
+// ((l32 >> 4) & 1) * 8 + ((l32 >> 3) & 1) * 4 + ((l32 >> 2) & 1) * 2 + ((l32 >> 1) & 1)   (conv_bf16x3's octet epilogue).
+__device__ __forceinline__ float fold16_half(const float (&v)[16], int l32) {
+    const bool b16 = l32 & 16, b8 = l32 & 8, b4 = l32 & 4, b2 = l32 & 2;
+    float w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w8[i] = (b16 ? v[i + 8] : v[i]) + __shfl_xor(b16 ? v[i] : v[i + 8], 16, 64);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w4[i] = (b8 ? w8[i + 4] : w8[i]) + __shfl_xor(b8 ? w8[i] : w8[i + 4], 8, 64);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) w2[i] = (b4 ? w4[i + 2] : w4[i]) + __shfl_xor(b4 ? w4[i] : w4[i + 2], 4, 64);
+    const float w1 = (b2 ? w2[1] : w2[0]) + __shfl_xor(b2 ? w2[0] : w2[1], 2, 64);
+    return w1 + __shfl_xor(w1, 1, 64);
+}
+
 template <class C>
 __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
     constexpr int PARTS = C::PARTS, NT = C::NT, IW = C::IW, PLANE = C::PLANE, XP = C::XP, NXP = C::NXP, WB = C::WB;
@@ -146,58 +163,65 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
         if (p.nseg > 2 && chunk >= p.seg[2].chunk_begin) s = 2;
         return s;
     };
-    // weight piece j = (tap i = j / PARTS of the list, part j % PARTS): its phase and byte offset inside the packed block
+    // weight piece j = (tap i = j / PARTS of the list, part j % PARTS) goes to wave j % 4.  Its source is the packed block of the
+    // tap's PHASE: block (phase, cout tile, chunk) lies phase * co_tiles * nchunks blocks behind block (0, cout tile, chunk), so
+    // the phase is folded into the piece's per-lane byte offset (a constant of the kernel) and a stage has ONE scalar weight base.
     constexpr int NWJ = (C::NTAPS * PARTS + 3) / 4;
-    int wph[NWJ], wsrc[NWJ];
-#pragma unroll
-    for (int jj = 0; jj < NWJ; ++jj) {
-        const int j = jj * 4 + wave, i = j / PARTS, part = j - i * PARTS;
-        int code = 0, n = 0;
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-            if (C::has(c >> 2, c & 3)) {
-                if (n == i) code = c;
-                ++n;
-            }
-        wph[jj] = code >> 2;
-        wsrc[jj] = (part * WB + (code & 3) * 64) * 16;
-    }
-    // one stage = the existing taps of the four phase blocks of (cout tile, chunk) + the activation tile of the chunk
-    auto issue = [&](const TileId& t, const int (&goff)[NXW], int chunk_, int buf) __attribute__((always_inline)) {
-        const int n = __builtin_amdgcn_readfirstlane(t.n), cot = __builtin_amdgcn_readfirstlane(t.cot);
-        chunk_ = __builtin_amdgcn_readfirstlane(chunk_);
-        const unsigned stage0 = lds0 + buf * STAGE * 16;
-        // weights: one 64-slot piece per (existing tap, part); piece j of the stage goes to wave j % 4
+    unsigned woff[NWJ];
+    {
+        const long long phase_bytes = (long long)co_tiles * nchunks * p.wfloats * 4;    // < 2^30 (host: conv2d_fwd_impl checks)
 #pragma unroll
         for (int jj = 0; jj < NWJ; ++jj) {
-            const int j = jj * 4 + wave;
-            if (j < C::NTAPS * PARTS) {
-                const unsigned char* src = reinterpret_cast<const unsigned char*>(
-                    p.wp + ((long long)(wph[jj] * co_tiles + cot) * nchunks + chunk_) * p.wfloats);
-                glds16_sv(src, (unsigned)(wsrc[jj] + lane * 16), stage0 + j * 64 * 16);
-            }
-        }
-        if (chunk_ < nreal) {                                       // (a padding chunk has zero weights: stale, finite data stays)
-            const int s = seg_of(chunk_);
-            const int cg0 = (chunk_ - p.seg[s].chunk_begin) * 2;
-            const int CG = p.seg[s].C >> 3;
-            const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
+            const int j = jj * 4 + wave, i = j / PARTS, part = j - i * PARTS;
+            int code = 0, n = 0;
 #pragma unroll
-            for (int part = 0; part < PARTS; ++part) {
-                const unsigned char* xb = xs + ((long long)(n * 2 + part) * CG + cg0) * (HW + 1) * 16;
-#pragma unroll
-                for (int k = 0; k < NXW; ++k)
-                    if (wave + 4 * k < NXP)
-                        glds16_sv(xb, (unsigned)goff[k], stage0 + (W_SLOTS + part * XP + (wave + 4 * k) * 64) * 16);
-            }
+            for (int c = 0; c < 16; ++c)
+                if (C::has(c >> 2, c & 3)) {
+                    if (n == i) code = c;
+                    ++n;
+                }
+            woff[jj] = (unsigned)((code >> 2) * phase_bytes) + (unsigned)((part * WB + (code & 3) * 64) * 16) + lane * 16;
         }
+    }
+    // One stage = the existing taps of the four phase blocks of (cout tile, chunk) + the activation tile of the chunk.
+    // As in conv_bf16x3 (profiles/r05_dominant_cycle_account.md): the scalar bases are computed once per stage and pinned in
+    // SGPRs, a piece is {s_add m0, base, literal; global_load_lds v_off, s[base]} and nothing else.  (Before: every piece
+    // re-derived its 64-bit source address -- ten to fourteen scalar multiplies / adds --, read spilled scalars back with
+    // v_readlane and tested its own validity: 260-350 scalar multiplies in a kernel of 18-96 MFMAs.)  alt / use_alt: the tile's
+    // last chunk stages the NEXT tile's chunk 0 with that tile's offsets.
+    auto issue = [&](int n_, int cot_, const int (&goff)[NXW], const int (&alt)[NXW], bool use_alt, int chunk_, int buf)
+                     __attribute__((always_inline)) {
+        const int n = __builtin_amdgcn_readfirstlane(n_), cot = __builtin_amdgcn_readfirstlane(cot_);
+        chunk_ = __builtin_amdgcn_readfirstlane(chunk_);
+        const int chunk = chunk_ < nreal ? chunk_ : nreal - 1;      // a padding chunk (zero weights) re-stages real, finite data
+        const int s = seg_of(chunk);
+        const int cg0 = (chunk - p.seg[s].chunk_begin) * 2;
+        const int CG = p.seg[s].C >> 3;
+        const unsigned char* xs = reinterpret_cast<const unsigned char*>(p.seg[s].data);
+        const unsigned char* xh = xs + ((long long)(n * 2 + 0) * CG + cg0) * (HW + 1) * 16;
+        const unsigned char* xl = xs + ((long long)(n * 2 + 1) * CG + cg0) * (HW + 1) * 16;
+        const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(p.wp + ((long long)cot * nchunks + chunk_) * p.wfloats);
+        unsigned wdst = lds0 + (buf * STAGE + wave * 64) * 16;
+        unsigned xdst = lds0 + (buf * STAGE + W_SLOTS + wave * 64) * 16;
+        asm volatile("" : "+s"(xh), "+s"(xl), "+s"(wsrc), "+s"(wdst), "+s"(xdst));
+        static_for<NWJ>([&](auto jt) __attribute__((always_inline)) {
+            constexpr int jj = decltype(jt)::value;
+            constexpr bool whole = jj * 4 + 3 < C::NTAPS * PARTS;   // every wave has a piece jj
+            if (whole || jj * 4 + wave < C::NTAPS * PARTS) glds16_si<jj * 4096>(wsrc, woff[jj], wdst);
+        });
+        static_for<PARTS * NXW>([&](auto jt) __attribute__((always_inline)) {
+            constexpr int part = decltype(jt)::value / NXW, k = decltype(jt)::value % NXW;
+            constexpr bool whole = 4 * k + 3 < NXP;
+            if (whole || wave + 4 * k < NXP)
+                glds16_si<(part * XP + k * 256) * 16>(part ? xl : xh, (unsigned)(use_alt ? alt[k] : goff[k]), xdst);
+        });
     };
 
     f32x16 acc[4][NT];
     TileId cur, nxt;
     int cgoff[NXW], ngoff[NXW];
     locate(tile, cur, cgoff);
-    issue(cur, cgoff, 0, 0);
+    issue(cur.n, cur.cot, cgoff, cgoff, false, 0, 0);
     for (;;) {
         const bool has_next = tile + tile_step < tile_end;
         locate(has_next ? tile + tile_step : tile, nxt, ngoff);
@@ -211,8 +235,12 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
             const int buf = c & 1;                                  // (nchunks is even: every tile starts in buffer 0)
             dma_wait_all();
             __syncthreads();        // stage c has landed for every wave; nobody reads the other buffer any more
-            if (c + 1 < nchunks) issue(cur, cgoff, c + 1, buf ^ 1);
-            else if (has_next) issue(nxt, ngoff, 0, buf ^ 1);
+            {
+                // the tile's last chunk stages chunk 0 of the next tile -- without a next tile this tile's own chunk 0 again,
+                // which nobody reads: one unconditional issue sequence (the two call sites were two copies of it)
+                const bool tailc = c + 1 >= nchunks;
+                issue(tailc ? nxt.n : cur.n, tailc ? nxt.cot : cur.cot, cgoff, ngoff, tailc, tailc ? 0 : c + 1, buf ^ 1);
+            }
             const uint4* Wc = smem + buf * STAGE + half * CO_TILE + l32;
             const uint4* Xc = smem + buf * STAGE + W_SLOTS + half * PLANE + (wpx * NT) * IW + l32;
             // the pairs that exist, position by position; the fragments of pair j + 1 are read while pair j multiplies
@@ -251,34 +279,64 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
             });
         }
         // ---- epilogue.  MFMA C/D layout: pixel column = lane & 31, cout row = (r & 3) + 8 (r >> 2) + 4 half.  The phases
-        // (phy, 0) and (phy, 1) are the even / odd output columns of one row: one 8-byte store per lane.
-        {
+        // (phy, 0) and (phy, 1) are the even / odd output columns of one row.
+        // FAST: no activation, no bias (compile time), whole pixel pairs and 16-byte aligned rows -- what every InstanceNorm-ed layer and
+        // every data gradient is.  The two lanes of a pixel pair (ox even, ox + 1) hold output columns 2 ox .. 2 ox + 3 of BOTH
+        // pixel rows of the tile; the even lane hands its row-1 pair to the odd lane and takes that lane's row-0 pair (DPP
+        // quad_perm [1,0,3,2]), so each lane stores one row as 4 consecutive floats: half the store instructions of the 8-byte
+        // form.  The destination is a per-lane pointer advanced by additions (the generic form below re-derives the 64-bit
+        // address, tests the activation code and loads its bias in front of every store: 26 k instructions for 64 stores).
+        auto epilogue = [&](auto fasttag) __attribute__((always_inline)) {
+            constexpr bool FAST = decltype(fasttag)::value;
             const int n = cur.n, cot = cur.cot;
             const int ox = cur.tx * 32 + l32;
             const bool want = p.stats != nullptr;
             if (want) __syncthreads();          // every wave is done with the fragments of stage buffer 1: it holds sred now
+            const bool odd = l32 & 1;
+            const int oyq = cur.ty * C::TH + wpx * NT + (odd ? 1 : 0);            // FAST: the pixel row this lane stores
+            float* lane_dst = p.y + (long long)n * p.o_nstride + (long long)(cot * CO_TILE + 4 * half) * p.o_cstride +
+                              (long long)(oyq * 2) * p.o_rstride + (ox & ~1) * 2;
+            const long long cs = p.o_cstride;
 #pragma unroll
-            for (int phy = 0; phy < 2; ++phy)
+            for (int phy = 0; phy < 2; ++phy) {
+                float* dst_r = lane_dst + (long long)phy * p.o_rstride;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
                     const int co = cot * CO_TILE + row;
                     const bool cok = co < p.Cout;
-                    const float bv = (p.bias != nullptr && cok) ? p.bias[co] : 0.f;
+                    const float bv = (!FAST && p.bias != nullptr && cok) ? p.bias[co] : 0.f;     // (FAST: no bias)
                     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+                    if constexpr (FAST) {
+                        static_assert(NT == 2, "one pixel row per lane of a pair");
+                        float own[2][2];
 #pragma unroll
-                    for (int q = 0; q < NT; ++q) {
-                        const int oy = cur.ty * C::TH + wpx * NT + q;
-                        const bool inside = oy < p.OH && ox < p.OW;
-                        const float v0 = acc[phy * 2][q][r] + bv, v1 = acc[phy * 2 + 1][q][r] + bv;
-                        if (inside) { s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1; }
-                        if (inside && cok) {
-                            float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
-                                         (long long)(oy * 2 + phy) * p.o_rstride + ox * 2;
-                            *reinterpret_cast<float2*>(dst) = make_float2(apply_act(v0, p.act), apply_act(v1, p.act));
+                        for (int q = 0; q < NT; ++q) {
+                            own[q][0] = acc[phy * 2][q][r] + bv;
+                            own[q][1] = acc[phy * 2 + 1][q][r] + bv;
+                        }
+                        const float g0 = odd ? own[0][0] : own[1][0], g1 = odd ? own[0][1] : own[1][1];     // the pair this lane gives away
+                        const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g0), 0xB1, 0xF, 0xF, true));
+                        const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g1), 0xB1, 0xF, 0xF, true));
+                        if (cok && oyq < p.OH && ox < p.OW)
+                            *reinterpret_cast<float4*>(dst_r) = odd ? make_float4(r0, r1, own[1][0], own[1][1])
+                                                                    : make_float4(own[0][0], own[0][1], r0, r1);
+                        dst_r += ((r & 3) == 3 ? 5 : 1) * cs;                     // rows 0..3, 8..11, 16..19, 24..27 (+ 4 half)
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NT; ++q) {
+                            const int oy = cur.ty * C::TH + wpx * NT + q;
+                            const bool inside = oy < p.OH && ox < p.OW;
+                            const float v0 = acc[phy * 2][q][r] + bv, v1 = acc[phy * 2 + 1][q][r] + bv;
+                            if (inside) { s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1; }
+                            if (inside && cok) {
+                                float* dst = p.y + (long long)n * p.o_nstride + (long long)co * p.o_cstride +
+                                             (long long)(oy * 2 + phy) * p.o_rstride + ox * 2;
+                                *reinterpret_cast<float2*>(dst) = make_float2(apply_act(v0, p.act), apply_act(v1, p.act));
+                            }
                         }
                     }
-                    if (want) {
+                    if (!FAST && want) {
                         float v[4] = {s0, q0, s1, q1};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {               // sum over the 32 lanes of the half-wave
@@ -296,6 +354,39 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
                         }
                     }
                 }
+            }
+            if constexpr (FAST) {
+                if (want) {
+                    // row sums of the four phases: one transpose-reduce per (phase, quantity) over the 16 cout rows a lane holds
+                    const bool in0 = cur.ty * C::TH + wpx * NT < p.OH && ox < p.OW, in1 = cur.ty * C::TH + wpx * NT + 1 < p.OH && ox < p.OW;
+                    const int rr = ((l32 >> 4) & 1) * 8 + ((l32 >> 3) & 1) * 4 + ((l32 >> 2) & 1) * 2 + ((l32 >> 1) & 1);
+                    const int my_row = (rr & 3) + 8 * (rr >> 2) + 4 * half;
+#pragma unroll
+                    for (int ph = 0; ph < 4; ++ph) {
+                        float st, qt;
+                        {
+                            float v[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v[r] = (in0 ? acc[ph][0][r] : 0.f) + (in1 ? acc[ph][1][r] : 0.f);
+                            st = fold16_half(v, l32);
+                        }
+                        {
+                            float v[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float a = in0 ? acc[ph][0][r] : 0.f, b = in1 ? acc[ph][1][r] : 0.f;
+                                v[r] = a * a + b * b;
+                            }
+                            qt = fold16_half(v, l32);
+                        }
+                        if ((l32 & 1) == 0) {
+                            float* d = sred + ((ph * C::WPX + wpx) * CO_TILE + my_row) * 2;
+                            d[0] = st;
+                            d[1] = qt;
+                        }
+                    }
+                }
+            }
             if (want) {
                 __syncthreads();
                 if (tid < 4 * CO_TILE) {
@@ -314,13 +405,20 @@ __global__ __launch_bounds__(256, 2) void conv_ph4(const ConvKParams p) {
                     }
                 }
             }
-        }
+        };
+        // (wave-uniform) whole pixel pairs, 16-byte aligned rows, no activation, no bias
+        if (p.act == 0 && p.bias == nullptr && (p.OW & 1) == 0 && (p.o_rstride & 3) == 0 && (p.o_cstride & 3) == 0 && (p.o_nstride & 3) == 0 &&
+            (reinterpret_cast<uintptr_t>(p.y) & 15) == 0)
+            epilogue(std::true_type{});
+        else
+            epilogue(std::false_type{});
         if (!has_next) break;
         cur = nxt;
 #pragma unroll
         for (int k = 0; k < NXW; ++k) cgoff[k] = ngoff[k];
         tile += tile_step;
     }
+    dma_wait_all();                                                // (the last tile's last chunk staged a chunk nobody reads)
 }
 
 }  // namespace apamd
