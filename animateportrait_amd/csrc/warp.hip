@@ -150,6 +150,9 @@ __device__ __forceinline__ void store_split_slot_s2d(uint4* xs, int n, int CG2, 
 // pixels x 8 channels) as ONE contiguous request per member and row, then transpose the 4 x 4 x 16-byte block inside the quad
 // with DPP quad_perm exchanges: a quarter of the L1 requests of the lane-per-pixel gather for ~200 more vector instructions per
 // pixel.  Measured slower (profiles/r04_warp_variants.md); kept so that the rejection has its measurement.
+#ifndef APAMD_WARP_WPE
+#define APAMD_WARP_WPE 4
+#endif
 template <int ACT, int WPE, int GATHER = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void warp_concat_kernel(const float* __restrict__ x, const float* __restrict__ x_mean,
                                                           const float* __restrict__ x_rstd, int x_act,
@@ -210,6 +213,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const int o00 = ly.i0 * S + lx.i0, o01 = ly.i0 * S + lx.i1, o10 = ly.i1 * S + lx.i0, o11 = ly.i1 * S + lx.i1;
         const float2* mo = reinterpret_cast<const float2*>(motion) + n * SS;
         const float2 a = mo[o00], b = mo[o01], c = mo[o10], d = mo[o11];
+#ifdef APAMD_HZ_NOP
+        asm volatile("s_nop 4" ::: "memory");       // co-residency lab, victim-side variant: idle states behind the four tap loads
+#endif
         gx = bilerp(a.x, b.x, c.x, d.x, ly, lx);
         gy = bilerp(a.y, b.y, c.y, d.y, ly, lx);
         const float* f0 = flow + (n * 2 + 0) * SS;
@@ -396,6 +402,9 @@ __global__ __launch_bounds__(256) void warp_concat_bwd_kernel(const float* __res
         const int o00 = ly.i0 * S + lx.i0, o01 = ly.i0 * S + lx.i1, o10 = ly.i1 * S + lx.i0, o11 = ly.i1 * S + lx.i1;
         const float2* mo = reinterpret_cast<const float2*>(motion) + n * SS;
         const float2 a = mo[o00], b = mo[o01], c = mo[o10], d = mo[o11];
+#ifdef APAMD_HZ_NOP
+        asm volatile("s_nop 4" ::: "memory");       // co-residency lab, victim-side variant: idle states behind the four tap loads
+#endif
         gx = bilerp(a.x, b.x, c.x, d.x, ly, lx);
         gy = bilerp(a.y, b.y, c.y, d.y, ly, lx);
         const float* f0 = flow + (n * 2 + 0) * SS;
@@ -481,6 +490,9 @@ __device__ __forceinline__ PixelTaps pixel_taps(int n, int oy, int ox, const flo
         const int o00 = ly.i0 * S + lx.i0, o01 = ly.i0 * S + lx.i1, o10 = ly.i1 * S + lx.i0, o11 = ly.i1 * S + lx.i1;
         const float2* mo = reinterpret_cast<const float2*>(motion) + n * SS;
         const float2 a = mo[o00], b = mo[o01], c = mo[o10], d = mo[o11];
+#ifdef APAMD_HZ_NOP
+        asm volatile("s_nop 4" ::: "memory");       // co-residency lab, victim-side variant: idle states behind the four tap loads
+#endif
         gx = bilerp(a.x, b.x, c.x, d.x, ly, lx);
         gy = bilerp(a.y, b.y, c.y, d.y, ly, lx);
         const float* f0 = flow + (n * 2 + 0) * SS;
@@ -899,13 +911,14 @@ extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const 
     if (tw_shift < 4 || tw_shift > 6 || (W & ((1 << tw_shift) - 1)) || (H & ((256 >> tw_shift) - 1))) tw_shift = 0;
     // (WPE = 4: 112 registers, no spills.  A budget for 5 waves per SIMD -- 96 registers, a dozen spills -- measured 210 us
     // against 154 us at the 256^2 level.)
-    auto* kern = x_act == 1 ? warp_concat_kernel<1, 4> : (x_act == 2 ? warp_concat_kernel<2, 4> : warp_concat_kernel<0, 4>);
+    // (APAMD_WARP_WPE: victim-side variants of the co-residency lab, tools/hazard/build_victims.sh; the product builds 4)
+    auto* kern = x_act == 1 ? warp_concat_kernel<1, APAMD_WARP_WPE> : (x_act == 2 ? warp_concat_kernel<2, APAMD_WARP_WPE> : warp_concat_kernel<0, APAMD_WARP_WPE>);
     // A/B switch for tools/warp_fwd_bench.py: the quad-cooperative gather (channel-octet inputs, whole 256-pixel blocks of
     // 4-aligned rows, so that every quad is four live neighbours of one row)
     const char* gather = getenv("APAMD_WARP_GATHER");           // read per call: tests flip it inside one process
     const bool quad = gather && !strcmp(gather, "quad");
     if (quad && (flags & 2) && (W & 3) == 0 && W >= 4 && ((H * W) & 255) == 0)
-        kern = x_act == 1 ? warp_concat_kernel<1, 4, 1> : (x_act == 2 ? warp_concat_kernel<2, 4, 1> : warp_concat_kernel<0, 4, 1>);
+        kern = x_act == 1 ? warp_concat_kernel<1, APAMD_WARP_WPE, 1> : (x_act == 2 ? warp_concat_kernel<2, APAMD_WARP_WPE, 1> : warp_concat_kernel<0, APAMD_WARP_WPE, 1>);
     hipLaunchKernelGGL(kern, grid, dim3(256), 0, (hipStream_t)stream, x, x_mean, x_rstd, x_act, motion,
                        flow, ifmask, out, reinterpret_cast<uint4*>(xs), C, H, W, S, flow_scale, flags & 3, tw_shift);
     return check_launch("warp_concat_kernel");

@@ -97,6 +97,24 @@ for v, note in ((0, '128 + 128 regs'), (8, '136 + 128'), (9, '144 + 128'), (10, 
     HZ.hz_aggr_registers(v, ctypes.byref(n))
     AGGR['synth:%d (%s; numRegs %d)' % (v, note, n.value)] = a_synth(v)
 
+# ---------------------------------------------------------------- victim-side experiment: the victim ALONE behind a poison kernel
+if os.environ.get('POISON'):
+    psink = torch.zeros(4, dtype=torch.int32, device=dev)
+    nrep = int(os.environ.get('POISON', '200'))
+    for vn, vf in VICTIMS.items():
+        with torch.no_grad():
+            ref = vf().clone()
+        torch.cuda.synchronize()
+        bad = 0
+        for _ in range(nrep):
+            assert HZ.hz_poison_launch(P(psink), cur()) == 0
+            with torch.no_grad():
+                o = vf()
+            torch.cuda.synchronize()
+            bad += int(not torch.equal(o, ref))
+        print('%-7s ALONE behind the poison kernel (NaN in every VGPR / AGPR / LDS dword of every CU): wrong launches %4d of %d' % (vn, bad, nrep), flush=True)
+    sys.exit(0)
+
 only_v = os.environ.get('VICTIMS')
 only_a = os.environ.get('AGGRESSORS')
 if only_v:
