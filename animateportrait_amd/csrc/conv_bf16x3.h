@@ -543,6 +543,14 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     const bool more = c + 1 < nchunks;
                     const bool tail = c + 2 >= nchunks;
                     const DmaCtx d = dma_setup(tail ? nxt.n : cur.n, tail ? nxt.cot : cur.cot, tail ? 0 : c + 2, P);
+                    // (the offset selects sit HERE, in front of the barrier: vector selects on SGPR-pair masks between LDS-DMA
+                    // pieces and MFMAs are what makes a kernel disturb a co-resident one, profiles/r04_cohazard.md)
+                    int ig[NIT];
+#pragma unroll
+                    for (int k = 0; k < NIT; ++k) {
+                        ig[k] = tail ? ngoff[k] : cgoff[k];
+                        asm volatile("" : "+v"(ig[k]));                 // (pinned here: the compiler sinks the select to its use)
+                    }
                     stage_sync(c);
                     constexpr int PPS = (NPIECE + NM - 1) / NM;                 // DMA pieces per MFMA slot
                     constexpr int RPS = (NRD + NM - 1) / NM;                    // fragment reads per MFMA slot
@@ -550,14 +558,15 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     const bool real_tap = K != 0 || ((tm >> tp) & 1u);
                     // (the MFMAs stay in straight-line code: with them inside the two arms of a branch the accumulators became phi
                     // nodes and the allocator moved all 128 between AGPRs and VGPRs every stage)
-                    const bool dma = more && !AP_ABLATE(p, 1);
+                    // (as scalar integers: left as `bool`s the compiler parks the condition in a VGPR and tests it from there)
+                    const int dma = __builtin_amdgcn_readfirstlane((more && !AP_ABLATE(p, 1)) ? 1 : 0);
                     static_for<NM>([&](auto it) __attribute__((always_inline)) {
                         constexpr int i = decltype(it)::value;
                         if (real_tap) mfma_one(i);
                         static_for<PPS>([&](auto ppt) __attribute__((always_inline)) {
                             constexpr int j = i * PPS + decltype(ppt)::value;
                             if constexpr (j < NPIECE) {
-                                if (dma) dma_piece(d, cgoff, ngoff, tail, std::integral_constant<int, j>{});
+                                if (dma) dma_piece(d, ig, ig, false, std::integral_constant<int, j>{});
                             }
                         });
                         if constexpr (XPF && i >= R0) {
