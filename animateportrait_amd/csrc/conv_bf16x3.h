@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     // a CU's LDS port keep that port ~75 % busy, so the head-only 3x3 kernel takes the window too (36 instead of 54 reads per chunk):
     // 132.8-134.8 -> 130.3 us per launch in the plain-bf16 train step (gpurun_out/r04ah_train_bf16_kernel_stats.md), i.e. the
     // port was not the bound either; kept because it is not slower.
-    constexpr bool WIN = (K == 4 || (K == 3 && C::PARTS == 1 && NT > 1)) && !C::ROW && S == 1;
+    constexpr bool WIN = (K == 4 || (K == 3 && NT > 1)) && !C::ROW && S == 1;
     constexpr int WR = WIN ? NT + K - 1 : 1;
     bf16x8 wh[2][WR], wl[2][WR];                                   // [kx parity][window row]
     auto fetch_a = [&](int stage_buf, int t, int buf) __attribute__((always_inline)) {

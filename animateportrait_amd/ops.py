@@ -611,7 +611,7 @@ def _zero_counters(n, device):
 # Convolution + InstanceNorm in one launch (ap_conv2d_fwd_norm) for the trunk of the generators in inference: OPT-IN.  Measured at
 # B = 16 it removes the 18 norm_split passes of a forward (0.6 ms) and gives the time back in its own epilogue -- every workgroup
 # bursts its (larger) output at the same moment and the matrix pipe idles meanwhile: 2131 vs 2110 and 2207 vs 2204 frames/s on two
-# boxes.  Not worth a kernel that waits on its peers by default.
+# boxes (HISTORY.md section 3.11).  Not worth a kernel that waits on its peers by default.
 FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
 
 

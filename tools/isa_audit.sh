@@ -2,7 +2,7 @@
 #   bash tools/isa_audit.sh conv_direct.h 'template __global__ void conv_direct_f32<DirectCfg<7, 1>>(const DirectKParams);' conv_direct_f32
 #   bash tools/isa_audit.sh warp.hip '' warp_concat_kernelILi1 -ffp-contract=off
 # Prints registers / spills / LDS of the kernel and its instruction histogram (how the per-element branch patterns of
-# DESIGN.md section 3.9b were found: count v_cndmask / s_cbranch / s_waitcnt against the arithmetic the kernel exists for).
+# HISTORY.md section 3.9b were found: count v_cndmask / s_cbranch / s_waitcnt against the arithmetic the kernel exists for).
 SRC=$1; INST=$2; PAT=$3; shift 3
 CS=$(dirname $0)/../animateportrait_amd/csrc
 OUT=${TMPDIR:-/tmp}/isa_audit; mkdir -p $OUT

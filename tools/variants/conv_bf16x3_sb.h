@@ -6,7 +6,7 @@
 // single stage (DMA, wait, multiply, repeat: nothing overlaps INSIDE it) and the CU's second workgroup fills its gaps: while
 // one waits for its DMA or writes its output, the other multiplies.  Same operands, same tile (64 couts x 16 rows x 32
 // columns), same arithmetic and accumulation order per tile as conv_bf16x3 -- the results are bit-identical.
-// Experiment of round 4; selected by APAMD_CONV_SB=1.
+// Experiment of round 4 (HISTORY.md section 3.12); selected by APAMD_CONV_SB=1.
 #pragma once
 #include "conv_bf16x3.h"
 

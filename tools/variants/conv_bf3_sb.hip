@@ -1,4 +1,4 @@
-// Rejected variant of the dominant 3x3 kernel, built only by `make -C animateportrait_amd/csrc variants`
+// Rejected variant of the dominant 3x3 kernel (HISTORY.md section 3.12), built only by `make -C animateportrait_amd/csrc variants`
 // into libapamd_variants.so and selected there with APAMD_CONV_SB=1 (tools/sb_check.py).
 #include "conv_bf16x3_sb.h"
 namespace apamd {
