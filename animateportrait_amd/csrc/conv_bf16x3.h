@@ -341,8 +341,10 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
     // one of row q+1 at tap (ky, kx).  With the taps walked column by column (kx outer, ky inner) a wave keeps a sliding
     // window of NT + K - 1 row fragments per kx and reads ONE new row per tap (NT at a column change) instead of NT.
     // Used for the 4x4 layers (MT = 1: 22 instead of 40 ds_read_b128 per tap column, 196 -> 170..185 us on the
-    // PatchGAN's 256 -> 512 layer); the 3x3 kernel (MT = 2: 72 instead of 108 per chunk) measured no faster with it --
-    // its fragment reads already hide under the MFMAs -- and keeps the plain tap order.
+    // PatchGAN's 256 -> 512 layer).  The split 3x3 kernel (MT = 2: 72 instead of 108 per chunk) is no faster per launch with it
+    // -- its fragment reads already hide under the MFMAs -- but a third fewer LDS reads is power the chip gives back as clock:
+    // 2257 / 2258 / 2259 -> 2272 / 2275 / 2263 frames/s, same box, interleaved (round 5, gpurun_out/r05n; the kernel runs at the
+    // board's power limit, profiles/r05e_power_gen.md), so it takes the window as well.
     // ... with ONE product per tap (plain bf16, PARTS = 1) it is the other way round: 6 fragment reads per 8 MFMAs and 8 waves on
     // a CU's LDS port keep that port ~75 % busy, so the head-only 3x3 kernel takes the window too (36 instead of 54 reads per chunk):
     // 132.8-134.8 -> 130.3 us per launch in the plain-bf16 train step (gpurun_out/r04ah_train_bf16_kernel_stats.md), i.e. the

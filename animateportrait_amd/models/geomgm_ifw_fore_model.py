@@ -184,10 +184,14 @@ class GeomGMIFWForeModel(BaseModel):
                 self.real_B3, self.real_B4 = dev('B3'), dev('B4')
         if self.aux['netF'] is not None:                                         # :503-505
             nf = self.aux['netF']                 # the frozen FlowUnet module itself; pre / post stages run on the device
-            self.iw_flow, self.real_A_if_mask = losses.flow_network_warp(nf, self.real_A, self.real_A_lm_68[:, :68],
-                                                                         self.target_B_lm_68[:, :68])
-            self.iw_flow2, self.real_A_if_mask2 = losses.flow_network_warp(nf, self.real_A, self.real_A_lm_68[:, :68],
-                                                                           self.target_B2_lm_68[:, :68])
+            # the reference calls flow_network_warp twice (photo -> target, photo -> second target); the frozen net is
+            # sample-independent (eval mode), so both calls run as ONE 2B batch: half the launches on its small maps
+            b = self.real_A.shape[0]
+            lm_a = self.real_A_lm_68[:, :68]
+            flow2, mask2 = losses.flow_network_warp(nf, self.real_A, torch.cat([lm_a, lm_a], 0),
+                                                    torch.cat([self.target_B_lm_68[:, :68], self.target_B2_lm_68[:, :68]], 0))
+            self.iw_flow, self.iw_flow2 = flow2[:b].contiguous(), flow2[b:].contiguous()
+            self.real_A_if_mask, self.real_A_if_mask2 = mask2[:b].contiguous(), mask2[b:].contiguous()
         else:
             self._notice('netF', 'no intrinsic-flow network: iw_flow / if_mask are read from the batch')
             self.iw_flow, self.real_A_if_mask = dev('iw_flow'), dev('if_mask')
