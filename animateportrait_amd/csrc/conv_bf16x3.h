@@ -49,9 +49,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // epilogue -- the workgroups that hold the tiles of one (image, cout tile) exchange their per-channel sums through global
 // memory (two rounds: mean, then centred squares), so the raw fp32 output never travels to HBM and the norm_split pass
 // between two convolutions disappears.  See fused_norm_epilogue in the kernel and ap_conv2d_fwd_norm.
-template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2, int S2D3_ = 0, int FNORM_ = 0>
+// OB16_ = 1 (plain bf16 arithmetic, dense 3x3 stride 1): the OUTPUT is stored as bf16 (round to nearest even; statistics from the
+// fp32 accumulators) -- the raw outputs of the ResNet trunk and the gradients that leave its data-gradient convolutions in the
+// plain-bf16 train step (ap_conv2d_fwd_bf16out): every reader of those tensors rounds them to bf16 anyway.
+template <int S_, int K_, int WCO_, int MT_, int WPX_, int NT_, int NTAP_ = 0, int ROW_ = 0, int PARTS_ = 2, int S2D3_ = 0, int FNORM_ = 0,
+          int OB16_ = 0>
 struct Bf3Cfg {
     static constexpr int FNORM = FNORM_;
+    static constexpr int OB16 = OB16_;
+    static_assert(!OB16_ || (K_ == 3 && S_ == 1 && PARTS_ == 1 && !FNORM_ && !ROW_), "bf16 output: the plain-bf16 3x3 stride-1 tiles");
     static_assert(!FNORM_ || (K_ == 3 && S_ == 1 && WCO_ == 1 && PARTS_ == 2), "fused normalisation: the 3x3 stride-1 split-bf16 tile");
     static constexpr int CI = 16, S = S_, K = K_, WCO = WCO_, MT = MT_, WPX = WPX_, NT = NT_, ROW = ROW_, PARTS = PARTS_;
     static constexpr int S2D3 = S2D3_;
@@ -754,7 +760,27 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                             const float vv[4] = {v.x + bv, v.y + bv, v.z + bv, v.w + bv};
                             if (cokc[ps] && oy < p.OH) {
                                 float* dst = p.y + cbase[ps] + rowoff;
-                                if (full) {
+                                if constexpr (C::OB16) {
+                                    // bf16 output: the same element offsets on a 2-byte element; 8-byte stores of 4 pixels (4-byte
+                                    // alignment suffices: the padded rows of a data gradient start at odd pixel pairs)
+                                    typedef unsigned u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+                                    __bf16* d16 = reinterpret_cast<__bf16*>(p.y) + cbase[ps] + rowoff;
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        if (full || oxv + j < p.OW) { s4[ps] += vv[j]; q4[ps] += vv[j] * vv[j]; }
+                                    if (full || (vec_ok && oxv + 3 < p.OW)) {
+                                        u32x2 pk;
+                                        pk[0] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(vv[0])) |
+                                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(vv[1])) << 16);
+                                        pk[1] = (unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(vv[2])) |
+                                                ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(vv[3])) << 16);
+                                        *reinterpret_cast<u32x2*>(d16) = pk;
+                                    } else {
+#pragma unroll
+                                        for (int j = 0; j < 4; ++j)
+                                            if (oxv + j < p.OW) d16[j * p.osx] = (__bf16)actf(vv[j]);
+                                    }
+                                } else if (full) {
                                     s4[ps] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
                                     q4[ps] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
                                     *reinterpret_cast<float4*>(dst) =
@@ -1092,7 +1118,8 @@ struct NormSplitParams {
 };
 
 // grid: (ceil(HW / (256 * VEC)), C/8, N); VEC pixels per thread (4 when HW % 4 == 0)
-template <int VEC>
+// XB16: x holds bf16 values (a raw convolution output stored by ap_conv2d_fwd_bf16out): same element offsets, 2-byte elements
+template <int VEC, bool XB16 = false>
 __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p) {
     __shared__ float s_m[8], s_r[8];
     __shared__ int s_bad[8];
@@ -1136,7 +1163,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
             const float* px = p.x + ((long long)n * C + cg * 8 + c) * HW;
             double s = 0.0, q = 0.0;
             for (int k = tid; k < HW; k += 256) {
-                const float d = px[k] - m0;
+                const float d = (XB16 ? (float)reinterpret_cast<const __bf16*>(p.x)[((long long)n * C + cg * 8 + c) * HW + k] : px[k]) - m0;
                 s += (double)d;
                 q += (double)d * (double)d;
             }
@@ -1190,7 +1217,16 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
         rm[c] = 0.f; rr[c] = 1.f;
         if (!live) continue;
         const long long off = ((long long)n * C + cg * 8 + c) * HW + pix;
-        if constexpr (VEC == 4) {
+        if constexpr (XB16) {
+            const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + off;
+            if constexpr (VEC == 4) {
+                const uint2 t = *reinterpret_cast<const uint2*>(xb);           // a bf16 is the upper half of the fp32 of the same value
+                v[c][0] = __uint_as_float(t.x << 16); v[c][1] = __uint_as_float(t.x & 0xffff0000u);
+                v[c][2] = __uint_as_float(t.y << 16); v[c][3] = __uint_as_float(t.y & 0xffff0000u);
+            } else {
+                v[c][0] = __uint_as_float((unsigned)xb[0] << 16);
+            }
+        } else if constexpr (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(p.x + off);
             v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
         } else {

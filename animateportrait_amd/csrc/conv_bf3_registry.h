@@ -20,6 +20,7 @@ struct Bf3Kernel {
     size_t (*lds_bytes1)(int);
     const void* fn_s2d3 = nullptr;    // the same tile with the compile-time tap sets of a space-to-depth 3x3 layer (Bf3Cfg::S2D3)
     const void* fn1_s2d3 = nullptr;
+    const void* fn1_ob16 = nullptr;   // plain-bf16 arithmetic with the OUTPUT stored as bf16 (Bf3Cfg::OB16; the 3x3 stride-1 tiles)
     const void* kernel(int precision) const { return precision == AP_PRECISION_BF16 ? fn1 : fn; }
     const void* kernel_s2d3(int precision) const { return precision == AP_PRECISION_BF16 ? fn1_s2d3 : fn_s2d3; }
     size_t lds(int precision, int ntaps) const { return precision == AP_PRECISION_BF16 ? lds_bytes1(ntaps) : lds_bytes(ntaps); }

@@ -605,12 +605,15 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
     p.heads_only = (flags & 1) ? 1 : 0;
     p.xs_relu = (flags & 2) ? 1 : 0;
     p.N = N; p.C = src->C; p.HW = H * W;
+    const bool xb16 = (flags & 8) != 0;       // src->data holds bf16 values (a raw output of ap_conv2d_fwd_bf16out)
     if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
         dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);
-        hipLaunchKernelGGL(norm_split_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (xb16) hipLaunchKernelGGL((norm_split_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((norm_split_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     } else {
         dim3 grid((p.HW + 255) / 256, src->C / 8, N);
-        hipLaunchKernelGGL(norm_split_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (xb16) hipLaunchKernelGGL((norm_split_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((norm_split_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
     }
     return check_launch("norm_split_kernel");
 }
@@ -771,7 +774,8 @@ int ap_conv2d_pack_run(const void* entries_dev, int32_t count, ap_stream_t strea
 }
 
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream, bool octet = false, const ap_fused_norm* fn = nullptr);
+                           float* stat_partials, ap_stream_t stream, bool octet = false, const ap_fused_norm* fn = nullptr,
+                           bool ob16 = false);
 
 int ap_conv2d_fwd(const ap_conv_desc* d, const float* packed, const float* bias, float* y,
                   float* stat_partials, ap_stream_t stream) {
@@ -800,6 +804,29 @@ int32_t ap_conv2d_octet_ok(const ap_conv_desc* d) {
 int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float* bias, float* y, float* stat_partials,
                         ap_stream_t stream) {
     return conv2d_fwd_impl(d, nullptr, packed, bias, y, stat_partials, stream, true);
+}
+
+// the bf16-output form exists for the plain-bf16 instantiations of the dense 3x3 stride-1 tiles (Bf3Cfg::OB16)
+static bool ob16_plan_ok(const ap_conv_desc* d, const Plan& pl) {
+    if (!pl.bf3 || pl.fused_phases || pl.ph4 || pl.launches.size() != 1 || d->precision != AP_PRECISION_BF16) return false;
+    return pl.bk && pl.bk->fn1_ob16 != nullptr;
+}
+
+int32_t ap_conv2d_bf16out_ok(const ap_conv_desc* d) {
+    Plan pl;
+    if (make_plan(d, pl)) return 0;
+    return ob16_plan_ok(d, pl) ? 1 : 0;
+}
+
+int ap_conv2d_fwd_bf16out(const ap_conv_desc* d, const float* packed, const float* bias, void* y_bf16, float* stat_partials,
+                          ap_stream_t stream) {
+    return conv2d_fwd_impl(d, nullptr, packed, bias, reinterpret_cast<float*>(y_bf16), stat_partials, stream, false, nullptr, true);
+}
+
+int ap_conv2d_fwd_view_bf16out(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, void* y_bf16,
+                               ap_stream_t stream) {
+    if (!view) return fail(AP_ERR_INVALID, "conv2d_fwd_view_bf16out: null view");
+    return conv2d_fwd_impl(d, view, packed, bias, reinterpret_cast<float*>(y_bf16), nullptr, stream, false, nullptr, true);
 }
 
 // ---- convolution + InstanceNorm in one launch (conv_bf16x3<..., FNORM>): which plans qualify, and is the launch deadlock-free?
@@ -860,10 +887,12 @@ int ap_conv2d_fwd_norm(const ap_conv_desc* d, const float* packed, const ap_fuse
 }
 
 static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, float* y,
-                           float* stat_partials, ap_stream_t stream, bool octet, const ap_fused_norm* fn) {
+                           float* stat_partials, ap_stream_t stream, bool octet, const ap_fused_norm* fn, bool ob16) {
     Plan pl;
     int rc = make_plan(d, pl);
     if (rc) return rc;
+    if (ob16 && (!ob16_plan_ok(d, pl) || octet || fn))
+        return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_bf16out: only the plain-bf16 dense 3x3 stride-1 layers store bf16 (ap_conv2d_bf16out_ok)");
     if (fn && !fnorm_plan_ok(d, pl))
         return fail(AP_ERR_UNSUPPORTED, "conv2d_fwd_norm: this layer / shape cannot normalise in its epilogue (ap_conv2d_fused_norm_ok)");
     if (!packed || !y) return fail(AP_ERR_INVALID, "null packed/y pointer");
@@ -932,7 +961,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         for (const auto& L : pl.launches) {
             const Bf3Kernel* kern = pl.ph4 ? pl.bk : bf3_for_taps(pl.bk, (int)L.taps.size());
             if (!kern) return fail(AP_ERR_UNSUPPORTED, "no split-bf16 kernel for a phase with %d taps", (int)L.taps.size());
-            const void* kfn = kern->kernel(d->precision);
+            const void* kfn = ob16 ? kern->fn1_ob16 : kern->kernel(d->precision);
             rc = ensure_lds_attr(kfn);
             if (rc) return rc;
             ConvKParams p;
