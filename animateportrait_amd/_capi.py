@@ -61,7 +61,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 8      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 9      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -104,6 +104,10 @@ SIGNATURES = {
     'ap_conv2d_fused_norm_counters': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
     'ap_conv2d_fwd_norm': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, ctypes.POINTER(ApFusedNorm), ctypes.c_void_p]),
     'ap_conv2d_fwd_octet': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_bf16out_ok': (ctypes.c_int32, [ctypes.POINTER(ApConvDesc)]),
+    'ap_conv2d_fwd_bf16out': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), c_f32p, c_f32p, ctypes.c_void_p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_fwd_view_bf16out': (ctypes.c_int, [ctypes.POINTER(ApConvDesc), ctypes.POINTER(ApOutView), c_f32p, c_f32p, ctypes.c_void_p,
+                                                  ctypes.c_void_p]),
     'ap_instnorm_apply': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]),
     'ap_warp_concat_fwd': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, ctypes.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,

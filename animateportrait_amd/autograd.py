@@ -208,6 +208,9 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         gfeat, gt, strip = ops.instnorm_bwd_split(red, out, gt_dims, want_xs, want_strip)
         dy = None
     else:
+        if out.data.dtype != torch.float32:      # (a bf16 raw output whose backward takes the fp32 route after all: convert once)
+            out = Feat(out.data.float(), out._mean, out._rstd, out.act)
+            contribs = [(g.float() if g.dtype != torch.float32 else g, pd) for g, pd in contribs]
         dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
         gfeat = Feat(dy)
     # ---- weight gradient
@@ -240,17 +243,24 @@ def conv_backward(tape, layer, srcs, out, norm, act):
             if fold_pad and ops.dgrad_strip_eligible(spec, gfeat):
                 # 66-column padded gradient: two whole tile columns + a transposed 2-column strip (ops.conv2d_dgrad_strip)
                 packed_t = layer.packed_dgrad((i, 'T'), spec, w.transpose(2, 3))
-                g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t, strip)
+                # (a source whose raw output is stored as bf16 has this gradient as its ONLY contribution and its InstanceNorm
+                # backward on the operand-writing route: the gradient is stored as bf16 too)
+                g = ops.conv2d_dgrad_strip(spec, gfeat, packed, packed_t, strip, out_bf16=f.data.dtype == torch.bfloat16)
             else:
                 g = ops.conv2d(spec, [gfeat], packed, None).data
             tape.add(f, g, fold_pad)
         c0 += c
 
 
-def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE, out_octet=False):
+def conv_forward(tape, layer, srcs, norm_act=None, act=ACT_NONE, out_octet=False, raw16=False):
+    """raw16: the raw output may be STORED as bf16 (plain-bf16 train step; the caller vouches that every reader of it is one of
+    ap_norm_apply_split, ap_instnorm_bwd_split and the padded-row operand kernel of the weight gradient: the main-branch
+    convolutions of the ResNet blocks)."""
     if not isinstance(srcs, (list, tuple)):
         srcs = [srcs]
-    out = layer.run(srcs, norm_act=norm_act, act=act, out_octet=out_octet and tape is None)
+    raw16 = (raw16 and tape is not None and norm_act is not None and ops.BF16_RAW and ops.DEFAULT_PRECISION == ops.PRECISION_BF16 and
+             layer.spec.precision == ops.PRECISION_BF16)
+    out = layer.run(srcs, norm_act=norm_act, act=act, out_octet=out_octet and tape is None, out_bf16=raw16)
     if tape is not None:
         tape.track(out)
         norm = norm_act is not None

@@ -10,6 +10,7 @@
 //   * bias_grad: per-channel sum of a gradient (layers whose bias is live: no InstanceNorm after them);
 //   * grad_fold_add: out = fold(a) + b  (residual stream accumulation).
 #include "common.h"
+#include <type_traits>
 
 #include <cstdlib>
 #include <cstring>
@@ -47,6 +48,21 @@ __device__ __forceinline__ float4 fold1_row4(const float* __restrict__ gp, int W
     float4 v = make_float4(t.x, t.y, t.z, t.w);
     if (x4 == 0) v.y += rp[0];                       // padded column 0 is the reflection of column 1
     if (x4 == W - 4) v.z += rp[W + 1];               // padded column W + 1 is the reflection of column W - 2
+    return v;
+}
+
+// ... on bf16 gradients (2-byte elements, any 2-byte alignment: the padded rows start at odd elements)
+__device__ __forceinline__ float bf16_val(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ float4 ld4_bf16(const unsigned short* __restrict__ q) {
+    typedef unsigned short us4 __attribute__((ext_vector_type(4), aligned(2)));
+    const us4 t = *reinterpret_cast<const us4*>(q);
+    return make_float4(bf16_val(t.x), bf16_val(t.y), bf16_val(t.z), bf16_val(t.w));
+}
+__device__ __forceinline__ float4 fold1_row4_bf16(const unsigned short* __restrict__ gp, int W, int py, int x4) {
+    const unsigned short* rp = gp + py * (W + 2);
+    float4 v = ld4_bf16(rp + x4 + 1);
+    if (x4 == 0) v.y += bf16_val(rp[0]);
+    if (x4 == W - 4) v.z += bf16_val(rp[W + 1]);
     return v;
 }
 
@@ -319,7 +335,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 }
 __device__ __forceinline__ float bf16_tail(float v) { return v - (float)(__bf16)v; }
 
-template <int NT>
+// YB16: y holds bf16 values (the raw output ap_conv2d_fwd_bf16out stored); G16: g1 holds bf16 values (a data gradient stored by
+// ap_conv2d_fwd_view_bf16out) -- same element offsets, 2-byte elements
+template <int NT, bool YB16 = false, bool G16 = false>
 __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplitParams p) {
     constexpr int NW = NT / 64;
     __shared__ float red[16][NW];
@@ -352,8 +370,17 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
             yv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             gq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) {
-                yv[c] = reinterpret_cast<const float4*>(p.y + nc * HW)[tid];
-                if (fold1) {         // the padded row itself; its reflected border terms follow
+                if constexpr (YB16) {
+                    const uint2 t = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) + nc * HW)[tid];
+                    yv[c] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                        __uint_as_float(t.y & 0xffff0000u));
+                } else {
+                    yv[c] = reinterpret_cast<const float4*>(p.y + nc * HW)[tid];
+                }
+                if constexpr (G16) {
+                    const unsigned short* g16 = reinterpret_cast<const unsigned short*>(p.g1);
+                    gq[c] = fold1 ? ld4_bf16(g16 + nc * (H + 2) * (W + 2) + (row + 1) * (W + 2) + x4 + 1) : ld4_bf16(g16 + nc * HW + tid * 4);
+                } else if (fold1) {         // the padded row itself; its reflected border terms follow
                     const float4u t = *reinterpret_cast<const float4u*>(p.g1 + nc * (H + 2) * (W + 2) + (row + 1) * (W + 2) + x4 + 1);
                     gq[c] = make_float4(t.x, t.y, t.z, t.w);
                 } else {
@@ -364,12 +391,21 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
         if (fold1 && live) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+                if constexpr (G16) {
+                    const unsigned short* gp = reinterpret_cast<const unsigned short*>(p.g1) + ((long long)n * p.C + c0 + c) * (H + 2) * (W + 2);
+                    const unsigned short* rp = gp + (row + 1) * (W + 2);
+                    if (x4 == 0) gq[c].y += bf16_val(rp[0]);
+                    if (x4 == W - 4) gq[c].z += bf16_val(rp[W + 1]);
+                    if (row == 1) { const float4 t = fold1_row4_bf16(gp, W, 0, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
+                    if (row == H - 2) { const float4 t = fold1_row4_bf16(gp, W, H + 1, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
+                } else {
                 const float* gp = p.g1 + ((long long)n * p.C + c0 + c) * (H + 2) * (W + 2);
                 const float* rp = gp + (row + 1) * (W + 2);
                 if (x4 == 0) gq[c].y += rp[0];
                 if (x4 == W - 4) gq[c].z += rp[W + 1];
                 if (row == 1) { const float4 t = fold1_row4(gp, W, 0, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
                 if (row == H - 2) { const float4 t = fold1_row4(gp, W, H + 1, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
+                }
             }
         }
         if (p.g2 != nullptr && live) {
@@ -802,7 +838,9 @@ int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, cons
         if (p.GHp < H || p.GX8 * 8 < W || p.Mp < C)
             return fail(AP_ERR_INVALID, "instnorm_bwd_split: operand %d x %d x %d smaller than the gradient", p.GHp, p.GX8, p.Mp);
     }
-    p.strip = strip; p.dy = dy; p.heads_only = heads_only ? 1 : 0;
+    // heads_only: bit 0 = only head planes are written; bit 1 = y holds bf16 values; bit 2 = g1 holds bf16 values
+    p.strip = strip; p.dy = dy; p.heads_only = (heads_only & 1) ? 1 : 0;
+    const bool yb16 = (heads_only & 2) != 0, g16 = (heads_only & 4) != 0;
     p.N = N;
     static int cus = 0;
     if (cus == 0) {
@@ -815,8 +853,15 @@ int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, cons
     const bool small = H * W / 4 <= 256;
     const int slots = cus * (small ? 4 : 1);          // resident workgroups: registers hold one 1024-thread item per CU, four of 256
     const dim3 grid(items < slots ? items : slots);
-    if (small) hipLaunchKernelGGL(instnorm_bwd_split_kernel<256>, grid, dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(instnorm_bwd_split_kernel<1024>, grid, dim3(1024), 0, (hipStream_t)stream, p);
+    auto launch = [&](auto nt) {
+        constexpr int NTH = decltype(nt)::value;
+        if (yb16 && g16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, true, true>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
+        else if (yb16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, true, false>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
+        else if (g16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, false, true>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, false, false>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
+    };
+    if (small) launch(std::integral_constant<int, 256>{});
+    else launch(std::integral_constant<int, 1024>{});
     return check_launch("instnorm_bwd_split_kernel");
 }
 

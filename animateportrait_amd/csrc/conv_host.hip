@@ -7,6 +7,7 @@
 #include "conv_registry.h"
 #include "conv_direct.h"
 #include "conv_bf3_registry.h"
+#include "conv_prepass.h"
 #include "conv_small.h"
 #include "conv_head.h"
 #include "conv_tsmall.h"

@@ -558,7 +558,16 @@ __global__ __launch_bounds__(256) void split_transpose_pad_kernel(const SplitTPa
                 const float* base = (sgi == 0 ? p.seg[0].data : (sgi == 1 ? p.seg[1].data : p.seg[2].data));
                 const int sc = sgi == 0 ? p.seg[0].C : (sgi == 1 ? p.seg[1].C : p.seg[2].C);
                 const int cs = c - (sgi == 0 ? 0 : (sgi == 1 ? p.seg[1].chunk_begin : p.seg[2].chunk_begin));
-                if (ok) v[i] = *reinterpret_cast<const float4*>(base + ((long long)n * sc + cs) * HW + soff);
+                const int b16 = sgi == 0 ? p.seg[0].pad_ : (sgi == 1 ? p.seg[1].pad_ : p.seg[2].pad_);   // the segment holds bf16 values
+                if (ok) {
+                    if (b16) {
+                        const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + ((long long)n * sc + cs) * HW + soff);
+                        v[i] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                                           __uint_as_float(t.y & 0xffff0000u));
+                    } else {
+                        v[i] = *reinterpret_cast<const float4*>(base + ((long long)n * sc + cs) * HW + soff);
+                    }
+                }
             }
         }
 #pragma unroll

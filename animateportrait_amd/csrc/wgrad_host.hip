@@ -254,14 +254,20 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     memset(&p, 0, sizeof(p));
     p.nseg = nseg;
     int cbeg = 0;
+    bool any_b16 = false;
     for (int s = 0; s < nseg; ++s) {
         p.seg[s].data = segs[s].data; p.seg[s].mean = segs[s].mean; p.seg[s].rstd = segs[s].rstd;
-        p.seg[s].C = segs[s].C; p.seg[s].act = segs[s].act; p.seg[s].chunk_begin = cbeg;
+        // ap_src.act bit 8: the segment's data are bf16 values (a raw output of ap_conv2d_fwd_bf16out); only the padded-row kernel reads those
+        p.seg[s].C = segs[s].C; p.seg[s].act = segs[s].act & 0xff; p.seg[s].chunk_begin = cbeg;
+        p.seg[s].pad_ = (segs[s].act >> 8) & 1;
+        any_b16 = any_b16 || p.seg[s].pad_;
         cbeg += segs[s].C;
     }
     p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
     p.s2d_c = s2d_c;
     p.heads_only = heads_only;
+    if (any_b16 && !(!getenv("APAMD_NO_SPLIT_ROWS") && (W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
+        return fail(AP_ERR_UNSUPPORTED, "split_transpose: a bf16 source needs the padded-row form (pad 1, W in {32, 64, 128, 256})");
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
     if (nseg == 1 && pad == 0 && s2d_c == 0 && X8 * 8 == W && !getenv("APAMD_NO_SPLIT_VEC")) {
         // unpadded operand with whole octet rows: 16-byte loads, 1 KiB per wave (split_transpose_vec_kernel)
@@ -424,6 +430,8 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
+        if ((d->src[s].act & 0x100) && !pl.bf3)      // bit 8: bf16 data (launch_split_transpose)
+            return fail(AP_ERR_UNSUPPORTED, "wgrad: segment %d holds bf16 values but the layer is not on the bf16 matrix plan", s);
     }
     if (pl.narrow_cob) {
         WgradNarrowParams p;

@@ -63,7 +63,7 @@ class ConvLayer(nn.Module):
     def packed(self):
         return self._packed('fwd', self.spec, ops.WeightView(self.weight.detach()))
 
-    def run(self, srcs, norm_act=None, act=ACT_NONE, out_octet=False):
+    def run(self, srcs, norm_act=None, act=ACT_NONE, out_octet=False, out_bf16=False):
         """norm_act=None: plain conv + bias + act.  norm_act=ACT_*: conv followed by InstanceNorm
         (bias skipped -- it cancels exactly under the mean subtraction) and that activation,
         both deferred to the consumer.  out_octet: see ops.conv2d (the output is read by the warp kernel only)."""
@@ -83,7 +83,8 @@ class ConvLayer(nn.Module):
             packed = self.packed()
         if norm_act is None:
             return ops.conv2d(spec, srcs, packed, self.bias.detach(), act=act, out_octet=out_octet)
-        return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act, out_octet=out_octet)
+        return ops.conv2d(spec, srcs, packed, None, want_stats=True, out_act=norm_act, out_octet=out_octet,
+                          out_bf16=out_bf16 and spec is self.spec)
 
     def stages_split(self, shape):
         """Whether this layer reads a source of ``shape`` (N, C, H, W) as its split-bf16 copy (then the producer may
@@ -144,8 +145,10 @@ class ResnetBlock(nn.Module):
             # no norm_split pass; the block's result lives as the split copy (next convolution) + channel-octet fp32 (next residual)
             y = c1.run_norm(x, act=ACT_RELU)
             return c5.run_norm(y, act=ACT_NONE, residual=x, want_oct=True)
-        y = conv_forward(tape, c1, x, norm_act=ACT_RELU)
-        y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
+        # (raw16: c1's raw output is read by c5's split pass, its own InstanceNorm backward and c5's weight gradient; c5's by the
+        # residual pass and its InstanceNorm backward -- all of which read bf16: plain-bf16 training stores them as bf16)
+        y = conv_forward(tape, c1, x, norm_act=ACT_RELU, raw16=True)
+        y = conv_forward(tape, c5, y, norm_act=ACT_NONE, raw16=True)
         return materialize_forward(tape, y, residual=x, consumer=consumer)
 
 
@@ -165,9 +168,9 @@ class ResnetBlock2(nn.Module):
             s = sc.run_norm(srcs, act=ACT_NONE, want_oct=True, want_xs=False)
             y = c1.run_norm(srcs, act=ACT_RELU)
             return c5.run_norm(y, act=ACT_NONE, residual=s, want_oct=True)
-        y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU)
-        y = conv_forward(tape, c5, y, norm_act=ACT_NONE)
-        s = conv_forward(tape, sc, srcs, norm_act=ACT_NONE)
+        y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU, raw16=True)
+        y = conv_forward(tape, c5, y, norm_act=ACT_NONE, raw16=True)
+        s = conv_forward(tape, sc, srcs, norm_act=ACT_NONE)            # (the shortcut's raw output is read as a normalised RESIDUAL: fp32)
         return materialize_forward(tape, y, residual=s, consumer=consumer)
 
 

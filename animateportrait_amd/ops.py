@@ -67,12 +67,23 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
-def _require_device(t, name):
+def _require_device(t, name, allow_bf16=False):
+    """allow_bf16: the caller's kernel also reads a tensor of bf16 values (a raw convolution output / a data gradient stored by
+    ap_conv2d_fwd_bf16out in the plain-bf16 train step) and is told so; everybody else refuses one loudly."""
     if not t.is_cuda:
         raise RuntimeError('animateportrait_amd: %s must live on the MI355X (got a %s tensor); '
                            'this package has no CPU path' % (name, t.device))
-    if t.dtype != torch.float32 or not t.is_contiguous():
-        raise RuntimeError('animateportrait_amd: %s must be contiguous fp32' % name)
+    if not t.is_contiguous() or not (t.dtype == torch.float32 or (allow_bf16 and t.dtype == torch.bfloat16)):
+        raise RuntimeError('animateportrait_amd: %s must be contiguous fp32%s (got %s)' % (name, ' or bf16' if allow_bf16 else '', t.dtype))
+
+
+# Plain-bf16 training (configs[2-3]): the raw outputs of the ResNet trunk's main-branch convolutions and the gradients that leave
+# their data-gradient convolutions are STORED as bf16 (ap_conv2d_fwd_bf16out; every reader rounds them to bf16 anyway);
+# APAMD_NO_BF16_RAW=1 keeps them fp32 (A/B).  Measured (round 5, profiles/r05p_bf16_raw.md): 148.7 -> 143.6 GB of HBM traffic per step,
+# -1.1 GB of memory, and only -0.4 ms of 56 -- the passes that read these tensors (norm_split, instnorm_bwd_split, the padded-row
+# operand transposition) run at 3.5-4.4 TB/s because of latency / issue, not bandwidth: with 8-byte instead of 16-byte loads per
+# lane they take as long per launch.
+BF16_RAW = os.environ.get('APAMD_NO_BF16_RAW', '0') != '1'
 
 
 class Feat:
@@ -126,6 +137,8 @@ class Feat:
                                                            _ptr(self._mean), _ptr(self._rstd), _stream()), 'instnorm_finalize_octet')
                 self.pending = None
                 return
+            if self.data.dtype != torch.float32:
+                raise RuntimeError('a bf16 raw output finalises its statistics inside ap_norm_apply_split (its first consumer), not here')
             C.check(C.lib().ap_instnorm_finalize(_ptr(partial), _ptr(self.data), n * c, tiles, h * w, EPS, _ptr(self._mean),
                                                  _ptr(self._rstd), _stream()), 'instnorm_finalize')
             self.pending = None
@@ -466,7 +479,7 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
     split copy is f's own and is cached on it."""
     x = f.data
     n, c, h, w = x.shape
-    _require_device(x, 'norm/split source')
+    _require_device(x, 'norm/split source', allow_bf16=True)
     s = C.ApSrc()
     s.data, s.C, s.act = x.data_ptr(), c, f.act
     partial, tiles, mo, ro = None, 0, None, None
@@ -495,11 +508,11 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
             r.data = residual.data.data_ptr()
             if residual.virtual:
                 r.mean, r.rstd = residual.mean.data_ptr(), residual.rstd.data_ptr()
-    y = torch.empty_like(x) if want_y else None
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device) if want_y else None
     xs = _alloc_xs(x) if want_xs else None
     # plain-bf16 mode: no kernel reads tail planes, so they are not written (the package-wide mode decides: split
     # copies are shared by every consumer of a feature)
-    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0) | res_flag
+    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0) | res_flag | (8 if x.dtype == torch.bfloat16 else 0)
     C.check(C.lib().ap_norm_apply_split_ex(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
                                            ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
                                            flags, _stream()), 'norm_apply_split')
@@ -526,7 +539,7 @@ def takes_split(spec, n, h, w):
     return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
 
 
-def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE, out_octet=False):
+def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_act=ACT_NONE, out_octet=False, out_bf16=False):
     """Run one convolution.  Returns a Feat:
     * want_stats=False: materialised ``act(conv + bias)``;
     * want_stats=True : raw conv output with its InstanceNorm statistics, to be consumed as
@@ -537,7 +550,7 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
     n, _, h, w = x0.shape
     for f, c in zip(srcs, spec.cin_segments):
         if not f.is_split_only:
-            _require_device(f.data, 'conv input')
+            _require_device(f.data, 'conv input', allow_bf16=True)      # (a bf16 source is legal only where it is staged as a split copy: below)
         if f.data.shape[1] != c or f.data.shape[0] != n or f.data.shape[2:] != x0.shape[2:]:
             raise ValueError('conv2d: source of shape %s does not match segment C=%d' % (tuple(f.data.shape), c))
     d = spec.desc(n, h, w, None, act)
@@ -556,14 +569,17 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
     else:
         if any(f.is_split_only for f in srcs):
             raise RuntimeError('conv2d: a source exists only as its split-bf16 copy but this layer reads fp32')
+        if any(f.data.dtype != torch.float32 for f in srcs):
+            raise RuntimeError('conv2d: a source holds bf16 values but this layer reads fp32')
         spec.fill_sources(d, srcs)
     ho, wo = ctypes.c_int32(), ctypes.c_int32()
     C.check(lib.ap_conv2d_out_size(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), 'conv2d_out_size')
     out_octet = bool(out_octet) and d.presplit == 1 and lib.ap_conv2d_octet_ok(ctypes.byref(d)) == 1
+    out_bf16 = bool(out_bf16) and not out_octet and d.presplit == 1 and lib.ap_conv2d_bf16out_ok(ctypes.byref(d)) == 1
     if out_octet:
         y = torch.empty((n, spec.cout // 8, ho.value * wo.value, 8), dtype=torch.float32, device=x0.device)
     else:
-        y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.float32, device=x0.device)
+        y = torch.empty((n, spec.cout, ho.value, wo.value), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x0.device)
     partial = None
     if want_stats:
         tiles = C.check(lib.ap_conv2d_stat_tiles(ctypes.byref(d)), 'conv2d_stat_tiles')
@@ -573,8 +589,8 @@ def conv2d(spec, srcs, packed, bias=None, act=ACT_NONE, want_stats=False, out_ac
         C.check(lib.ap_conv2d_kernel_name(ctypes.byref(d), buf, 96), 'conv2d_kernel_name')
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    C.check((lib.ap_conv2d_fwd_octet if out_octet else lib.ap_conv2d_fwd)(ctypes.byref(d), _ptr(packed), _ptr(bias), _ptr(y),
-                                                                          _ptr(partial), _stream()), 'conv2d_fwd')
+    fwd = lib.ap_conv2d_fwd_octet if out_octet else (lib.ap_conv2d_fwd_bf16out if out_bf16 else lib.ap_conv2d_fwd)
+    C.check(fwd(ctypes.byref(d), _ptr(packed), _ptr(bias), _ptr(y), _ptr(partial), _stream()), 'conv2d_fwd')
     if PROFILER is not None:
         e1.record()
         # algorithmic FLOPs = 2 * MACs of the dense operator (transposed: every input pixel x k*k taps)
@@ -711,8 +727,8 @@ def _conv2d_view(spec, srcs, packed, out, view):
         d.src[i].data = presplit(f, spec.precision).data_ptr()
         d.src[i].mean = d.src[i].rstd = None
         d.src[i].act = ACT_NONE
-    C.check(C.lib().ap_conv2d_fwd_view(ctypes.byref(d), ctypes.byref(view), _ptr(packed), None, _ptr(out), _stream()),
-            'conv2d_fwd_view')
+    fn = C.lib().ap_conv2d_fwd_view_bf16out if out.dtype == torch.bfloat16 else C.lib().ap_conv2d_fwd_view
+    C.check(fn(ctypes.byref(d), ctypes.byref(view), _ptr(packed), None, _ptr(out), _stream()), 'conv2d_fwd_view')
 
 
 def dgrad_strip_eligible(spec, g):
@@ -729,7 +745,7 @@ def dgrad_strip_eligible(spec, g):
     return bool(C.check(C.lib().ap_conv2d_wants_presplit(ctypes.byref(d)), 'wants_presplit'))
 
 
-def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None):
+def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None, out_bf16=False):
     """Padded-coordinate data gradient (N, Cin, H+2, W+2) of a reflection-padded 3x3 layer in two launches instead of a
     three-tile-column one: W+2 = 32 m + 2, so the last tile column of a plain launch would hold 2 of 32 columns.
     * the two last padded columns depend on the two last gradient columns only: the same operator on their
@@ -738,7 +754,11 @@ def conv2d_dgrad_strip(spec, g, packed, packed_t, strip=None):
     * the main launch then writes columns 0 .. W-1 (whole tile columns), overwriting those two."""
     n, c, h, w = g.data.shape
     hp, wp = h + 2, w + 2
-    out = torch.empty((n, spec.cout, hp, wp), dtype=torch.float32, device=g.data.device)
+    # out_bf16: the gradient is stored as bf16 (plain-bf16 train step; its only reader is ap_instnorm_bwd_split, which is told)
+    d0 = spec.desc(n, h, w, None, ACT_NONE)
+    d0.presplit = 1
+    out_bf16 = bool(out_bf16) and C.lib().ap_conv2d_bf16out_ok(ctypes.byref(d0)) == 1
+    out = torch.empty((n, spec.cout, hp, wp), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=g.data.device)
     if strip is None and g.is_split_only:
         raise RuntimeError('conv2d_dgrad_strip: the gradient exists only as its split copy and no column strip was prepared '
                            '(ap_instnorm_bwd_split writes it when the backward plan asks for one)')
@@ -951,11 +971,12 @@ def _wgrad_desc(k, stride, pad, pad_mode, g_shape, g, srcs, precision):
         d.g.rstd = g.rstd.data_ptr() if g.rstd is not None else None
         d.g.act = g.act
     for i, f in enumerate(srcs):
-        _require_device(f.data, 'wgrad source')
+        _require_device(f.data, 'wgrad source', allow_bf16=True)
         d.src[i].data = f.data.data_ptr()
         d.src[i].mean = f.mean.data_ptr() if f.mean is not None else None
         d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
-        d.src[i].C, d.src[i].act = f.data.shape[1], f.act
+        # ap_src.act bit 8: the segment holds bf16 values (the C side refuses it where its kernels cannot read them)
+        d.src[i].C, d.src[i].act = f.data.shape[1], f.act | (0x100 if f.data.dtype == torch.bfloat16 else 0)
     return d
 
 
@@ -1068,11 +1089,15 @@ def instnorm_bwd_split(red, f, gt_dims=None, want_xs=True, want_strip=False, wan
         gt = alloc(n * 2 * ghp * gx8 * mp * 16, dtype=torch.uint8, device=dev)
         dims = (ctypes.c_int32 * 3)(ghp, gx8, mp)
     strip = torch.empty((n, c, 2, h), dtype=torch.float32, device=dev) if want_strip else None
-    dy = torch.empty_like(f.data) if want_dy else None
+    dy = torch.empty(f.data.shape, dtype=torch.float32, device=dev) if want_dy else None
+    # bit 1: y holds bf16 values (ap_conv2d_fwd_bf16out); bit 2: so does the gradient g1 (ap_conv2d_fwd_view_bf16out)
+    flags = (1 if heads_only else 0) | (2 if f.data.dtype == torch.bfloat16 else 0) | (4 if g1.dtype == torch.bfloat16 else 0)
+    if g2 is not None and g2.dtype != torch.float32:
+        raise RuntimeError('instnorm_bwd_split: only the first gradient contribution may hold bf16 values')
     if PROFILER is not None:
         PROFILER.note('instnorm_bwd_split<%d>' % (h * w // 4))       # threads per (image, channel octet) item: 4 pixels each
     C.check(C.lib().ap_instnorm_bwd_split(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act, n, c, h, w,
-                                          _ptr(xs), _ptr(gt), dims, _ptr(strip), _ptr(dy), 1 if heads_only else 0, _stream()),
+                                          _ptr(xs), _ptr(gt), dims, _ptr(strip), _ptr(dy), flags, _stream()),
             'instnorm_bwd_split')
     if dy is not None:
         gf = Feat(dy)

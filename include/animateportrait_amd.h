@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 8
+#define AP_ABI_VERSION 9
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -197,6 +197,18 @@ int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const flo
 int32_t ap_conv2d_octet_ok(const ap_conv_desc* d);
 int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float* bias, float* y, float* stat_partials,
                         ap_stream_t stream);
+/* ap_conv2d_fwd / ap_conv2d_fwd_view with the OUTPUT stored as bf16 (round to nearest even; InstanceNorm partial sums still from the
+ * fp32 accumulators): the plain-bf16 train step (precision = AP_PRECISION_BF16, BASELINE configs[2-3]) stores the raw outputs of the
+ * ResNet trunk's convolutions (networks.py:2329-2421) and the gradients that leave their data-gradient convolutions this way --
+ * every reader of those tensors rounds them to bf16 anyway.  Only where ap_conv2d_bf16out_ok(d) == 1 (dense 3x3 stride-1 layers on
+ * the bf16 matrix path).  Readers that take such a tensor: ap_norm_apply_split_ex (flags bit 3), ap_instnorm_bwd_split (heads_only
+ * bit 1: y, bit 2: g1), the padded-row operand pass of ap_conv2d_wgrad (ap_src.act bit 8).  Element offsets / strides are those of
+ * the fp32 forms (in elements). */
+int32_t ap_conv2d_bf16out_ok(const ap_conv_desc* d);
+int ap_conv2d_fwd_bf16out(const ap_conv_desc* d, const float* packed, const float* bias, void* y_bf16, float* stat_partials,
+                          ap_stream_t stream);
+int ap_conv2d_fwd_view_bf16out(const ap_conv_desc* d, const ap_out_view* view, const float* packed, const float* bias, void* y_bf16,
+                               ap_stream_t stream);
 
 /* Split-bf16 path (precision = AP_PRECISION_BF16X3, wide 3x3 layers): the convolution consumes its sources as
  * split tensors XS[n][head|tail][C/8][H*W + 1][8 x bf16] (the last 16-byte slot of every plane is all-zero and

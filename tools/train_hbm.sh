@@ -6,7 +6,7 @@ TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp
 STEPS=3
-for ROUTE in split fp32route; do
+for ROUTE in ${ROUTES:-split fp32route}; do
   OFF=0; [ $ROUTE = fp32route ] && OFF=1
   for PASS in time fetch write; do
     D=$ROOT/gpurun_out/${TAG}_thbm_${ROUTE}_$PASS
