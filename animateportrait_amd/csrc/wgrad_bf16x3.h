@@ -39,11 +39,15 @@ struct WgradBf3Params {
 
 // PARTS_ = 2: head + tail staged, three products per tap.  PARTS_ = 1 (AP_PRECISION_BF16): head planes only -- half the
 // LDS stage and LDS-DMA traffic, one product per tap, two workgroups per CU.
-template <int K_, int PARTS_ = 2>
+// KY_ = 1: the ROW form of a K x K layer on few channels (the 7x7 stems): the shifted operand is prepared with one channel per
+// (input channel, kernel row) -- channel ci * K + ky of row y is the padded input row y + ky (split_transpose_kernel, rows_k) --
+// so the kernel sees a 1 x K layer over K * Cin channels: K taps, no row shift, and dW[m][ci * K + ky][kx] IS the OIHW tensor.
+template <int K_, int PARTS_ = 2, int KY_ = K_>
 struct WgradBf3Cfg {
-    static constexpr int K = K_, T = K * K, PR = 2, PARTS = PARTS_;
+    static constexpr int K = K_, KY = KY_, T = K * KY, PR = 2, PARTS = PARTS_;
     static_assert(PARTS == 1 || PARTS == 2, "head only, or head + tail");
-    static constexpr int ROWS = PR + K - 1;                 // staged rows of the shifted operand
+    static_assert(KY == K || KY == 1, "square taps, or the row form");
+    static constexpr int ROWS = PR + KY - 1;                // staged rows of the shifted operand
     static constexpr int NXG = 5;                           // staged octets per row: 4 + 1 for the column shift
     static constexpr int G_SLOTS = PARTS * PR * 4 * 64;     // [part][row][octet][m]
     static constexpr int A_SLOTS = PARTS * ROWS * NXG * 64; // [part][row][octet][ci]
@@ -75,7 +79,7 @@ __device__ __forceinline__ bf16x8 funnel8(const u32x4 lo, const u32x4 hi) {
 template <class C>
 __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3Params p) {
     constexpr int PARTS = C::PARTS, PROD = PARTS == 1 ? 1 : 3;
-    constexpr int K = C::K, T = C::T, ROWS = C::ROWS, NXG = C::NXG;
+    constexpr int K = C::K, KY = C::KY, T = C::T, ROWS = C::ROWS, NXG = C::NXG;
     constexpr int G_SLOTS = C::G_SLOTS, A_SLOTS = C::A_SLOTS, STAGE = G_SLOTS + A_SLOTS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const uint4* const smem = reinterpret_cast<const uint4*>(smem_raw);
@@ -167,28 +171,31 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     //                                the odd-shift operands of group g+1 are funnelled out of ITS raw octets,
     // so every LDS read and every vector-ALU result has a whole group (>= 9 MFMAs) before its first use, and the
     // products go round the K accumulators of the kernel row (consecutive MFMAs never wait on each other).
-    constexpr int NG = 4 * K;
-    constexpr int RB = K == 3 ? 3 : 4;                                 // raw-octet register sets (RB divides NG)
+    constexpr int NG = 4 * KY;
+    constexpr int RB = KY == 3 ? 3 : 4;                                // raw-octet register sets (RB divides NG)
     static_assert(NG % RB == 0 && NG % 2 == 0, "register set indices must be stage-invariant");
-    bf16x8 ah[2], al[2];                                               // by ks parity
+    // G fragments by ks parity -- in the row form (one group per K step) by group index mod RB, as the raw octets: the fetch of
+    // group g + 2 precedes the products of group g in program order
+    constexpr int NGF = KY == 1 ? RB : 2;
+    bf16x8 ah[NGF], al[NGF];
     u32x4 rh[RB][2], rl[RB][2];                                        // by group index mod RB: [octet j]
     bf16x8 sh[2][K], sl[2][K];                                         // funnelled operands by group parity (odd shifts)
     // live = false: the stage does not exist (the padding stage of an odd count, see the stage loop): its G fragments are
     // forced to zero, so its products are exact zeros whatever finite data the buffer holds
     auto fetch_group = [&](int buf, int gidx, bool live) __attribute__((always_inline)) {
-        const int ks = gidx / K, ky = gidx % K, rb = gidx % RB;
+        const int ks = gidx / KY, ky = gidx % KY, rb = gidx % RB;
         const int py = ks >> 1, xh = ks & 1;
         const uint4* S0 = smem + buf * STAGE;
         if (ky == 0) {
             u32x4 th = *reinterpret_cast<const u32x4*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * 64);
 #pragma unroll
             for (int d = 0; d < 4; ++d) th[d] = live ? th[d] : 0u;
-            ah[ks & 1] = __builtin_bit_cast(bf16x8, th);
+            ah[KY == 1 ? rb : (ks & 1)] = __builtin_bit_cast(bf16x8, th);
             if constexpr (PARTS == 2) {
                 u32x4 tl = *reinterpret_cast<const u32x4*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) tl[d] = live ? tl[d] : 0u;
-                al[ks & 1] = __builtin_bit_cast(bf16x8, tl);
+                al[KY == 1 ? rb : (ks & 1)] = __builtin_bit_cast(bf16x8, tl);
             }
         }
         const int row = py + ky;
@@ -206,16 +213,23 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
             sh[pb][3] = funnel8<3>(rh[rb][0], rh[rb][1]);
             if constexpr (PARTS == 2) sl[pb][3] = funnel8<3>(rl[rb][0], rl[rb][1]);
         }
+        if constexpr (K > 5) {
+            sh[pb][5] = funnel8<5>(rh[rb][0], rh[rb][1]);
+            if constexpr (PARTS == 2) sl[pb][5] = funnel8<5>(rl[rb][0], rl[rb][1]);
+        }
     };
     auto mfma_one = [&](int gidx, int i) __attribute__((always_inline)) {
-        const int ks = gidx / K, ky = gidx % K, rb = gidx % RB, pb = gidx & 1;
+        const int ks = gidx / KY, ky = gidx % KY, rb = gidx % RB, pb = gidx & 1;
         const int pr = PROD == 1 ? 2 : i / K, kx = i % K;               // product-major: round the K accumulators
         bf16x8 bh, bl;
         if (kx == 0) { bh = funnel8<0>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<0>(rl[rb][0], rl[rb][1]); }
         else if (kx == 2) { bh = funnel8<2>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<2>(rl[rb][0], rl[rb][1]); }
+        else if (kx == 4) { bh = funnel8<4>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<4>(rl[rb][0], rl[rb][1]); }
+        else if (kx == 6) { bh = funnel8<6>(rh[rb][0], rh[rb][1]); if constexpr (PARTS == 2) bl = funnel8<6>(rl[rb][0], rl[rb][1]); }
         else { bh = sh[pb][kx]; if constexpr (PARTS == 2) bl = sl[pb][kx]; }
         f32x16& a = acc[ky * K + kx];
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al[ks & 1] : ah[ks & 1], pr == 1 ? bl : bh, a, 0, 0, 0);
+        const int gs = KY == 1 ? rb : (ks & 1);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pr == 0 ? al[gs] : ah[gs], pr == 1 ? bl : bh, a, 0, 0, 0);
     };
 
     auto stage = [&](auto ptag, int st) __attribute__((always_inline)) {
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         }
         if (!live) {                                                   // (the fragments of its first groups were not fetched)
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NGF; ++i) {
                 ah[i] = bf16x8{};
                 if constexpr (PARTS == 2) al[i] = bf16x8{};
             }
@@ -352,6 +366,7 @@ struct SplitTParams {
     int N, C, H, W, pad, pad_mode, Hp, X8, Cp;
     int s2d_c;                // > 0: space-to-depth view of a pad-1 source with s2d_c channels (see below)
     int heads_only;           // 1: the consumer multiplies head parts only (AP_PRECISION_BF16): the tail planes are not written
+    int rows_k;               // > 0: row view of a K x K layer's source, K = rows_k (see below; split_transpose_kernel only)
     uint4* out;
 };
 
@@ -359,6 +374,9 @@ struct SplitTParams {
 // pad1(act(IN(concat(src))))[c][2 y + ry][2 x + rx] -- the operand of a stride-2 K x K (K = 3, 4) layer rewritten as
 // the 2 x 2 stride-1 layer over 4 C0 channels (as ap_split_prepass_s2d does for the forward pass), so that strided
 // weight gradients run on the same bf16 GEMM kernel.  p.H / p.W are then the source's own size and pad must be 0.
+// Row view (rows_k = K > 0): channel c' = c * K + ky of the H x (W + 2 pad) map is pad(act(IN(src)))[c][y + ky][x] -- the operand of
+// a K x K stride-1 layer on few channels rewritten as the 1 x K layer over K C channels (as ap_split_prepass_rows does for the
+// forward pass: WgradBf3Cfg KY = 1).  p.C is then the number of VIEW channels (K times the source's).
 // grid: (ceil(Hp * X8 / 8), Cp / 64, N): a workgroup transposes 8 consecutive octets (64 padded pixels, possibly
 // across a row boundary) of 64 channels.
 __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams p) {
@@ -374,6 +392,8 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
         bool ok = oct < noct && y < He && x < We;
         if (p.s2d_c > 0) {
             ok = oct < noct && y <= p.H / 2 && x <= p.W / 2;       // the view is (H/2 + 1) x (W/2 + 1)
+        } else if (p.rows_k > 0) {
+            ok = oct < noct && y < p.H && x < We;                  // the view is H x (W + 2 pad); rows resolved per channel
         } else if (p.pad_mode == 1) {
             sy = reflect_clamp(sy, p.H);
             sx = reflect_clamp(sx, p.W);
@@ -395,6 +415,17 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const SplitTParams
                     c -= r * p.s2d_c;
                     const int yy = 2 * y + (r >> 1) - 1, xx = 2 * x + (r & 1) - 1;
                     okc = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    so = okc ? yy * p.W + xx : 0;
+                } else if (p.rows_k > 0) {
+                    const int cc = c / p.rows_k;
+                    int yy = y + (c - cc * p.rows_k) - p.pad, xx = sx;
+                    c = cc;
+                    if (p.pad_mode == 1) {
+                        yy = reflect_clamp(yy, p.H);
+                        xx = reflect_clamp(xx, p.W);
+                    } else {
+                        okc = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                    }
                     so = okc ? yy * p.W + xx : 0;
                 }
                 int s = 0;

@@ -52,6 +52,8 @@ struct WgradPlan {
     int c_tiles = 0, Mp = 0, Cp = 0, GX8 = 0, AX8 = 0;
     // ... of the space-to-depth form of a stride-2 layer: a 2 x 2 stride-1 layer over 4 Cin channels
     bool s2d = false;
+    // ... of the row form of a 7x7 stem: a 1 x 7 layer over 7 Cin channels (channel ci * 7 + ky = the input shifted by ky rows)
+    bool rows = false;
     int Kb = 0, Cb = 0, Hb = 0, Wb = 0;     // kernel size, channels and operand size the bf16 GEMM kernel sees
     // streaming kernel for 1..2 input channels (wgrad_narrow.h): > 0 = output channels per workgroup
     int narrow_cob = 0, narrow_ppt = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
@@ -72,6 +74,9 @@ static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
      reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 1>>), WgradBf3Cfg<K, 1>::lds_bytes()}
         APAMD_WBF3(3), APAMD_WBF3(4), APAMD_WBF3(2),   // (K = 2: the space-to-depth forms of stride-2 layers)
 #undef APAMD_WBF3
+        // K = 7: the ROW form of the 7x7 stems (1 x 7 taps over 7 Cin row channels: WgradBf3Cfg KY = 1)
+        {7, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<7, 2, 1>>), WgradBf3Cfg<7, 2, 1>::lds_bytes(),
+         reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<7, 1, 1>>), WgradBf3Cfg<7, 1, 1>::lds_bytes()},
     };
     return v;
 }
@@ -160,7 +165,12 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
                      d->H % 2 == 0 && d->W % 2 == 0 && !(nos && atoi(nos));
     pl.Kb = K; pl.Cb = pl.Cin; pl.Hb = d->H; pl.Wb = d->W;
     if (s2d) { pl.s2d = true; pl.Kb = 2; pl.Cb = 4 * pl.Cin; pl.Hb = d->H / 2 + 1; pl.Wb = d->W / 2 + 1; }
-    if (s2d || (bf_ok && S == 1 && (K == 3 || K == 4) && pl.Cin >= 32)) {
+    // 7x7 stems on a few channels (the generator's three input layers): the row form -- a 1 x 7 layer over 7 Cin channels -- as the
+    // forward pass runs them (ap_split_prepass_rows); one 64-channel tile holds up to 9 input channels
+    const char* nor = getenv("APAMD_NO_ROWS_WGRAD");
+    const bool rows = bf_ok && S == 1 && K == 7 && d->pad == 3 && d->nsrc == 1 && pl.Cin * 7 <= 64 && !(nor && atoi(nor));
+    if (rows) { pl.rows = true; pl.Cb = 7 * pl.Cin; }
+    if (s2d || rows || (bf_ok && S == 1 && (K == 3 || K == 4) && pl.Cin >= 32)) {
         // wide layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
         pl.bf3 = true;
         pl.tiles_x = (d->GW + 31) / 32;
@@ -175,7 +185,7 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             told = true;
         }
         // one workgroup per CU (its LDS stages fill a CU); two with head-only staging
-        const int target = e ? atoi(e) : num_cus_w() * (d->precision == AP_PRECISION_BF16 && pl.Kb <= 3 ? 2 : 1);
+        const int target = e ? atoi(e) : num_cus_w() * (d->precision == AP_PRECISION_BF16 && (pl.Kb <= 3 || pl.rows) ? 2 : 1);
         int P = target / (pl.m_tiles * pl.c_tiles);
         if (P > pl.nstages / 2) P = pl.nstages / 2;
         if (P < 1) P = 1;
@@ -184,11 +194,11 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.Cp = pl.c_tiles * 64;
         pl.GHp = pl.tiles_y * 2;
         pl.GX8 = pl.tiles_x * 4;
-        pl.Hp = pl.GHp + pl.Kb - 1;
+        pl.Hp = pl.rows ? pl.GHp : pl.GHp + pl.Kb - 1;
         pl.AX8 = pl.tiles_x * 4 + 1;
         pl.a_floats = (long long)d->N * 2 * pl.Hp * pl.AX8 * pl.Cp * 4;      // 16-byte slots -> floats
         pl.g_floats = (long long)d->N * 2 * pl.GHp * pl.GX8 * pl.Mp * 4;
-        pl.part_floats = (long long)pl.P * pl.m_tiles * pl.c_tiles * 4 * pl.Kb * pl.Kb * 1024;   // accumulator-order tiles
+        pl.part_floats = (long long)pl.P * pl.m_tiles * pl.c_tiles * 4 * (pl.rows ? pl.Kb : pl.Kb * pl.Kb) * 1024;   // accumulator-order tiles
         return AP_OK;
     }
     const int PR = pl.k->PR;
@@ -249,7 +259,7 @@ static int set_dyn_lds(const void* fn, int bytes) {
 }
 
 static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, int H, int W, int pad, int pad_mode,
-                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c, int heads_only) {
+                                  int Hp, int X8, int Cp, uint4* out, hipStream_t stream, int s2d_c, int heads_only, int rows_k = 0) {
     SplitTParams p;
     memset(&p, 0, sizeof(p));
     p.nseg = nseg;
@@ -266,6 +276,13 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     p.N = N; p.C = C; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.out = out;
     p.s2d_c = s2d_c;
     p.heads_only = heads_only;
+    p.rows_k = rows_k;
+    if (rows_k > 0) {                                 // the row view exists in the general kernel only
+        if (any_b16 || s2d_c) return fail(AP_ERR_UNSUPPORTED, "split_transpose: row view of a bf16 / space-to-depth source");
+        if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
+        hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
+        return check_launch("split_transpose_kernel");
+    }
     if (any_b16 && !(!getenv("APAMD_NO_SPLIT_ROWS") && (W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
         return fail(AP_ERR_UNSUPPORTED, "split_transpose: a bf16 source needs the padded-row form (pad 1, W in {32, 64, 128, 256})");
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
@@ -467,7 +484,7 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
         float* partial = workspace + pl.a_floats + pl.g_floats;
         rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
-                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16);
+                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16, pl.rows ? pl.Kb : 0);
         if (rc) return rc;
         if (g_t) {
             gt = reinterpret_cast<uint4*>(const_cast<void*>(g_t));
@@ -480,7 +497,7 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         WgradBf3Params p;
         memset(&p, 0, sizeof(p));
         p.gt = gt; p.at = at;
-        p.N = d->N; p.M = d->M; p.Cin = pl.Cb; p.Q = pl.Cb * pl.Kb * pl.Kb;
+        p.N = d->N; p.M = d->M; p.Cin = pl.Cb; p.Q = pl.Cb * (pl.rows ? pl.Kb : pl.Kb * pl.Kb);
         p.GHp = pl.GHp; p.GX8 = pl.GX8; p.Mp = pl.Mp; p.Hp = pl.Hp; p.AX8 = pl.AX8; p.Cp = pl.Cp;
         p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P;
         p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
@@ -496,7 +513,7 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args,
                                        d->precision == AP_PRECISION_BF16 ? bk->lds_bytes1 : bk->lds_bytes, stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
-        const int T = pl.Kb * pl.Kb;
+        const int T = pl.rows ? pl.Kb : pl.Kb * pl.Kb;
         const long long total = (long long)pl.m_tiles * pl.c_tiles * 4 * T * 1024;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, d->M, pl.Cb, T,

@@ -552,6 +552,9 @@ def test_conv_backward_vs_autograd(dev, case, norm):
     ([40, 24, 8], 80, 3, 1, 'zero', 19, 64, 2),         # padded-row operand kernel: 3 segments, odd rows, partial group
     ([32], 64, 3, 1, 'reflect', 10, 128, 1),            # ... two rows per workgroup
     ([32], 48, 3, 1, 'reflect', 5, 256, 1),             # ... one row per workgroup
+    ([3], 64, 7, 3, 'reflect', 64, 64, 2),              # 7x7 stem in its row form (1 x 7 taps over 21 row channels)
+    ([4], 48, 7, 3, 'reflect', 21, 45, 1),              # ... ragged: odd rows, partial column tile, 48 outputs
+    ([9], 64, 7, 3, 'zero', 32, 40, 1),                 # ... 63 of the tile's 64 row channels, zero padding
 ])
 def test_wgrad_bf16x3(dev, case):
     """Weight gradient on the bf16 matrix pipe (split operands) against the fp64 gradient, beside the exact-fp32
