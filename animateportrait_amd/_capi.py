@@ -57,11 +57,12 @@ class ApWgradDesc(ctypes.Structure):
     _fields_ = [('N', ctypes.c_int32), ('M', ctypes.c_int32), ('GH', ctypes.c_int32), ('GW', ctypes.c_int32),
                 ('H', ctypes.c_int32), ('W', ctypes.c_int32), ('K', ctypes.c_int32), ('stride', ctypes.c_int32),
                 ('pad', ctypes.c_int32), ('pad_mode', ctypes.c_int32), ('nsrc', ctypes.c_int32),
-                ('precision', ctypes.c_int32), ('g', ApSrc), ('src', ApSrc * 3)]
+                ('precision', ctypes.c_int32), ('g', ApSrc), ('src', ApSrc * 3),
+                ('src_xs', ctypes.c_void_p * 3), ('src_xs_s2d', ctypes.c_void_p), ('xs_parts', ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 9      # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 10     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),

@@ -695,4 +695,117 @@ __global__ __launch_bounds__(256) void split_transpose_s2d_kernel(const SplitTPa
     }
 }
 
+// ---- the same operand from the FORWARD pass's split copy.  The convolution that produced the layer's output staged
+// XS[n][part][C/8][HW + 1][8 channels] (conv_prepass.h: act(IN(.)) applied, split, slot HW all-zero) of every source; it is
+// still alive when the backward pass runs, and it holds exactly the values the operand needs -- so the operand is a
+// re-tiling of 16-byte slots (8 channels of a pixel -> 8 pixels of a channel), not a second normalisation pass over the
+// fp32 tensor: a thread loads the 8 slots of one pixel octet (padding = index arithmetic; out-of-image taps of a
+// zero-padded layer read slot HW), transposes the 8 x 8 halfwords in registers (32 v_perm_b32) and stores 128 contiguous
+// bytes.  No LDS, no statistics, bf16 in and out: 33 MB read + 39 MB written for a 256-channel 64 x 64 layer at B = 16
+// in plain-bf16 mode, where split_transpose_pad_kernel reads 67 (bf16 source) .. 134 MB.
+// The space-to-depth operand of a stride-2 layer comes the same way from ITS forward copy (ap_split_prepass_s2d: the
+// view (4 C0, H0/2 + 1, W0/2 + 1), zero ring included): pad = 0 on the view.
+// Lanes: 8 consecutive lanes own one pixel octet, lane e its pixel e -- a load instruction fetches 64 consecutive pixels'
+// slots (1 KiB contiguous) and, after the transposition, lane c holds the octet's slot of channel c, so a store
+// instruction writes whole 128-byte lines (8 channels x 16 bytes per octet).  The 8 x 8 halfword transposition runs
+// ACROSS the 8 lanes as three butterfly exchanges (lane ^ 4 on dword pairs: ds_swizzle; lane ^ 2 on dwords and lane ^ 1
+// on halfwords: DPP quad permutes + v_perm_b32).  (First form, one thread per (octet, channel octet) with a register
+// transposition: every load and store instruction touched 64 different lines, 16 bytes of each -- 38 us per launch in
+// the train step where this form takes ~20.)
+// grid: (ceil(Hp * X8 / 32), ceil(Cp / 8 / 4), N): a workgroup = 32 pixel octets x 4 channel octets.
+struct XsTParams {
+    const uint4* xs[kMaxSeg];     // split copy of each source segment
+    int cg_begin[kMaxSeg + 1];    // first channel octet of each segment; [nseg] = total octets (C / 8)
+    int nseg;
+    int N, H, W, pad, pad_mode, Hp, X8, Cp;
+    int parts;                    // 1: head planes only
+    int s2d_c, H0, W0;            // s2d_c = C0 > 0: the space-to-depth view (4 C0, H, W) = (.., H0/2 + 1, W0/2 + 1) gathered from the
+                                  // PLAIN copy of the (C0, H0, W0) source (a stride-2 layer whose forward pass staged that one):
+                                  // view channel r * C0 + c, pixel (y, x) = pad1(source)[c][2 y + (r >> 1)][2 x + (r & 1)]
+    uint4* out;
+};
+
+constexpr int kXsCgPerThread = 4;
+
+template <int XOR>
+__device__ __forceinline__ unsigned lane_xor(unsigned v) {
+    if constexpr (XOR == 4) return (unsigned)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);               // bit mode: and 0x1f, xor 4
+    else if constexpr (XOR == 2) return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+    else return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);                       // quad_perm [1,0,3,2]
+}
+
+__global__ __launch_bounds__(256) void xs_transpose_kernel(const XsTParams p) {
+    const int tid = threadIdx.x, e = tid & 7;
+    const int pos = blockIdx.x * 32 + (tid >> 3);
+    if (pos >= p.Hp * p.X8) return;                                 // (whole 8-lane groups)
+    const int n = blockIdx.z;
+    const int y = pos / p.X8, k = pos - y * p.X8;
+    const int HW = p.H * p.W, He = p.H + 2 * p.pad, We = p.W + 2 * p.pad;
+    int idx;
+    {
+        const int x = k * 8 + e;
+        int sy = y - p.pad, sx = x - p.pad;
+        bool ok = y < He && x < We;
+        if (p.pad_mode == 1) {
+            sy = reflect_clamp(sy, p.H);
+            sx = reflect_clamp(sx, p.W);
+        } else {
+            ok = ok && sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+        }
+        idx = ok ? sy * p.W + sx : HW;                              // slot HW: zeros
+    }
+    const int total_cg = p.cg_begin[p.nseg];
+    for (int part = 0; part < p.parts; ++part) {
+        uint4 v[kXsCgPerThread];
+#pragma unroll
+        for (int i = 0; i < kXsCgPerThread; ++i) {
+            const int cg = blockIdx.y * kXsCgPerThread + i;         // (block-uniform)
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (cg < total_cg) {
+                if (p.s2d_c > 0) {
+                    const int CG0 = p.s2d_c >> 3, r = cg / CG0, cgl = cg - r * CG0, HW0 = p.H0 * p.W0;
+                    const int yy = 2 * y + (r >> 1) - 1, xx = 2 * (k * 8 + e) + (r & 1) - 1;
+                    const bool ok = y < p.H && k * 8 + e < p.W && yy >= 0 && yy < p.H0 && xx >= 0 && xx < p.W0;
+                    v[i] = p.xs[0][((long long)(n * 2 + part) * CG0 + cgl) * (HW0 + 1) + (ok ? yy * p.W0 + xx : HW0)];
+                    continue;
+                }
+                int s = 0;
+                if (p.nseg > 1 && cg >= p.cg_begin[1]) s = 1;
+                if (p.nseg > 2 && cg >= p.cg_begin[2]) s = 2;
+                const int CGs = p.cg_begin[s + 1] - p.cg_begin[s], cgl = cg - p.cg_begin[s];
+                const uint4* src = s == 0 ? p.xs[0] : (s == 1 ? p.xs[1] : p.xs[2]);
+                v[i] = src[((long long)(n * 2 + part) * CGs + cgl) * (HW + 1) + idx];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kXsCgPerThread; ++i) {
+            const int cg = blockIdx.y * kXsCgPerThread + i;
+            if (cg * 8 >= p.Cp) continue;
+            unsigned d0 = v[i].x, d1 = v[i].y, d2 = v[i].z, d3 = v[i].w;
+            {   // lane ^ 4: dword pairs
+                const bool hi = e & 4;
+                const unsigned s0 = hi ? d0 : d2, s1 = hi ? d1 : d3;
+                const unsigned r0 = lane_xor<4>(s0), r1 = lane_xor<4>(s1);
+                if (hi) { d0 = r0; d1 = r1; } else { d2 = r0; d3 = r1; }
+            }
+            {   // lane ^ 2: dwords inside each pair
+                const bool hi = e & 2;
+                const unsigned s0 = hi ? d0 : d1, s1 = hi ? d2 : d3;
+                const unsigned r0 = lane_xor<2>(s0), r1 = lane_xor<2>(s1);
+                if (hi) { d0 = r0; d2 = r1; } else { d1 = r0; d3 = r1; }
+            }
+            {   // lane ^ 1: halfwords inside each dword.  even lane: (own.lo, other.lo); odd lane: (other.hi, own.hi)
+                const bool hi = e & 1;
+                const unsigned r0 = lane_xor<1>(d0), r1 = lane_xor<1>(d1), r2 = lane_xor<1>(d2), r3 = lane_xor<1>(d3);
+                d0 = hi ? __builtin_amdgcn_perm(d0, r0, 0x07060302u) : __builtin_amdgcn_perm(r0, d0, 0x05040100u);
+                d1 = hi ? __builtin_amdgcn_perm(d1, r1, 0x07060302u) : __builtin_amdgcn_perm(r1, d1, 0x05040100u);
+                d2 = hi ? __builtin_amdgcn_perm(d2, r2, 0x07060302u) : __builtin_amdgcn_perm(r2, d2, 0x05040100u);
+                d3 = hi ? __builtin_amdgcn_perm(d3, r3, 0x07060302u) : __builtin_amdgcn_perm(r3, d3, 0x05040100u);
+            }
+            // lane e now holds channel e of the octet: pixels 0..7
+            p.out[(((long long)(n * 2 + part) * p.Hp + y) * p.X8 + k) * p.Cp + cg * 8 + e] = make_uint4(d0, d1, d2, d3);
+        }
+    }
+}
+
 }  // namespace apamd

@@ -168,7 +168,12 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     // 7x7 stems on a few channels (the generator's three input layers): the row form -- a 1 x 7 layer over 7 Cin channels -- as the
     // forward pass runs them (ap_split_prepass_rows); one 64-channel tile holds up to 9 input channels
     const char* nor = getenv("APAMD_NO_ROWS_WGRAD");
-    const bool rows = bf_ok && S == 1 && K == 7 && d->pad == 3 && d->nsrc == 1 && pl.Cin * 7 <= 64 && !(nor && atoi(nor));
+    // Plain-bf16 arithmetic only: the operands of a stem are prepared for this one launch (a 64-channel gradient at 256 x 256 and a
+    // row view padded to 64 channels), which costs ~340 us per layer at 2B = 32 -- with one product per tap the whole operator is
+    // ~390 us against 430-455 on the fp32 kernel; with three products and both parts (split-bf16) it is ~680 (profiles/r05_wgrad_routes.md).
+    // (a 32-output stem fills half a tile)
+    const bool rows_m = d->precision == AP_PRECISION_BF16 && d->M >= 24 && !(nob && atoi(nob));
+    const bool rows = rows_m && S == 1 && K == 7 && d->pad == 3 && d->nsrc == 1 && pl.Cin * 7 <= 64 && !(nor && atoi(nor));
     if (rows) { pl.rows = true; pl.Cb = 7 * pl.Cin; }
     if (s2d || rows || (bf_ok && S == 1 && (K == 3 || K == 4) && pl.Cin >= 32)) {
         // wide layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)
@@ -322,6 +327,38 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
     return check_launch("split_transpose_kernel");
 }
 
+// the shifted operand re-tiled from the forward pass's split copies (xs_transpose_kernel); C = channels of the view
+static int launch_xs_transpose(const void* const* xs, const int* seg_c, int nseg, int N, int H, int W, int pad, int pad_mode,
+                               int Hp, int X8, int Cp, int parts, uint4* out, hipStream_t stream, int s2d_c = 0, int H0 = 0, int W0 = 0) {
+    XsTParams p;
+    memset(&p, 0, sizeof(p));
+    p.nseg = nseg;
+    int cg = 0;
+    for (int s = 0; s < nseg; ++s) {
+        p.xs[s] = reinterpret_cast<const uint4*>(xs[s]);
+        p.cg_begin[s] = cg;
+        cg += seg_c[s] / 8;
+    }
+    p.cg_begin[nseg] = cg;
+    p.N = N; p.H = H; p.W = W; p.pad = pad; p.pad_mode = pad_mode; p.Hp = Hp; p.X8 = X8; p.Cp = Cp; p.parts = parts; p.out = out;
+    p.s2d_c = s2d_c; p.H0 = H0; p.W0 = W0;
+    if (N > 65535 || Cp / 8 > 65535) return fail(AP_ERR_UNSUPPORTED, "xs_transpose: N=%d Cp=%d", N, Cp);
+    hipLaunchKernelGGL(xs_transpose_kernel, dim3((Hp * X8 + 31) / 32, (Cp / 8 + kXsCgPerThread - 1) / kXsCgPerThread, N), dim3(256), 0,
+                       stream, p);
+    return check_launch("xs_transpose_kernel");
+}
+
+// can the shifted operand of this plan come from the forward split copies the descriptor carries?
+static bool wgrad_xs_route(const ap_wgrad_desc* d, const WgradPlan& pl) {
+    if (!pl.bf3 || pl.rows || getenv("APAMD_NO_XS_WGRAD")) return false;
+    if (d->precision != AP_PRECISION_BF16 && d->xs_parts != 2) return false;      // a split-bf16 product reads the tail planes
+    if (d->xs_parts != 1 && d->xs_parts != 2) return false;
+    if (pl.s2d) return (d->src_xs_s2d != nullptr || d->src_xs[0] != nullptr) && d->nsrc == 1 && pl.Cin % 8 == 0;
+    for (int s = 0; s < d->nsrc; ++s)
+        if (!d->src_xs[s] || d->src[s].C % 8 != 0) return false;
+    return true;
+}
+
 static std::mutex g_wattr_mu;
 static std::vector<const void*> g_wattr_done;
 
@@ -443,8 +480,9 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
     if (g_t && !pl.bf3) return fail(AP_ERR_UNSUPPORTED, "wgrad: a prepared operand needs the bf16 matrix plan (ap_conv2d_wgrad_gt_dims)");
     if (!workspace || !dw || (!d->g.data && !g_t)) return fail(AP_ERR_INVALID, "wgrad: null pointer");
     if ((d->g.mean == nullptr) != (d->g.rstd == nullptr)) return fail(AP_ERR_INVALID, "wgrad: g mean/rstd mismatch");
+    const bool from_xs = wgrad_xs_route(d, pl);
     for (int s = 0; s < d->nsrc; ++s) {
-        if (!d->src[s].data) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
+        if (!d->src[s].data && !from_xs) return fail(AP_ERR_INVALID, "wgrad: segment %d: null data", s);
         if ((d->src[s].mean == nullptr) != (d->src[s].rstd == nullptr))
             return fail(AP_ERR_INVALID, "wgrad: segment %d mean/rstd mismatch", s);
         if ((d->src[s].act & 0x100) && !pl.bf3)      // bit 8: bf16 data (launch_split_transpose)
@@ -483,8 +521,24 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         uint4* at = reinterpret_cast<uint4*>(workspace);
         uint4* gt = reinterpret_cast<uint4*>(workspace + pl.a_floats);
         float* partial = workspace + pl.a_floats + pl.g_floats;
-        rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
-                                    pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16, pl.rows ? pl.Kb : 0);
+        if (from_xs) {
+            const int parts = d->precision == AP_PRECISION_BF16 ? 1 : 2;
+            if (pl.s2d) {
+                // the forward pass staged the space-to-depth copy (2 x 2 form) or, where it ran the stride-2 kernel, the plain one
+                const void* xs[1] = {d->src_xs_s2d ? d->src_xs_s2d : d->src_xs[0]};
+                const int cs[1] = {pl.Cb};
+                rc = launch_xs_transpose(xs, cs, 1, d->N, pl.Hb, pl.Wb, 0, AP_PAD_ZERO, pl.Hp, pl.AX8, pl.Cp, parts, at, stream,
+                                         d->src_xs_s2d ? 0 : pl.Cin, d->H, d->W);
+            } else {
+                int cs[kMaxSeg];
+                for (int s = 0; s < d->nsrc; ++s) cs[s] = d->src[s].C;
+                rc = launch_xs_transpose(d->src_xs, cs, d->nsrc, d->N, d->H, d->W, d->pad, d->pad_mode, pl.Hp, pl.AX8, pl.Cp, parts,
+                                         at, stream);
+            }
+        } else {
+            rc = launch_split_transpose(d->src, d->nsrc, d->N, pl.Cb, d->H, d->W, pl.s2d ? 0 : d->pad, d->pad_mode, pl.Hp, pl.AX8,
+                                        pl.Cp, at, stream, pl.s2d ? pl.Cin : 0, d->precision == AP_PRECISION_BF16, pl.rows ? pl.Kb : 0);
+        }
         if (rc) return rc;
         if (g_t) {
             gt = reinterpret_cast<uint4*>(const_cast<void*>(g_t));

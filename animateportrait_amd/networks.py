@@ -78,7 +78,9 @@ class ConvLayer(nn.Module):
             # 4x4 stride-2 PatchGAN layer / 3x3 stride-2 encoder layer: 2x2 split-bf16 convolution over the space-to-depth
             # copy of the input -- made here, or already written by the producer (the warp kernel, ops.warp_concat s2d=True)
             spec, packed = self.s2d_spec(), self.packed_s2d()
-            srcs = [srcs[0].s2d if srcs[0].s2d is not None else ops.presplit_s2d(srcs[0])]
+            if srcs[0].s2d is None:
+                srcs[0].s2d = ops.presplit_s2d(srcs[0])      # (kept on the source: the weight gradient re-tiles its operand from it)
+            srcs = [srcs[0].s2d]
         if packed is None:
             packed = self.packed()
         if norm_act is None:

@@ -84,6 +84,8 @@ def _require_device(t, name, allow_bf16=False):
 # operand transposition) run at 3.5-4.4 TB/s because of latency / issue, not bandwidth: with 8-byte instead of 16-byte loads per
 # lane they take as long per launch.
 BF16_RAW = os.environ.get('APAMD_NO_BF16_RAW', '0') != '1'
+# the weight gradients' shifted operand re-tiled from the forward pass's split copies (ap_wgrad_desc.src_xs); 1 turns it off
+XS_WGRAD = os.environ.get('APAMD_NO_XS_WGRAD', '0') != '1'
 
 
 class Feat:
@@ -977,6 +979,16 @@ def _wgrad_desc(k, stride, pad, pad_mode, g_shape, g, srcs, precision):
         d.src[i].rstd = f.rstd.data_ptr() if f.rstd is not None else None
         # ap_src.act bit 8: the segment holds bf16 values (the C side refuses it where its kernels cannot read them)
         d.src[i].C, d.src[i].act = f.data.shape[1], f.act | (0x100 if f.data.dtype == torch.bfloat16 else 0)
+    # the split copies the forward pass staged of the same sources (still alive on the tape): the C side re-tiles the shifted
+    # operand from them instead of normalising + splitting the fp32 tensors again (ap_wgrad_desc.src_xs)
+    if XS_WGRAD:
+        heads = DEFAULT_PRECISION == PRECISION_BF16 or any(f.xs_heads_only for f in srcs)
+        d.xs_parts = 1 if heads else 2
+        if all(f.xs is not None for f in srcs):
+            for i, f in enumerate(srcs):
+                d.src_xs[i] = f.xs.data_ptr()
+        if len(srcs) == 1 and srcs[0].s2d is not None and srcs[0].s2d.xs is not None:
+            d.src_xs_s2d = srcs[0].s2d.xs.data_ptr()
     return d
 
 

@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 9
+#define AP_ABI_VERSION 10
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -340,6 +340,17 @@ typedef struct ap_wgrad_desc {
                              product only (plain bf16 operands, fp32 accumulation) */
     ap_src g;             /* g.C is ignored (M is used) */
     ap_src src[3];
+    /* Optional (ABI 10): the split-bf16 copies the FORWARD pass staged of the same sources, still alive in the backward pass.
+     * When every segment has one (channels a multiple of 8) and the layer is on the bf16 matrix plan, the shifted operand is
+     * re-tiled from them (16-byte slot transposition, no second normalisation pass over src[].data, which is then not read):
+     *   src_xs[i]   ap_split_prepass layout of segment i (stride-1 3x3 / 4x4 layers);
+     *   src_xs_s2d  ap_split_prepass_s2d layout of the single source (stride-2 layers in their space-to-depth form; without it
+ *               the view is gathered from src_xs[0]);
+     *   xs_parts    planes those copies hold: 2 = head + tail, 1 = heads only (copies written in AP_PRECISION_BF16 mode:
+     *               usable by a BF16 weight gradient only).  All null / 0: the operand is prepared from src[].data. */
+    const void* src_xs[3];
+    const void* src_xs_s2d;
+    int32_t xs_parts;
 } ap_wgrad_desc;
 /* Weight gradient of a one-output-channel 4x4 stride-1 layer on a small map (the PatchGAN output layer,
  * networks.py:2643): dw[0][c][ky][kx] = sum_{n,oy,ox} g[n,0,oy,ox] * act(IN(src))[n,c,oy+ky-pad,ox+kx-pad].  One workgroup

@@ -552,9 +552,10 @@ def test_conv_backward_vs_autograd(dev, case, norm):
     ([40, 24, 8], 80, 3, 1, 'zero', 19, 64, 2),         # padded-row operand kernel: 3 segments, odd rows, partial group
     ([32], 64, 3, 1, 'reflect', 10, 128, 1),            # ... two rows per workgroup
     ([32], 48, 3, 1, 'reflect', 5, 256, 1),             # ... one row per workgroup
-    ([3], 64, 7, 3, 'reflect', 64, 64, 2),              # 7x7 stem in its row form (1 x 7 taps over 21 row channels)
+    ([3], 64, 7, 3, 'reflect', 64, 64, 2),              # 7x7 stem: in plain-bf16 arithmetic the row form (1 x 7 taps over 21 row channels)
     ([4], 48, 7, 3, 'reflect', 21, 45, 1),              # ... ragged: odd rows, partial column tile, 48 outputs
     ([9], 64, 7, 3, 'zero', 32, 40, 1),                 # ... 63 of the tile's 64 row channels, zero padding
+    ([3], 32, 7, 3, 'reflect', 40, 40, 2),              # ... 32 outputs (the generator's half-width stem): half a tile
 ])
 def test_wgrad_bf16x3(dev, case):
     """Weight gradient on the bf16 matrix pipe (split operands) against the fp64 gradient, beside the exact-fp32
@@ -581,6 +582,50 @@ def test_wgrad_bf16x3(dev, case):
         got[prec] = ops.wgrad(k, 1, pad, pm, ops.Feat(up.to(dev)), feats, (cout, cin, k, k), precision=prec)
     assert linf(got[ops.PRECISION_FP32], ref) < 5e-6 * scale
     assert linf(got[ops.PRECISION_BF16X3], ref) < 5e-5 * scale, linf(got[ops.PRECISION_BF16X3], ref) / scale
+    if k == 7:
+        # the stems' row form runs in plain-bf16 arithmetic only (one product per tap): the fp64 sum of bf16-rounded operands
+        r16 = lambda t: t.float().bfloat16().double()
+        w16 = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+        xp16 = F.pad(r16(xr), (pad,) * 4, mode='reflect') if mode == 'reflect' else F.pad(r16(xr), (pad,) * 4)
+        (F.conv2d(xp16, w16) * r16(up)).sum().backward()
+        # (a plain source: act(IN(.)) evaluated on the device may round an element to the neighbouring bf16)
+        got16 = ops.wgrad(k, 1, pad, pm, ops.Feat(up.to(dev)), [ops.Feat(xr.float().to(dev))], (cout, cin, k, k),
+                          precision=ops.PRECISION_BF16)
+        assert linf(got16, w16.grad) < 3e-5 * float(w16.grad.abs().max())
+    # ... and with the shifted operand re-tiled from the forward pass's split copies (ap_wgrad_desc.src_xs: every segment a
+    # multiple of 8 channels), which the sources carry once a split-bf16 convolution has staged them
+    if all(c % 8 == 0 for c in segs) and k != 7:
+        for f in feats:
+            ops.presplit(f, ops.PRECISION_BF16X3)
+        again = ops.wgrad(k, 1, pad, pm, ops.Feat(up.to(dev)), feats, (cout, cin, k, k), precision=ops.PRECISION_BF16X3)
+        assert linf(again, ref) < 5e-5 * scale, linf(again, ref) / scale
+
+
+@pytest.mark.parametrize('k', [3, 4])
+def test_wgrad_stride2_operand_from_forward_copies(dev, k):
+    """Stride-2 weight gradients run as 2 x 2 layers over the space-to-depth view; that view's operand comes from the fp32
+    source, from the space-to-depth split copy the forward pass staged (ap_wgrad_desc.src_xs_s2d) or is gathered from the
+    plain split copy (src_xs[0], where the forward pass ran the stride-2 kernel): all three against the fp64 gradient."""
+    from animateportrait_amd import ops
+    g = torch.Generator().manual_seed(40 + k)
+    n, cin, cout, H, W = 2, 64, 128, 32, 48
+    x = torch.randn(n, cin, H, W, generator=g) * 1.5 + 0.3
+    m0 = x.mean((2, 3)).reshape(-1)
+    r0 = 1.0 / torch.sqrt(x.var((2, 3), unbiased=False).reshape(-1) + 1e-5)
+    w = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(F.relu(F.instance_norm(x)).double(), w, stride=2, padding=1)
+    up = torch.randn(y.shape, generator=g)
+    (y * up.double()).sum().backward()
+    ref, scale = w.grad, float(w.grad.abs().max())
+
+    def feat():
+        return ops.Feat(x.to(dev), m0.to(dev), r0.to(dev), ops.ACT_RELU)
+    plain, with_xs, with_s2d = feat(), feat(), feat()
+    ops.presplit(with_xs, ops.PRECISION_BF16X3)
+    with_s2d.s2d = ops.presplit_s2d(with_s2d)
+    for f in (plain, with_xs, with_s2d):
+        got = ops.wgrad(k, 2, 1, ops.PAD_ZERO, ops.Feat(up.to(dev)), [f], (cout, cin, k, k), precision=ops.PRECISION_BF16X3)
+        assert linf(got, ref) < 5e-5 * scale, linf(got, ref) / scale
 
 
 @pytest.mark.parametrize('shape,act,two,pad', [((2, 5, 40, 36), 1, True, 0), ((2, 3, 128, 128), 2, False, 0),

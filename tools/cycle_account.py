@@ -16,6 +16,8 @@ LAYERS = {
     'res': ('res 256->256 k3 @64', [256], 256, 3, 1, 1, True, False, 64),
     'res2': ('res2 288->256 k3 @64', [256, 16, 16], 256, 3, 1, 1, True, False, 64),
     'merge': ('merge 768->256 k3 @64', [256, 256, 256], 256, 3, 1, 1, False, False, 64),
+    'stem': ('stem 3->64 k7 @256 (row form)', [3], 64, 7, 1, 3, True, False, 256),
+    'down': ('down 64->128 k3 s2 @256 (space-to-depth form)', [64], 128, 3, 2, 1, False, False, 256),
 }
 KIND = {0: 'A arrive', 1: 'B dma landed', 2: 'C barrier passed', 3: 'last MFMA issued', 4: 'epilogue done', 5: 'sync after epilogue',
         6: 'next chunk-1 DMA issued', 7: 'entry', 8: 'prologue landed', 9: 'stores issued', 10: 'stores acknowledged'}

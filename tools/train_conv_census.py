@@ -37,9 +37,11 @@ def main():
                spec.w_layout, spec.w_flip)] += 1
         return conv2d(spec, srcs, *a, **k)
 
-    def wgrad_logged(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None):
-        wgrads[(tuple(g.data.shape), tuple(f.data.shape[1] for f in srcs), k, stride, tuple(out_shape))] += 1
-        return wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision)
+    def wgrad_logged(k, stride, pad, pad_mode, g, srcs, out_shape, **kw):
+        copies = 'xs' if all(f.xs is not None for f in srcs) else ('s2d' if len(srcs) == 1 and srcs[0].s2d is not None else '-')
+        wgrads[(tuple(g.data.shape), tuple(f.data.shape[1] for f in srcs), k, stride, tuple(out_shape), copies,
+                'prepared G' if kw.get('g_t') is not None else 'G from dy')] += 1
+        return wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, **kw)
     ops.conv2d, ops.wgrad = conv2d_logged, wgrad_logged
     model.set_input(batch); model.optimize_parameters()
     ops.conv2d, ops.wgrad = conv2d, wgrad
@@ -49,7 +51,7 @@ def main():
             print('%3d x %s' % (cnt, key))
     print('--- weight gradients')
     for key, cnt in sorted(wgrads.items()):
-        print('%3d x g%s srcC%s k%d s%d -> %s' % ((cnt,) + key))
+        print('%3d x g%s srcC%s k%d s%d -> %s  forward copies: %s, %s' % ((cnt,) + key))
 
 
 if __name__ == '__main__':
