@@ -167,13 +167,14 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     if (s2d) { pl.s2d = true; pl.Kb = 2; pl.Cb = 4 * pl.Cin; pl.Hb = d->H / 2 + 1; pl.Wb = d->W / 2 + 1; }
     // 7x7 stems on a few channels (the generator's three input layers): the row form -- a 1 x 7 layer over 7 Cin channels -- as the
     // forward pass runs them (ap_split_prepass_rows); one 64-channel tile holds up to 9 input channels
-    const char* nor = getenv("APAMD_NO_ROWS_WGRAD");
-    // Plain-bf16 arithmetic only: the operands of a stem are prepared for this one launch (a 64-channel gradient at 256 x 256 and a
-    // row view padded to 64 channels), which costs ~340 us per layer at 2B = 32 -- with one product per tap the whole operator is
-    // ~390 us against 430-455 on the fp32 kernel; with three products and both parts (split-bf16) it is ~680 (profiles/r05_wgrad_routes.md).
-    // (a 32-output stem fills half a tile)
-    const bool rows_m = d->precision == AP_PRECISION_BF16 && d->M >= 24 && !(nob && atoi(nob));
-    const bool rows = rows_m && S == 1 && K == 7 && d->pad == 3 && d->nsrc == 1 && pl.Cin * 7 <= 64 && !(nor && atoi(nor));
+    // OPT-IN (APAMD_ROWS_WGRAD=1), plain-bf16 arithmetic only.  Measured in the train step at 2B = 32 (profiles/r05_wgrad_routes.md):
+    // the kernel itself takes 125 us, but both operands have to be prepared for this one launch -- the 64-channel gradient at
+    // 256 x 256 into pixel-octet slots (~140 us) and the row view padded from 21 to the kernel's 64 channels (~210 us, 277 MB
+    // written) -- so the whole operator is ~470 us and 1.1 GB more HBM traffic per stem against 433 us on the fp32 kernel (and ~680 us
+    // with three products and both parts).  Kept for the tests and as the starting point of a 32-channel tile.
+    const char* wr = getenv("APAMD_ROWS_WGRAD");
+    const bool rows_m = d->precision == AP_PRECISION_BF16 && d->M >= 24 && !(nob && atoi(nob)) && wr && atoi(wr);
+    const bool rows = rows_m && S == 1 && K == 7 && d->pad == 3 && d->nsrc == 1 && pl.Cin * 7 <= 64;
     if (rows) { pl.rows = true; pl.Cb = 7 * pl.Cin; }
     if (s2d || rows || (bf_ok && S == 1 && (K == 3 || K == 4) && pl.Cin >= 32)) {
         // wide layer: operands split into bf16 head + tail, bf16 matrix pipe (wgrad_bf16x3.h)

@@ -80,14 +80,16 @@ def test_conv_bf16_is_fp32_sum_of_bf16_products(dev, case):
 
 
 @pytest.mark.parametrize('case', [c for c in CASES if c[3] in (3, 4, 7)], ids=[c[0] for c in CASES if c[3] in (3, 4, 7)])
-def test_conv_bf16_backward_is_fp32_sum_of_bf16_products(dev, case):
+def test_conv_bf16_backward_is_fp32_sum_of_bf16_products(dev, case, monkeypatch):
     """Data and weight gradients of a plain (bias + no norm) layer in bf16 mode.  Operators on the bf16 matrix path
-    (stride-1 3x3 / 4x4 weight gradients, the 7x7 stems' in their row form, every wide data gradient) must equal the fp64 sum of bf16-rounded operands
+    (stride-1 3x3 / 4x4 weight gradients, the 7x7 stems' in their opt-in row form, every wide data gradient) must equal the fp64 sum of bf16-rounded operands
     -- dgrad: bf16(dy) x bf16(w), wgrad: bf16(dy) x bf16(x); the ones that stay on the exact-fp32 kernels (strided /
     transposed weight gradients, 16-channel segments) must equal the exact result.  Nothing in between."""
     from animateportrait_amd import ops, autograd
     from animateportrait_amd.networks import ConvLayer
     name, segs, cout, k, stride, pad, mode, tr, H, W = case
+    if k == 7:
+        monkeypatch.setenv('APAMD_ROWS_WGRAD', '1')      # the stems' row form is opt-in (DESIGN.md 3.3)
     g = torch.Generator().manual_seed(7 + sum(map(ord, name)))
     n = 2
     xs = [torch.randn(n, c, H, W, generator=g) for c in segs]

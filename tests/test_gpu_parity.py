@@ -552,12 +552,12 @@ def test_conv_backward_vs_autograd(dev, case, norm):
     ([40, 24, 8], 80, 3, 1, 'zero', 19, 64, 2),         # padded-row operand kernel: 3 segments, odd rows, partial group
     ([32], 64, 3, 1, 'reflect', 10, 128, 1),            # ... two rows per workgroup
     ([32], 48, 3, 1, 'reflect', 5, 256, 1),             # ... one row per workgroup
-    ([3], 64, 7, 3, 'reflect', 64, 64, 2),              # 7x7 stem: in plain-bf16 arithmetic the row form (1 x 7 taps over 21 row channels)
+    ([3], 64, 7, 3, 'reflect', 64, 64, 2),              # 7x7 stem: with APAMD_ROWS_WGRAD=1 in plain-bf16 arithmetic the row form (1 x 7 taps over 21 row channels)
     ([4], 48, 7, 3, 'reflect', 21, 45, 1),              # ... ragged: odd rows, partial column tile, 48 outputs
     ([9], 64, 7, 3, 'zero', 32, 40, 1),                 # ... 63 of the tile's 64 row channels, zero padding
     ([3], 32, 7, 3, 'reflect', 40, 40, 2),              # ... 32 outputs (the generator's half-width stem): half a tile
 ])
-def test_wgrad_bf16x3(dev, case):
+def test_wgrad_bf16x3(dev, case, monkeypatch):
     """Weight gradient on the bf16 matrix pipe (split operands) against the fp64 gradient, beside the exact-fp32
     kernel on the same data; the input is a virtual (IN + ReLU) feature for the first segment."""
     from animateportrait_amd import ops
@@ -583,7 +583,8 @@ def test_wgrad_bf16x3(dev, case):
     assert linf(got[ops.PRECISION_FP32], ref) < 5e-6 * scale
     assert linf(got[ops.PRECISION_BF16X3], ref) < 5e-5 * scale, linf(got[ops.PRECISION_BF16X3], ref) / scale
     if k == 7:
-        # the stems' row form runs in plain-bf16 arithmetic only (one product per tap): the fp64 sum of bf16-rounded operands
+        # the stems' row form (opt-in, plain-bf16 arithmetic only: one product per tap): the fp64 sum of bf16-rounded operands
+        monkeypatch.setenv('APAMD_ROWS_WGRAD', '1')
         r16 = lambda t: t.float().bfloat16().double()
         w16 = torch.zeros(cout, cin, k, k, dtype=torch.float64, requires_grad=True)
         xp16 = F.pad(r16(xr), (pad,) * 4, mode='reflect') if mode == 'reflect' else F.pad(r16(xr), (pad,) * 4)
