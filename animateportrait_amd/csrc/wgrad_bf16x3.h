@@ -42,20 +42,25 @@ struct WgradBf3Params {
 // KY_ = 1: the ROW form of a K x K layer on few channels (the 7x7 stems): the shifted operand is prepared with one channel per
 // (input channel, kernel row) -- channel ci * K + ky of row y is the padded input row y + ky (split_transpose_kernel, rows_k) --
 // so the kernel sees a 1 x K layer over K * Cin channels: K taps, no row shift, and dW[m][ci * K + ky][kx] IS the OIHW tensor.
-template <int K_, int PARTS_ = 2, int KY_ = K_>
+// WM_ = 4: EIGHT waves, 4 (m) x 2 (ci) -> a 128 x 64 channel tile.  With head + tail staged a 4-wave workgroup fills a CU's LDS, so
+// every SIMD holds ONE wave and nothing covers its LDS / MFMA latencies; the 8-wave workgroup stages 1.3x the bytes (the shifted
+// operand is shared by twice the products) for 2x the products and puts two waves on every SIMD.
+template <int K_, int PARTS_ = 2, int KY_ = K_, int WM_ = 2>
 struct WgradBf3Cfg {
-    static constexpr int K = K_, KY = KY_, T = K * KY, PR = 2, PARTS = PARTS_;
+    static constexpr int K = K_, KY = KY_, T = K * KY, PR = 2, PARTS = PARTS_, WM = WM_;
+    static_assert(WM == 2 || WM == 4, "2 x 2 or 4 x 2 waves");
+    static constexpr int NWAVES = 2 * WM, M_TILE = 32 * WM, MH = WM / 2;   // MH: 64-channel DMA pieces per G octet
     static_assert(PARTS == 1 || PARTS == 2, "head only, or head + tail");
     static_assert(KY == K || KY == 1, "square taps, or the row form");
     static constexpr int ROWS = PR + KY - 1;                // staged rows of the shifted operand
     static constexpr int NXG = 5;                           // staged octets per row: 4 + 1 for the column shift
-    static constexpr int G_SLOTS = PARTS * PR * 4 * 64;     // [part][row][octet][m]
+    static constexpr int G_SLOTS = PARTS * PR * 4 * M_TILE; // [part][row][octet][m]
     static constexpr int A_SLOTS = PARTS * ROWS * NXG * 64; // [part][row][octet][ci]
     static constexpr int NPIECE = (G_SLOTS + A_SLOTS) / 64; // 1 KiB DMA pieces per stage
     static constexpr size_t lds_bytes() { return (size_t)2 * (G_SLOTS + A_SLOTS) * 16; }
     // one accumulator tile per tap: 16 K^2 registers -- with head-only staging two workgroups share a CU when that
     // leaves room for the operand registers (K <= 3; a 4x4 layer's 256 accumulators need a SIMD's whole file)
-    static constexpr int WG_PER_CU = (PARTS == 1 && T * 16 <= 160) ? 2 : 1;
+    static constexpr int WG_PER_CU = (PARTS == 1 && T * 16 <= 160 && WM == 2) ? 2 : 1;
     static_assert(K - 1 < 8, "the column shift must stay inside one extra octet");
 };
 
@@ -77,7 +82,8 @@ __device__ __forceinline__ bf16x8 funnel8(const u32x4 lo, const u32x4 hi) {
 // PARTS = 2: split-bf16 arithmetic (tail x head, head x tail, head x head per tap).  PARTS = 1: plain bf16 arithmetic
 // (AP_PRECISION_BF16): the head x head product only, head planes only.
 template <class C>
-__global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3Params p) {
+__global__ __launch_bounds__(C::NWAVES * 64, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3Params p) {
+    constexpr int WM = C::WM, NWAVES = C::NWAVES, M_TILE = C::M_TILE, MH = C::MH;
     constexpr int PARTS = C::PARTS, PROD = PARTS == 1 ? 1 : 3;
     constexpr int K = C::K, KY = C::KY, T = C::T, ROWS = C::ROWS, NXG = C::NXG;
     constexpr int G_SLOTS = C::G_SLOTS, A_SLOTS = C::A_SLOTS, STAGE = G_SLOTS + A_SLOTS;
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-    const int wm = wave & 1, wq = wave >> 1;
+    const int wm = wave % WM, wq = wave / WM;
     int b = blockIdx.x;
     const int split = b % p.P; b /= p.P;
     const int ct = b % p.c_tiles;
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     const int dpart = PARTS == 2 ? (wave & 1) : 0, dhw = wave >> 1;
     constexpr int NGP = PARTS == 2 ? 4 : 2;                            // G pieces per wave and stage
     constexpr int NAE = ROWS * NXG, NAP = PARTS == 2 ? (NAE + 1) / 2 : (NAE + 3) / 4;   // (row, octet) pairs; per wave
-    constexpr int NPW = NGP + NAP;                                     // pieces per wave and stage
+    constexpr int NPW = WM == 2 ? NGP + NAP                            // pieces per wave and stage
+                                : (PARTS * C::PR * 4 * MH + PARTS * ROWS * NXG + NWAVES - 1) / NWAVES;
     const long long g_row = (long long)p.GX8 * p.Mp, g_part = g_row * p.GHp;
     const long long a_row = (long long)p.AX8 * p.Cp, a_part = a_row * p.Hp;
     int in_ = 0, ity = 0, itx = 0;                                      // (image, tile row, tile column) to issue next
@@ -118,8 +125,13 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     }
     long long gbase = 0, abase = 0;                                     // slot of (image, this wave's part, tile origin)
     auto locate = [&]() __attribute__((always_inline)) {
-        gbase = ((long long)(in_ * 2 + dpart) * p.GHp + ity * C::PR + dhw) * g_row + (long long)(itx * 4) * p.Mp + mt * 64;
-        abase = ((long long)(in_ * 2 + dpart) * p.Hp + ity * C::PR) * a_row + (long long)(itx * 4) * p.Cp + ct * 64;
+        if constexpr (WM == 2) {
+            gbase = ((long long)(in_ * 2 + dpart) * p.GHp + ity * C::PR + dhw) * g_row + (long long)(itx * 4) * p.Mp + mt * 64;
+            abase = ((long long)(in_ * 2 + dpart) * p.Hp + ity * C::PR) * a_row + (long long)(itx * 4) * p.Cp + ct * 64;
+        } else {                                                      // (part 0, row 0 of the tile: the rest per piece)
+            gbase = ((long long)(in_ * 2) * p.GHp + ity * C::PR) * g_row + (long long)(itx * 4) * p.Mp + mt * M_TILE;
+            abase = ((long long)(in_ * 2) * p.Hp + ity * C::PR) * a_row + (long long)(itx * 4) * p.Cp + ct * 64;
+        }
     };
     auto advance = [&]() __attribute__((always_inline)) {
         if (++itx == p.tiles_x) {
@@ -127,8 +139,25 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
             if (++ity == p.tiles_y) { ity = 0; ++in_; }
         }
     };
+    // 8 waves: piece j of the wave = piece (wave + 8 j) of the stage's list [G: part][row][octet][64-channel half], then
+    // [A: part][row][octet]; the decode is scalar arithmetic on the wave index
+    constexpr int NGPIECE = PARTS * C::PR * 4 * MH, NAPIECE = PARTS * ROWS * NXG;
+    auto issue_piece8 = [&](int buf, int i) __attribute__((always_inline)) {
+        const int j = wave + NWAVES * i;
+        if (j < NGPIECE) {
+            const int mh = j % MH, t1 = j / MH, o = t1 % 4, t2 = t1 / 4, row = t2 % C::PR, part = t2 / C::PR;
+            glds16_sv(p.gt + gbase + part * g_part + row * g_row + (long long)o * p.Mp + mh * 64, lane16,
+                      lds0 + (buf * STAGE + (((part * C::PR + row) * 4 + o) * MH + mh) * 64) * 16);
+        } else if (j < NGPIECE + NAPIECE) {
+            const int e = j - NGPIECE, o = e % NXG, t1 = e / NXG, r = t1 % ROWS, part = t1 / ROWS;
+            glds16_sv(p.at + abase + part * a_part + r * a_row + (long long)o * p.Cp, lane16,
+                      lds0 + (buf * STAGE + G_SLOTS + ((part * ROWS + r) * NXG + o) * 64) * 16);
+        }
+    };
     auto issue_piece = [&](int buf, int j) __attribute__((always_inline)) {   // uses gbase / abase of the located stage
-        if (j < NGP) {
+        if constexpr (WM == 4) {
+            issue_piece8(buf, j);
+        } else if (j < NGP) {
             const int o = PARTS == 2 ? j : 2 * (wave & 1) + j;          // octet of the G row
             glds16_sv(p.gt + gbase + (long long)o * p.Mp, lane16,
                       lds0 + (buf * STAGE + ((dpart * C::PR + dhw) * 4 + o) * 64) * 16);
@@ -155,7 +184,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // fragment slots (16 bytes each) relative to a stage buffer
-    const int ga = (half) * 64 + wm * 32 + l32;                        // + (part*PR*4 + py*4 + xh*2) * 64
+    const int ga = (half) * M_TILE + wm * 32 + l32;                    // + (part*PR*4 + py*4 + xh*2) * M_TILE
     const int ab = G_SLOTS + half * 64 + wq * 32 + l32;                // + ((part*ROWS + row)*NXG + xh*2 + j) * 64
 
     if (st0 < st1) {
@@ -187,12 +216,12 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         const int py = ks >> 1, xh = ks & 1;
         const uint4* S0 = smem + buf * STAGE;
         if (ky == 0) {
-            u32x4 th = *reinterpret_cast<const u32x4*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * 64);
+            u32x4 th = *reinterpret_cast<const u32x4*>(S0 + ga + ((0 * C::PR + py) * 4 + xh * 2) * M_TILE);
 #pragma unroll
             for (int d = 0; d < 4; ++d) th[d] = live ? th[d] : 0u;
             ah[KY == 1 ? rb : (ks & 1)] = __builtin_bit_cast(bf16x8, th);
             if constexpr (PARTS == 2) {
-                u32x4 tl = *reinterpret_cast<const u32x4*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * 64);
+                u32x4 tl = *reinterpret_cast<const u32x4*>(S0 + ga + ((1 * C::PR + py) * 4 + xh * 2) * M_TILE);
 #pragma unroll
                 for (int d = 0; d < 4; ++d) tl[d] = live ? tl[d] : 0u;
                 al[KY == 1 ? rb : (ks & 1)] = __builtin_bit_cast(bf16x8, tl);
@@ -297,7 +326,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
     // fills buffer 1, so it is cleared here.
     if (st0 + 1 == st1) {
         uint4* z = reinterpret_cast<uint4*>(smem_raw) + STAGE;
-        for (int i = tid; i < STAGE; i += 256) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < STAGE; i += NWAVES * 64) z[i] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
     }
     for (int st = st0; st < st1; st += 2) {
@@ -313,7 +342,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
         if (acc[0][0] == 123.456f) p.partial[0] = 1.f;
         return;
     }
-    const long long tile_floats = 4LL * T * 1024;
+    const long long tile_floats = (long long)NWAVES * T * 1024;
     float* out = p.partial + ((long long)split * p.m_tiles * p.c_tiles + (long long)mt * p.c_tiles + ct) * tile_floats +
                  (long long)wave * T * 1024 + lane;
 #pragma unroll
@@ -328,7 +357,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void wgrad_bf16x3(const WgradBf3
 // dW[m][c][2 ty + ry][2 tx + rx], taps >= K (a 3x3 layer's seven all-zero ones) dropped.
 __global__ __launch_bounds__(256) void wgrad_bf3_reduce_kernel(const float* __restrict__ partial, int P, int M, int Cin,
                                                                int T, int c_tiles, long long total, int s2d_c, int K,
-                                                               float* __restrict__ dw) {
+                                                               float* __restrict__ dw, int WM = 2) {
     for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
         float s = 0.f;
         int k = 0;
@@ -341,11 +370,12 @@ __global__ __launch_bounds__(256) void wgrad_bf3_reduce_kernel(const float* __re
         const int lane = (int)(j & 63), r = (int)((j >> 6) & 15);
         const long long jt = j >> 10;
         const int t = (int)(jt % T);
-        const int wave = (int)((jt / T) & 3);
-        const int tile = (int)(jt / T / 4);
+        const int nw = 2 * WM;                       // waves per tile: WM (m) x 2 (ci)
+        const int wave = (int)((jt / T) % nw);
+        const int tile = (int)(jt / T / nw);
         const int mt = tile / c_tiles, ct = tile - mt * c_tiles;
-        const int mm = mt * 64 + (wave & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int ci = ct * 64 + (wave >> 1) * 32 + (lane & 31);
+        const int mm = mt * (32 * WM) + (wave % WM) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int ci = ct * 64 + (wave / WM) * 32 + (lane & 31);
         if (mm >= M || ci >= Cin) continue;
         if (s2d_c == 0) {
             dw[((long long)mm * Cin + ci) * T + t] = s;

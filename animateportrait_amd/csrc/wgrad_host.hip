@@ -54,6 +54,7 @@ struct WgradPlan {
     bool s2d = false;
     // ... of the row form of a 7x7 stem: a 1 x 7 layer over 7 Cin channels (channel ci * 7 + ky = the input shifted by ky rows)
     bool rows = false;
+    bool wide = false;                      // the 8-wave workgroup: 128-channel M tiles (split-bf16 arithmetic, K <= 3, M % 128 == 0)
     int Kb = 0, Cb = 0, Hb = 0, Wb = 0;     // kernel size, channels and operand size the bf16 GEMM kernel sees
     // streaming kernel for 1..2 input channels (wgrad_narrow.h): > 0 = output channels per workgroup
     int narrow_cob = 0, narrow_ppt = 0, gwc = 0, gwc_shift = 0, rpi = 0, rows_per_block = 0;
@@ -66,13 +67,20 @@ struct WgradBf3Kernel {
     size_t lds_bytes;
     const void* fn1;       // head planes only, one product per tap (AP_PRECISION_BF16): two workgroups per CU
     size_t lds_bytes1;
+    const void* fn_wide = nullptr;   // the 8-wave workgroup (128 x 64 channel tile, WgradBf3Cfg WM = 4) of the split-bf16 form
+    size_t lds_bytes_wide = 0;
 };
 static const std::vector<WgradBf3Kernel>& wgrad_bf3_registry() {
     static std::vector<WgradBf3Kernel> v = {
 #define APAMD_WBF3(K)                                                                                         \
     {K, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 2>>), WgradBf3Cfg<K, 2>::lds_bytes(),     \
      reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 1>>), WgradBf3Cfg<K, 1>::lds_bytes()}
-        APAMD_WBF3(3), APAMD_WBF3(4), APAMD_WBF3(2),   // (K = 2: the space-to-depth forms of stride-2 layers)
+#define APAMD_WBF3W(K)                                                                                        \
+    {K, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 2>>), WgradBf3Cfg<K, 2>::lds_bytes(),     \
+     reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 1>>), WgradBf3Cfg<K, 1>::lds_bytes(),         \
+     reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<K, 2, K, 4>>), WgradBf3Cfg<K, 2, K, 4>::lds_bytes()}
+        APAMD_WBF3W(3), APAMD_WBF3(4), APAMD_WBF3W(2),   // (K = 2: the space-to-depth forms of stride-2 layers)
+#undef APAMD_WBF3W
 #undef APAMD_WBF3
         // K = 7: the ROW form of the 7x7 stems (1 x 7 taps over 7 Cin row channels: WgradBf3Cfg KY = 1)
         {7, reinterpret_cast<const void*>(&wgrad_bf16x3<WgradBf3Cfg<7, 2, 1>>), WgradBf3Cfg<7, 2, 1>::lds_bytes(),
@@ -182,7 +190,13 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.tiles_x = (d->GW + 31) / 32;
         pl.tiles_y = (d->GH + 1) / 2;
         pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
-        pl.m_tiles = (d->M + 63) / 64;
+        // split-bf16 arithmetic on 128-output multiples: the 8-wave workgroup (two waves per SIMD where the 4-wave one, whose
+        // head + tail stages fill the LDS, has one)
+        const char* now_ = getenv("APAMD_NO_WIDE_WGRAD");
+        // (plain bf16 keeps two 4-wave workgroups per CU: the 8-wave form measured the same, 160.9 against 160.0 us per 3x3 layer)
+        pl.wide = d->precision == AP_PRECISION_BF16X3 && !pl.rows && pl.Kb <= 3 && d->M % 128 == 0 && !(now_ && atoi(now_));
+        const int mtile = pl.wide ? 128 : 64;
+        pl.m_tiles = (d->M + mtile - 1) / mtile;
         pl.c_tiles = (pl.Cb + 63) / 64;
         const char* e = getenv("APAMD_WGRAD_BLOCKS");
         if (e) {                                                  // tuning / test knob: never silent
@@ -191,12 +205,12 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             told = true;
         }
         // one workgroup per CU (its LDS stages fill a CU); two with head-only staging
-        const int target = e ? atoi(e) : num_cus_w() * (d->precision == AP_PRECISION_BF16 && (pl.Kb <= 3 || pl.rows) ? 2 : 1);
+        const int target = e ? atoi(e) : num_cus_w() * (d->precision == AP_PRECISION_BF16 && (pl.Kb <= 3 || pl.rows) && !pl.wide ? 2 : 1);
         int P = target / (pl.m_tiles * pl.c_tiles);
         if (P > pl.nstages / 2) P = pl.nstages / 2;
         if (P < 1) P = 1;
         pl.P = P;
-        pl.Mp = pl.m_tiles * 64;
+        pl.Mp = pl.m_tiles * mtile;
         pl.Cp = pl.c_tiles * 64;
         pl.GHp = pl.tiles_y * 2;
         pl.GX8 = pl.tiles_x * 4;
@@ -204,7 +218,7 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.AX8 = pl.tiles_x * 4 + 1;
         pl.a_floats = (long long)d->N * 2 * pl.Hp * pl.AX8 * pl.Cp * 4;      // 16-byte slots -> floats
         pl.g_floats = (long long)d->N * 2 * pl.GHp * pl.GX8 * pl.Mp * 4;
-        pl.part_floats = (long long)pl.P * pl.m_tiles * pl.c_tiles * 4 * (pl.rows ? pl.Kb : pl.Kb * pl.Kb) * 1024;   // accumulator-order tiles
+        pl.part_floats = (long long)pl.P * pl.m_tiles * pl.c_tiles * (pl.wide ? 8 : 4) * (pl.rows ? pl.Kb : pl.Kb * pl.Kb) * 1024;   // accumulator-order tiles
         return AP_OK;
     }
     const int PR = pl.k->PR;
@@ -516,7 +530,9 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         for (const auto& k : wgrad_bf3_registry())
             if (k.K == pl.Kb) bk = &k;
         if (!bk) return fail(AP_ERR_UNSUPPORTED, "wgrad: no split-bf16 kernel for k=%d", pl.Kb);
-        const void* wfn = d->precision == AP_PRECISION_BF16 ? bk->fn1 : bk->fn;
+        if (pl.wide && !bk->fn_wide) return fail(AP_ERR_UNSUPPORTED, "wgrad: no 8-wave kernel for k=%d", pl.Kb);
+        const bool b16 = d->precision == AP_PRECISION_BF16;
+        const void* wfn = pl.wide ? bk->fn_wide : (b16 ? bk->fn1 : bk->fn);
         rc = ensure_wattr(wfn);
         if (rc) return rc;
         uint4* at = reinterpret_cast<uint4*>(workspace);
@@ -565,14 +581,14 @@ static int wgrad_impl(const ap_wgrad_desc* d, const void* g_t, float* workspace,
         }
         void* args[] = {&p};
         const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
-        hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(256), args,
-                                       d->precision == AP_PRECISION_BF16 ? bk->lds_bytes1 : bk->lds_bytes, stream);
+        hipError_t e = hipLaunchKernel(wfn, dim3(nblk), dim3(pl.wide ? 512 : 256), args,
+                                       pl.wide ? bk->lds_bytes_wide : (b16 ? bk->lds_bytes1 : bk->lds_bytes), stream);
         if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_bf16x3 launch: %s", hipGetErrorString(e));
         const int T = pl.rows ? pl.Kb : pl.Kb * pl.Kb;
-        const long long total = (long long)pl.m_tiles * pl.c_tiles * 4 * T * 1024;
+        const long long total = (long long)pl.m_tiles * pl.c_tiles * (pl.wide ? 8 : 4) * T * 1024;
         const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
         hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, partial, pl.P, d->M, pl.Cb, T,
-                           pl.c_tiles, total, pl.s2d ? pl.Cin : 0, d->K, dw);
+                           pl.c_tiles, total, pl.s2d ? pl.Cin : 0, d->K, dw, pl.wide ? 4 : 2);
         return check_launch("wgrad_bf3_reduce_kernel");
     }
     rc = ensure_wattr(pl.k->fn);
