@@ -934,8 +934,15 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         p.src.C = d->src[0].C; p.src.act = d->src[0].act;
         p.N = d->N; p.C = pl.Cin; p.H = d->H; p.W = d->W; p.OH = pl.Hout; p.OW = pl.Wout;
         p.w = packed + pl.head_w_off; p.bias = bias; p.act = d->act; p.y = y;
-        hipLaunchKernelGGL(conv_head_fwd_kernel<kHeadBand>, dim3(d->N, (pl.Hout + kHeadBand - 1) / kHeadBand), dim3(1024), 0,
-                           (hipStream_t)stream, p);
+        // rows per workgroup: the tallest band that still gives every CU a workgroup (N x bands >= ~200) -- with 10-row bands a
+        // B = 16 launch is 48 workgroups on 256 CUs (53 us for 50 MB); shorter bands re-read 3 halo rows each, which is cheap here
+        const int rb10 = d->N * ((pl.Hout + 9) / 10), rb5 = d->N * ((pl.Hout + 4) / 5);
+        if (rb10 >= 200 || env_int("APAMD_HEAD_BAND", 0) == 10)
+            hipLaunchKernelGGL(conv_head_fwd_kernel<10>, dim3(d->N, (pl.Hout + 9) / 10), dim3(1024), 0, (hipStream_t)stream, p);
+        else if (rb5 >= 200 || env_int("APAMD_HEAD_BAND", 0) == 5)
+            hipLaunchKernelGGL(conv_head_fwd_kernel<5>, dim3(d->N, (pl.Hout + 4) / 5), dim3(1024), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL(conv_head_fwd_kernel<3>, dim3(d->N, (pl.Hout + 2) / 3), dim3(1024), 0, (hipStream_t)stream, p);
         return check_launch("conv_head_fwd_kernel");
     }
     if (pl.small) {
