@@ -62,7 +62,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 10     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 11     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -146,6 +146,8 @@ SIGNATURES = {
                                              ctypes.c_void_p]),
     'ap_conv2d_wgrad_gt_dims': (ctypes.c_int, [ctypes.POINTER(ApWgradDesc), ctypes.POINTER(ctypes.c_int32)]),
     'ap_conv2d_wgrad_pre': (ctypes.c_int, [ctypes.POINTER(ApWgradDesc), ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_conv2d_wgrad_xs_ok': (ctypes.c_int32, [ctypes.POINTER(ApWgradDesc)]),
+    'ap_conv2d_wgrad_xs': (ctypes.c_int, [ctypes.POINTER(ApWgradDesc), ctypes.c_void_p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_act_bwd': (ctypes.c_int, [c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
                                   ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),
     'ap_bias_grad': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, ctypes.c_void_p]),

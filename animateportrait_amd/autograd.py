@@ -160,7 +160,8 @@ def _split_backward_plan(tape, layer, srcs, out, contribs):
     # per layer and step otherwise)
     key = (n, c, h, w, bool(pads), layer.weight.requires_grad, tuple(tape.tracked(f) for f in srcs),
            tuple(tuple(f.data.shape) for f in srcs), s.precision, ops.DEFAULT_PRECISION,
-           tuple(os.environ.get(v) for v in ('APAMD_NO_INBWD_SPLIT', 'APAMD_NO_DGRAD_STRIP', 'APAMD_NO_BF16X3', 'APAMD_NO_S2D')))
+           tuple(os.environ.get(v) for v in ('APAMD_NO_INBWD_SPLIT', 'APAMD_NO_DGRAD_STRIP', 'APAMD_NO_BF16X3', 'APAMD_NO_S2D')),
+           ops.XS_DIRECT, all(f.xs is not None for f in srcs))
     cache = layer.__dict__.setdefault('_split_bwd_plans', {})
     if key not in cache:
         cache[key] = _split_backward_decision(tape, layer, srcs, out, bool(pads))
@@ -176,10 +177,16 @@ def _split_backward_decision(tape, layer, srcs, out, folded):
     if not ops.instnorm_bwd_split_ok(out, 1 if folded else 0):
         return None
     gt_dims = None
+    wg_xs = False
     if layer.weight.requires_grad:
-        gt_dims = ops.wgrad_gt_dims(s.k, s.stride, s.pad, s.pad_mode, (n, c, h, w), srcs, s.precision)
-        if gt_dims is None:
-            return None
+        # split-bf16 3x3 layers whose sources carry their forward copies: the weight gradient reads the gradient's split copy itself
+        # (ops.wgrad g_xs=, ap_conv2d_wgrad_xs) -- no prepared operand; plain bf16 keeps the prepared-operand kernel (faster there)
+        wg_xs = (s.precision == ops.PRECISION_BF16X3 and ops.DEFAULT_PRECISION == ops.PRECISION_BF16X3 and
+                 ops.wgrad_xs_ok(s.k, s.stride, s.pad, s.pad_mode, (n, c, h, w), srcs, s.precision))
+        if not wg_xs:
+            gt_dims = ops.wgrad_gt_dims(s.k, s.stride, s.pad, s.pad_mode, (n, c, h, w), srcs, s.precision)
+            if gt_dims is None:
+                return None
     want_xs = want_strip = False
     probe = Feat(out.data)                 # a plain feature of the gradient's shape
     for i, f in enumerate(srcs):
@@ -189,9 +196,9 @@ def _split_backward_decision(tape, layer, srcs, out, folded):
                 return None
             want_xs = True
             want_strip = want_strip or bool(fold_pad and ops.dgrad_strip_eligible(spec, probe))
-    if gt_dims is None and not want_xs:
+    if gt_dims is None and not want_xs and not wg_xs:
         return None
-    return gt_dims, want_xs, want_strip
+    return gt_dims, want_xs or wg_xs, want_strip, wg_xs
 
 
 def conv_backward(tape, layer, srcs, out, norm, act):
@@ -200,12 +207,13 @@ def conv_backward(tape, layer, srcs, out, norm, act):
     if not contribs:
         return
     s = layer.spec
-    gt = strip = None
+    gt = strip = g_xs = None
     plan = _split_backward_plan(tape, layer, srcs, out, contribs) if norm else None
     if plan is not None:
         # the gradient only feeds the bf16 matrix kernels: its producer writes their operands, no fp32 dy (ops.instnorm_bwd_split)
-        red, gt_dims, want_xs, want_strip = plan
+        red, gt_dims, want_xs, want_strip, wg_xs = plan
         gfeat, gt, strip = ops.instnorm_bwd_split(red, out, gt_dims, want_xs, want_strip)
+        g_xs = gfeat.xs if wg_xs else None
         dy = None
     else:
         if out.data.dtype != torch.float32:      # (a bf16 raw output whose backward takes the fp32 route after all: convert once)
@@ -221,7 +229,7 @@ def conv_backward(tape, layer, srcs, out, norm, act):
                            out=tape.slot(layer.weight))
         else:
             dw = ops.wgrad(s.k, s.stride, s.pad, s.pad_mode, gfeat, srcs, layer.weight.shape, precision=s.precision,
-                           out=tape.slot(layer.weight), g_t=gt)
+                           out=tape.slot(layer.weight), g_t=gt, g_xs=g_xs)
         tape.add_param(layer.weight, dw)
     if layer.bias.requires_grad:
         # a bias in front of InstanceNorm has an exactly-zero gradient (it is removed by the mean subtraction)

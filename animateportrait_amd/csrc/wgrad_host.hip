@@ -6,6 +6,7 @@
 #include "common.h"
 #include "conv_head.h"
 #include "wgrad_bf16x3.h"
+#include "wgrad_xs.h"
 #include "wgrad_igemm.h"
 #include "wgrad_narrow.h"
 #include "wgrad_final.h"
@@ -390,6 +391,75 @@ static int ensure_wattr(const void* fn) {
 }  // namespace apamd
 
 using namespace apamd;
+
+// ---- both operands straight from the convolutions' split copies (wgrad_xs.h): no operand preparation at all
+static bool wgrad_xs_direct_ok(const ap_wgrad_desc* d, const WgradPlan& pl) {
+    if (!pl.bf3 || pl.rows || pl.s2d || getenv("APAMD_NO_XS_DIRECT")) return false;
+    if (d->stride != 1 || d->K != 3 || d->M % 8 != 0) return false;
+    // (the kernel indexes a copy's 16-byte slots with 32 bits)
+    if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
+    for (int s = 0; s < d->nsrc; ++s)
+        if ((long long)d->N * 2 * (d->src[s].C / 8) * ((long long)d->H * d->W + 1) >= (1LL << 31)) return false;
+    if (d->precision != AP_PRECISION_BF16 && d->xs_parts != 2) return false;
+    if (d->xs_parts != 1 && d->xs_parts != 2) return false;
+    for (int s = 0; s < d->nsrc; ++s)
+        if (!d->src_xs[s] || d->src[s].C % 8 != 0) return false;
+    return true;
+}
+
+template <class C>
+static int launch_wgrad_xs(const WgradXsParams& p, unsigned nblk, hipStream_t stream) {
+    const void* fn = reinterpret_cast<const void*>(&wgrad_xs_kernel<C>);
+    int rc = ensure_wattr(fn);
+    if (rc) return rc;
+    WgradXsParams q = p;
+    void* args[] = {&q};
+    hipError_t e = hipLaunchKernel(fn, dim3(nblk), dim3(C::NT), args, C::lds_bytes(), stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_xs launch: %s", hipGetErrorString(e));
+    return AP_OK;
+}
+
+extern "C" int32_t ap_conv2d_wgrad_xs_ok(const ap_wgrad_desc* d) {
+    WgradPlan pl;
+    if (make_wgrad_plan(d, pl)) return 0;
+    return wgrad_xs_direct_ok(d, pl) ? 1 : 0;
+}
+
+extern "C" int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, float* workspace, float* dw, ap_stream_t stream_) {
+    WgradPlan pl;
+    int rc = make_wgrad_plan(d, pl);
+    if (rc) return rc;
+    if (!g_xs || !workspace || !dw) return fail(AP_ERR_INVALID, "wgrad_xs: null pointer");
+    if (!wgrad_xs_direct_ok(d, pl)) return fail(AP_ERR_UNSUPPORTED, "wgrad_xs: the layer is not on this route (ap_conv2d_wgrad_xs_ok)");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool b16 = d->precision == AP_PRECISION_BF16;
+    WgradXsParams p;
+    memset(&p, 0, sizeof(p));
+    p.g_xs = reinterpret_cast<const uint4*>(g_xs);
+    p.nseg = d->nsrc;
+    int cg = 0;
+    for (int s = 0; s < d->nsrc; ++s) {
+        p.a_xs[s] = reinterpret_cast<const uint4*>(d->src_xs[s]);
+        p.a_cg_begin[s] = cg;
+        cg += d->src[s].C / 8;
+    }
+    p.a_cg_begin[d->nsrc] = cg;
+    p.N = d->N; p.M = d->M; p.GH = d->GH; p.GW = d->GW; p.H = d->H; p.W = d->W; p.pad = d->pad; p.pad_mode = d->pad_mode;
+    p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P; p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
+    p.partial = workspace;
+    const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
+    if (pl.wide) rc = launch_wgrad_xs<WgradXsCfg<3, 2, 4>>(p, nblk, stream);
+    else if (b16) rc = launch_wgrad_xs<WgradXsCfg<3, 1, 2>>(p, nblk, stream);
+    else rc = launch_wgrad_xs<WgradXsCfg<3, 2, 2>>(p, nblk, stream);
+    if (rc) return rc;
+    const int T = 9;
+    const long long total = (long long)pl.m_tiles * pl.c_tiles * (pl.wide ? 8 : 4) * T * 1024;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.P, d->M, pl.Cb, T, pl.c_tiles, total, 0,
+                       d->K, dw, pl.wide ? 4 : 2);
+    return check_launch("wgrad_bf3_reduce_kernel");
+}
+
 
 extern "C" {
 

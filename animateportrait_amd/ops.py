@@ -86,6 +86,8 @@ def _require_device(t, name, allow_bf16=False):
 BF16_RAW = os.environ.get('APAMD_NO_BF16_RAW', '0') != '1'
 # the weight gradients' shifted operand re-tiled from the forward pass's split copies (ap_wgrad_desc.src_xs); 1 turns it off
 XS_WGRAD = os.environ.get('APAMD_NO_XS_WGRAD', '0') != '1'
+# ... and, where the gradient's split copy exists too, both operands read as split copies by the kernel itself (ap_conv2d_wgrad_xs)
+XS_DIRECT = XS_WGRAD and os.environ.get('APAMD_NO_XS_DIRECT', '0') != '1'
 
 
 class Feat:
@@ -898,12 +900,14 @@ def _grad_out(out, shape, device):
     return out
 
 
-def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None, g_t=None):
+def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None, g_t=None, g_xs=None):
     """Weight gradient (see include/animateportrait_amd.h: ap_conv2d_wgrad).  g: Feat of the M-role tensor,
     srcs: Feats of the shifted tensor's segments.  Returns a tensor of ``out_shape`` (OIHW / IOHW): ``out`` when given
     (the layer's slot in the network's contiguous gradient block), else a new tensor.
     precision: PRECISION_* (default: the package default, i.e. split-bf16 for the wide stride-1 layers).
-    g_t: the M-role operand as instnorm_bwd_split wrote it (wgrad_gt_dims); ``g`` then only carries the shape."""
+    g_t: the M-role operand as instnorm_bwd_split wrote it (wgrad_gt_dims); ``g`` then only carries the shape.
+    g_xs: the split copy of the gradient (instnorm_bwd_split's ``xs``): where the layer is served by ap_conv2d_wgrad_xs (both operands
+    read as the convolutions' split copies, no preparation) that route is taken; ``g`` again only carries the shape."""
     n, m, gh, gw = g.data.shape
     cin = sum(f.data.shape[1] for f in srcs)
     if (m == 1 and k == 4 and stride == 1 and len(srcs) == 1 and cin >= 64 and not g.virtual and g.act == ACT_NONE and
@@ -941,13 +945,19 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
     if m <= 4 and stride == 1 and cin >= 16 and tuple(out_shape) == (m, cin, k, k) and 2 * pad == k - 1:
         dw = _wgrad_few_outputs(k, pad, pad_mode, g, srcs, out_shape)
         return dw if out is None else out.copy_(dw)
-    d = _wgrad_desc(k, stride, pad, pad_mode, (n, m, gh, gw), None if g_t is not None else g, srcs, precision)
+    d = _wgrad_desc(k, stride, pad, pad_mode, (n, m, gh, gw), None if (g_t is not None or g_xs is not None) else g, srcs, precision)
     lib = C.lib()
     nws = C.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_workspace_floats')
     ws = torch.empty(nws, dtype=torch.float32, device=srcs[0].data.device)
     dw = _grad_out(out, out_shape, srcs[0].data.device)
     assert dw.numel() == m * cin * k * k
-    if g_t is not None:
+    if g_xs is not None:
+        if lib.ap_conv2d_wgrad_xs_ok(ctypes.byref(d)) != 1:
+            raise RuntimeError('wgrad: the split copy of the gradient was passed but the layer is not served by ap_conv2d_wgrad_xs')
+        if PROFILER is not None:
+            PROFILER.note('wgrad_xs<%d> (split copies)' % k)
+        C.check(lib.ap_conv2d_wgrad_xs(ctypes.byref(d), _ptr(g_xs), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad_xs')
+    elif g_t is not None:
         if PROFILER is not None:
             PROFILER.note('wgrad_bf16x3<%d> (prepared operand)' % k)  # only that kernel takes the operand instnorm_bwd_split wrote
         C.check(lib.ap_conv2d_wgrad_pre(ctypes.byref(d), _ptr(g_t), _ptr(ws), _ptr(dw), _stream()), 'conv2d_wgrad_pre')
@@ -990,6 +1000,14 @@ def _wgrad_desc(k, stride, pad, pad_mode, g_shape, g, srcs, precision):
         if len(srcs) == 1 and srcs[0].s2d is not None and srcs[0].s2d.xs is not None:
             d.src_xs_s2d = srcs[0].s2d.xs.data_ptr()
     return d
+
+
+def wgrad_xs_ok(k, stride, pad, pad_mode, g_shape, srcs, precision=None):
+    """Is this weight gradient served with both operands as split copies (ap_conv2d_wgrad_xs)?  Needs the sources' forward copies."""
+    if not XS_DIRECT or g_shape[1] <= 4:
+        return False
+    d = _wgrad_desc(k, stride, pad, pad_mode, g_shape, None, srcs, precision)
+    return C.lib().ap_conv2d_wgrad_xs_ok(ctypes.byref(d)) == 1
 
 
 def wgrad_gt_dims(k, stride, pad, pad_mode, g_shape, srcs, precision=None):

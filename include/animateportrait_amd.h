@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 10
+#define AP_ABI_VERSION 11
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -398,6 +398,13 @@ int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, cons
  * d->g.data is not read by ap_conv2d_wgrad_pre. */
 int ap_conv2d_wgrad_gt_dims(const ap_wgrad_desc* d, int32_t* dims);
 int ap_conv2d_wgrad_pre(const ap_wgrad_desc* d, const void* g_t, float* workspace, float* dw, ap_stream_t stream);
+/* ap_conv2d_wgrad with BOTH operands taken as the split copies the convolutions stage (ABI 11; stride-1 3x3 layers on the bf16 matrix
+ * plan): the shifted operand from d->src_xs[] (the forward pass's copies, see ap_wgrad_desc), the M-role operand from g_xs = the
+ * split copy of dy in the ap_split_prepass layout (what ap_instnorm_bwd_split writes as `xs` for the data-gradient convolution).
+ * No operand is prepared: the kernel reads 8-channel slots with transposing LDS reads.  d->g / d->src[].data are not read.
+ * ap_conv2d_wgrad_xs_ok: 1 when the descriptor (with its src_xs / xs_parts) is served.  Workspace: ap_conv2d_wgrad_workspace_floats. */
+int32_t ap_conv2d_wgrad_xs_ok(const ap_wgrad_desc* d);
+int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, float* workspace, float* dw, ap_stream_t stream);
 /* dy = (fold(g1) + g2) * act'(out) for layers without normalisation; act = NONE makes it a fold-and-add
  * (out may then be NULL).  AP_ACT_TANH: 1 - out^2; RELU / LRELU: from the sign of the activated output. */
 int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,
