@@ -394,8 +394,15 @@ using namespace apamd;
 
 // ---- both operands straight from the convolutions' split copies (wgrad_xs.h): no operand preparation at all
 static bool wgrad_xs_direct_ok(const ap_wgrad_desc* d, const WgradPlan& pl) {
-    if (!pl.bf3 || pl.rows || pl.s2d || getenv("APAMD_NO_XS_DIRECT")) return false;
-    if (d->stride != 1 || d->K != 3 || d->M % 8 != 0) return false;
+    if (!pl.bf3 || pl.rows || getenv("APAMD_NO_XS_DIRECT")) return false;
+    if (d->M % 8 != 0) return false;
+    if (pl.s2d) {
+        // the space-to-depth form of a stride-2 layer: the 2 x 2 layer over the forward pass's space-to-depth copy (split-bf16 only)
+        if (d->precision != AP_PRECISION_BF16X3 || d->xs_parts != 2 || !d->src_xs_s2d || d->nsrc != 1 || pl.Cin % 8 != 0) return false;
+        if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
+        return (long long)d->N * 2 * (pl.Cb / 8) * ((long long)pl.Hb * pl.Wb + 1) < (1LL << 31);
+    }
+    if (d->stride != 1 || d->K != 3) return false;
     // (the kernel indexes a copy's 16-byte slots with 32 bits)
     if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
     for (int s = 0; s < d->nsrc; ++s)
@@ -436,27 +443,36 @@ extern "C" int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, floa
     WgradXsParams p;
     memset(&p, 0, sizeof(p));
     p.g_xs = reinterpret_cast<const uint4*>(g_xs);
-    p.nseg = d->nsrc;
-    int cg = 0;
-    for (int s = 0; s < d->nsrc; ++s) {
-        p.a_xs[s] = reinterpret_cast<const uint4*>(d->src_xs[s]);
-        p.a_cg_begin[s] = cg;
-        cg += d->src[s].C / 8;
+    p.N = d->N; p.M = d->M; p.GH = d->GH; p.GW = d->GW;
+    if (pl.s2d) {
+        p.nseg = 1;
+        p.a_xs[0] = reinterpret_cast<const uint4*>(d->src_xs_s2d);
+        p.a_cg_begin[0] = 0; p.a_cg_begin[1] = pl.Cb / 8;
+        p.H = pl.Hb; p.W = pl.Wb; p.pad = 0; p.pad_mode = AP_PAD_ZERO;
+    } else {
+        p.nseg = d->nsrc;
+        int cg = 0;
+        for (int s = 0; s < d->nsrc; ++s) {
+            p.a_xs[s] = reinterpret_cast<const uint4*>(d->src_xs[s]);
+            p.a_cg_begin[s] = cg;
+            cg += d->src[s].C / 8;
+        }
+        p.a_cg_begin[d->nsrc] = cg;
+        p.H = d->H; p.W = d->W; p.pad = d->pad; p.pad_mode = d->pad_mode;
     }
-    p.a_cg_begin[d->nsrc] = cg;
-    p.N = d->N; p.M = d->M; p.GH = d->GH; p.GW = d->GW; p.H = d->H; p.W = d->W; p.pad = d->pad; p.pad_mode = d->pad_mode;
     p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.nstages = pl.nstages; p.P = pl.P; p.m_tiles = pl.m_tiles; p.c_tiles = pl.c_tiles;
     p.partial = workspace;
     const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
-    if (pl.wide) rc = launch_wgrad_xs<WgradXsCfg<3, 2, 4>>(p, nblk, stream);
+    if (pl.s2d) rc = pl.wide ? launch_wgrad_xs<WgradXsCfg<2, 2, 4>>(p, nblk, stream) : launch_wgrad_xs<WgradXsCfg<2, 2, 2>>(p, nblk, stream);
+    else if (pl.wide) rc = launch_wgrad_xs<WgradXsCfg<3, 2, 4>>(p, nblk, stream);
     else if (b16) rc = launch_wgrad_xs<WgradXsCfg<3, 1, 2>>(p, nblk, stream);
     else rc = launch_wgrad_xs<WgradXsCfg<3, 2, 2>>(p, nblk, stream);
     if (rc) return rc;
-    const int T = 9;
+    const int T = pl.Kb * pl.Kb;
     const long long total = (long long)pl.m_tiles * pl.c_tiles * (pl.wide ? 8 : 4) * T * 1024;
     const int blocks = (int)std::min<long long>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.P, d->M, pl.Cb, T, pl.c_tiles, total, 0,
-                       d->K, dw, pl.wide ? 4 : 2);
+    hipLaunchKernelGGL(wgrad_bf3_reduce_kernel, dim3(blocks), dim3(256), 0, stream, workspace, pl.P, d->M, pl.Cb, T, pl.c_tiles, total,
+                       pl.s2d ? pl.Cin : 0, d->K, dw, pl.wide ? 4 : 2);
     return check_launch("wgrad_bf3_reduce_kernel");
 }
 

@@ -638,6 +638,11 @@ def test_wgrad_stride2_operand_from_forward_copies(dev, k):
     for f in (plain, with_xs, with_s2d):
         got = ops.wgrad(k, 2, 1, ops.PAD_ZERO, ops.Feat(up.to(dev)), [f], (cout, cin, k, k), precision=ops.PRECISION_BF16X3)
         assert linf(got, ref) < 5e-5 * scale, linf(got, ref) / scale
+    # ... and with both operands read as split copies by the kernel (ap_conv2d_wgrad_xs on the space-to-depth copy)
+    gf = ops.Feat(up.to(dev))
+    ops.presplit(gf, ops.PRECISION_BF16X3)
+    got = ops.wgrad(k, 2, 1, ops.PAD_ZERO, gf, [with_s2d], (cout, cin, k, k), precision=ops.PRECISION_BF16X3, g_xs=gf.xs)
+    assert linf(got, ref) < 5e-5 * scale, linf(got, ref) / scale
 
 
 @pytest.mark.parametrize('shape,act,two,pad', [((2, 5, 40, 36), 1, True, 0), ((2, 3, 128, 128), 2, False, 0),
