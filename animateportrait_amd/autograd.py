@@ -221,6 +221,12 @@ def conv_backward(tape, layer, srcs, out, norm, act):
             contribs = [(g.float() if g.dtype != torch.float32 else g, pd) for g, pd in contribs]
         dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
         gfeat = Feat(dy)
+        # split-bf16 layers served by ap_conv2d_wgrad_xs (3x3, the PatchGAN's 4x4): the gradient's split copy -- which the data-gradient
+        # convolution stages anyway (cached on the Feat) -- is the weight gradient's operand too: no operand preparation
+        if (layer.weight.requires_grad and not s.transposed and s.precision == ops.PRECISION_BF16X3 and
+                ops.DEFAULT_PRECISION == ops.PRECISION_BF16X3 and dy.shape[1] % 8 == 0 and
+                ops.wgrad_xs_ok(s.k, s.stride, s.pad, s.pad_mode, tuple(dy.shape), srcs, s.precision)):
+            g_xs = ops.presplit(gfeat, s.precision)
     # ---- weight gradient
     if layer.weight.requires_grad:
         if s.transposed:

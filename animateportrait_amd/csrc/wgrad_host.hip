@@ -402,7 +402,8 @@ static bool wgrad_xs_direct_ok(const ap_wgrad_desc* d, const WgradPlan& pl) {
         if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
         return (long long)d->N * 2 * (pl.Cb / 8) * ((long long)pl.Hb * pl.Wb + 1) < (1LL << 31);
     }
-    if (d->stride != 1 || d->K != 3) return false;
+    // 3x3, and (split bf16) the PatchGAN's 4x4 stride-1 layers: 16 accumulator tiles, the 4-wave workgroup, one per CU
+    if (d->stride != 1 || !(d->K == 3 || (d->K == 4 && d->precision == AP_PRECISION_BF16X3))) return false;
     // (the kernel indexes a copy's 16-byte slots with 32 bits)
     if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
     for (int s = 0; s < d->nsrc; ++s)
@@ -464,6 +465,7 @@ extern "C" int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, floa
     p.partial = workspace;
     const unsigned nblk = (unsigned)(pl.m_tiles * pl.c_tiles * pl.P);
     if (pl.s2d) rc = pl.wide ? launch_wgrad_xs<WgradXsCfg<2, 2, 4>>(p, nblk, stream) : launch_wgrad_xs<WgradXsCfg<2, 2, 2>>(p, nblk, stream);
+    else if (d->K == 4) rc = launch_wgrad_xs<WgradXsCfg<4, 2, 2>>(p, nblk, stream);
     else if (pl.wide) rc = launch_wgrad_xs<WgradXsCfg<3, 2, 4>>(p, nblk, stream);
     else if (b16) rc = launch_wgrad_xs<WgradXsCfg<3, 1, 2>>(p, nblk, stream);
     else rc = launch_wgrad_xs<WgradXsCfg<3, 2, 2>>(p, nblk, stream);
