@@ -28,6 +28,9 @@ def test_ctypes_struct_layout_matches_header():
     from animateportrait_amd import _capi
     assert ctypes.sizeof(_capi.ApSrc) == 32
     assert ctypes.sizeof(_capi.ApConvDesc) == 18 * 4 + 3 * 32
+    # ap_wgrad_desc: 12 ints, g + 3 sources, then (ABI 10) src_xs[3], src_xs_s2d, xs_parts (+ tail padding to 8)
+    assert ctypes.sizeof(_capi.ApWgradDesc) == 12 * 4 + 4 * 32 + 4 * 8 + 8
+    assert _capi.ApWgradDesc.src_xs.offset == 12 * 4 + 4 * 32 and _capi.ApWgradDesc.xs_parts.offset == 12 * 4 + 4 * 32 + 4 * 8
 
 
 def test_planning_queries_need_no_gpu():
