@@ -398,7 +398,8 @@ static bool wgrad_xs_direct_ok(const ap_wgrad_desc* d, const WgradPlan& pl) {
     if (d->M % 8 != 0) return false;
     if (pl.s2d) {
         // the space-to-depth form of a stride-2 layer: the 2 x 2 layer over the forward pass's space-to-depth copy (split-bf16 only)
-        if (d->precision != AP_PRECISION_BF16X3 || d->xs_parts != 2 || !d->src_xs_s2d || d->nsrc != 1 || pl.Cin % 8 != 0) return false;
+        // (that copy, or the plain one: the view is then gathered from it)
+        if (d->precision != AP_PRECISION_BF16X3 || d->xs_parts != 2 || !(d->src_xs_s2d || d->src_xs[0]) || d->nsrc != 1 || pl.Cin % 8 != 0) return false;
         if ((long long)d->N * 2 * (d->M / 8) * ((long long)d->GH * d->GW + 1) >= (1LL << 31)) return false;
         return (long long)d->N * 2 * (pl.Cb / 8) * ((long long)pl.Hb * pl.Wb + 1) < (1LL << 31);
     }
@@ -447,9 +448,10 @@ extern "C" int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, floa
     p.N = d->N; p.M = d->M; p.GH = d->GH; p.GW = d->GW;
     if (pl.s2d) {
         p.nseg = 1;
-        p.a_xs[0] = reinterpret_cast<const uint4*>(d->src_xs_s2d);
+        p.a_xs[0] = reinterpret_cast<const uint4*>(d->src_xs_s2d ? d->src_xs_s2d : d->src_xs[0]);
         p.a_cg_begin[0] = 0; p.a_cg_begin[1] = pl.Cb / 8;
         p.H = pl.Hb; p.W = pl.Wb; p.pad = 0; p.pad_mode = AP_PAD_ZERO;
+        p.s2d_c = d->src_xs_s2d ? 0 : pl.Cin;
     } else {
         p.nseg = d->nsrc;
         int cg = 0;

@@ -26,6 +26,9 @@ struct WgradXsParams {
     int a_cg_begin[kMaxSeg + 1];  // first channel octet of each segment; [nseg] = Cin / 8
     int nseg;
     int N, M, GH, GW, H, W, pad, pad_mode;
+    int s2d_c;                    // C0 > 0: the shifted operand is the space-to-depth VIEW (4 C0 channels, H x W = H0/2 + 1 x W0/2 + 1, pad 0)
+                                  // gathered from the PLAIN copy of the (C0, 2 (H - 1), 2 (W - 1)) source: view channel r * C0 + c, pixel
+                                  // (y, x) = pad1(source)[c][2 y + (r >> 1)][2 x + (r & 1)]  (a stride-2 layer whose forward pass staged that copy)
     int tiles_x, tiles_y, nstages, P, m_tiles, c_tiles;
     float* partial;               // [P][tile][wave][tap][16][64]
 };
@@ -90,14 +93,23 @@ __global__ __launch_bounds__(C::NT, C::WG_PER_CU) void wgrad_xs_kernel(const Wgr
     int which[NPT];                // 0: g_xs, 1..3: a_xs[which - 1]
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
-        const int kind = code[i] >> 28, o = (code[i] >> 20) & 0xff;
+        const int kind = code[i] >> 28, o = (code[i] >> 20) & 0x3f;
         obase[i] = 0; ostride[i] = 0; which[i] = -1;
         if (kind == 0) {
             const int go = mt * GOCT + o;
             if (go < MG) { obase[i] = go * (GHW + 1); ostride[i] = MG * (GHW + 1); which[i] = 0; }
         } else if (kind == 1) {
             const int ao = ct * 8 + o;
-            if (ao < p.a_cg_begin[p.nseg]) {
+            if (p.s2d_c > 0) {
+                const int CG0 = p.s2d_c >> 3, H0 = 2 * (p.H - 1), W0 = 2 * (p.W - 1);
+                if (ao < 4 * CG0) {
+                    const int r = ao / CG0;
+                    obase[i] = (ao - r * CG0) * (H0 * W0 + 1);
+                    ostride[i] = CG0 * (H0 * W0 + 1);
+                    which[i] = 1;
+                    code[i] |= r << 26;                              // the phase of this octet (bits 26-27)
+                }
+            } else if (ao < p.a_cg_begin[p.nseg]) {
                 int sg = 0;
                 if (p.nseg > 1 && ao >= p.a_cg_begin[1]) sg = 1;
                 if (p.nseg > 2 && ao >= p.a_cg_begin[2]) sg = 2;
@@ -127,14 +139,19 @@ __global__ __launch_bounds__(C::NT, C::WG_PER_CU) void wgrad_xs_kernel(const Wgr
         } else {
             int y = ity * C::PR + row - p.pad, x = itx * 32 + px - p.pad;
             bool ok = true;
-            if (p.pad_mode == 1) {
+            if (p.s2d_c > 0) {
+                const int r = (code[i] >> 26) & 3, H0 = 2 * (p.H - 1), W0 = 2 * (p.W - 1);
+                const int yy = 2 * y + (r >> 1) - 1, xx = 2 * x + (r & 1) - 1;
+                ok = y < p.H && x < p.W && yy >= 0 && yy < H0 && xx >= 0 && xx < W0;
+                pix = ok ? yy * W0 + xx : H0 * W0;
+            } else if (p.pad_mode == 1) {
                 // (rows / columns of tiles beyond the output grid: their G slots are zero, any finite value will do)
                 y = reflect_clamp(y < p.H + p.pad ? y : p.H - 1, p.H);
                 x = reflect_clamp(x < p.W + p.pad ? x : p.W - 1, p.W);
             } else {
                 ok = y >= 0 && y < p.H && x >= 0 && x < p.W;
             }
-            pix = ok ? y * p.W + x : HW;
+            if (p.s2d_c == 0) pix = ok ? y * p.W + x : HW;
         }
         const uint4* base = which[i] == 0 ? p.g_xs : (which[i] == 1 ? p.a_xs[0] : (which[i] == 2 ? p.a_xs[1] : p.a_xs[2]));
 #pragma unroll

@@ -643,8 +643,9 @@ def test_wgrad_stride2_operand_from_forward_copies(dev, k):
     # ... and with both operands read as split copies by the kernel (ap_conv2d_wgrad_xs on the space-to-depth copy)
     gf = ops.Feat(up.to(dev))
     ops.presplit(gf, ops.PRECISION_BF16X3)
-    got = ops.wgrad(k, 2, 1, ops.PAD_ZERO, gf, [with_s2d], (cout, cin, k, k), precision=ops.PRECISION_BF16X3, g_xs=gf.xs)
-    assert linf(got, ref) < 5e-5 * scale, linf(got, ref) / scale
+    for f in (with_s2d, with_xs):          # (from the space-to-depth copy; from the plain copy: the view gathered inside the kernel)
+        got = ops.wgrad(k, 2, 1, ops.PAD_ZERO, gf, [f], (cout, cin, k, k), precision=ops.PRECISION_BF16X3, g_xs=gf.xs)
+        assert linf(got, ref) < 5e-5 * scale, linf(got, ref) / scale
 
 
 @pytest.mark.parametrize('shape,act,two,pad', [((2, 5, 40, 36), 1, True, 0), ((2, 3, 128, 128), 2, False, 0),
