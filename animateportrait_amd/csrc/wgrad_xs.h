@@ -15,6 +15,10 @@
 // octet strides = 4 (mod 16) slots: the four channel octets a 32-lane group reads land on disjoint 16-bank groups.
 // Staging is a per-lane gather (one 16-byte slot per lane and LDS-DMA piece): padding is index arithmetic (reflection) or
 // the copy's all-zero slot HW.
+//
+// Served (wgrad_host.hip, ap_conv2d_wgrad_xs): 3x3 stride-1 layers; 4x4 stride-1 layers (split bf16; 16 accumulator tiles: the
+// 4-wave workgroup); the 2x2 space-to-depth forms of stride-2 layers, from the forward pass's space-to-depth copy or with the
+// view gathered from its plain copy (WgradXsParams::s2d_c).  Measurements and what was tried: profiles/r05_wgrad_routes.md.
 #pragma once
 #include "wgrad_bf16x3.h"
 
