@@ -41,6 +41,9 @@ import torch  # noqa: E402
 GFLOP_PER_FRAME = 140.125          # 70.063 GMAC conv + conv-transpose
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+# what the chip SUSTAINS on this kernel's operand data: a register-only stream of v_mfma_f32_32x32x16_bf16 on all 256 CUs
+# with random bf16 heads + tails (tools/mfma_peak.hip; profiles/r06_power.md): the matrix pipe is power-limited on real data
+SUSTAINED_BF16_MFMA_TFLOPS = 1710.0
 BATCH = 16
 
 
@@ -537,6 +540,10 @@ def main():
     roofline = {'bound': 'mfma', 'kernel': kname, 'pipe': pipe,
                 'achieved': round(alg, 2), 'peak': peak, 'unit': 'TFLOP/s',
                 'frac': round(alg / peak, 4), 'frac_algorithmic': round(alg / peak, 4),
+                'frac_vs_sustained': round(alg * mult / SUSTAINED_BF16_MFMA_TFLOPS, 4) if mult == 3.0 else None,
+                'sustained_note': 'frac_vs_sustained = executed FLOP/s over the %.0f TFLOP/s a register-only MFMA stream sustains on random '
+                                  'bf16 operands on this chip (tools/mfma_peak.hip, profiles/r06_power.md); frac stays against the '
+                                  'nominal peak' % SUSTAINED_BF16_MFMA_TFLOPS,
                 'executed_tflops': round(alg * mult, 2), 'mfma_pipe_utilisation': round(alg * mult / peak, 4),
                 'executed_flops_per_algorithmic_flop': mult,
                 'launches_per_step': dk['launches'] // psteps,
@@ -559,6 +566,7 @@ def main():
     roofline['traffic'] = ent['hbm_bytes_per_launch']
     roofline['traffic_unit'] = 'bytes/launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE)'
     roofline['traffic_source'] = 'profiles/hbm_traffic.json, PMC passes of profile round %s (not collected in this run)' % ent.get('round')
+    train_hbm = {k: tab.get(k) for k in ('__train_step_bf16__', '__train_step_bf16x3__')}
 
     # ---- the same workload with every product on the exact-fp32 MFMA (APAMD_PRECISION=fp32): reported next to the
     # headline so that the split-bf16 arithmetic (3 bf16 MFMAs per fp32 product, fp32 accumulate) is an explicit,
@@ -658,6 +666,22 @@ def main():
                 train_bf16['max_rel_loss_diff_vs_bf16x3'] = round(max(
                     abs(train_bf16['losses'][k] - train['losses'][k]) / max(abs(train['losses'][k]), 1e-6) for k in gk), 5)
             out['train_step_bf16'] = train_bf16
+        # the second half of the BASELINE metric ("train step ms") where the driver's record keeps it: sub-records of `roofline`
+        for key, rec in (('train_step_bf16', train_bf16), ('train_step', train)):
+            if rec is None:
+                continue
+            hb = train_hbm.get('__%s__' % (key if key.endswith('bf16') else key + '_bf16x3')) or {}
+            roofline[key] = {
+                'ms_per_step': rec['ms_per_step'], 'ms_per_step_with_standin_aux': rec.get('ms_per_step_with_standin_aux'),
+                'netF_ms_per_step': rec.get('netF_ms_per_step'), 'aux_ms_per_step': rec.get('aux_ms_per_step'),
+                'samples_per_s': rec['samples_per_s'], 'frac_algorithmic': rec['frac_algorithmic'],
+                'frac_algorithmic_with_standin_aux': (round(BATCH * 1.234 / (rec['ms_per_step_with_standin_aux'] * 1e-3) / PEAK_BF16_MFMA_TFLOPS, 4)
+                                                      if rec.get('ms_per_step_with_standin_aux') else None),
+                'hbm_gb_per_step': hb.get('hbm_gb_per_step'),
+                'hbm_source': ('profiles/hbm_traffic.json: FETCH_SIZE*2 + WRITE_SIZE over all kernels of the step with stand-in aux nets, '
+                               'PMC passes of profile round %s (tools/train_hbm.sh; not collected in this run)' % hb.get('round')) if hb else None,
+                'dtype': rec['dtype'], 'batch_per_gpu': BATCH, 'world_size': world,
+                'max_rel_loss_diff_vs_bf16x3': rec.get('max_rel_loss_diff_vs_bf16x3')}
         if stream_rec is not None:
             out['stream'] = stream_rec
         if cpu is not None:

@@ -271,6 +271,27 @@ def test_generator_width_whose_upconvolution_reads_fp32(dev, ngf):
     assert linf(y, ref) < 1e-3
 
 
+@pytest.mark.parametrize('ngf', [8, 64])
+def test_generator_output_nc3_cartoon_configuration(dev, ngf):
+    """The cartoon configuration (readme.md:67, `--output_nc 3`, geomgm_ifw_cartoon_fore_model.py): define_G(3, 3, ...) -- the
+    generator's last layer is ReflectionPad(3) + Conv7x7(ngf -> 3) + tanh (networks.py:1277-1279) and nothing else changes.
+    Against the oracle's forward on the same weights and batch, at the reduced width and at full width."""
+    from animateportrait_amd import networks as N
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    from oracle import generator as og
+    args = generator_args(make_generator_inputs(2, seed=11))
+    sd = og.init_params(og.generator_param_shapes(3, 3, ngf, 9, 3, 3), seed=11)
+    G = N.define_G(3, 3, ngf, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
+    G.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        y = G(*[a.to(dev) for a in args])
+        ref = og.generator_forward(sd, *args, div=3, disp=3)
+    assert y.shape == (2, 3, 256, 256)
+    err = linf(y, ref)
+    print('output_nc=3 ngf=%d generator L-inf vs oracle: %.3e' % (ngf, err))
+    assert err < 1e-3
+
+
 def test_static_generator(dev, golden):
     """resnet_style2_9blocks (networks.py:573-637) on the HIP path against the reference's
     outputs; cat[f1, style] is a two-segment source of model.0, never a tensor."""

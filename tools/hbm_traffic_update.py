@@ -45,7 +45,7 @@ for name, v in fd.items():
     print('%-40s %8.1f MB read x2, %8.1f MB written  <- %s' % (k, f * 1024 / 1e6, w * 1024 / 1e6, name))
 # entries of other rounds are dropped: they belong to kernels as they were then (seven r01* keys of kernel names that no
 # longer exist); a kernel the bench asks for and this round's passes did not see stops the bench (APAMD_BENCH_NO_TRAFFIC to develop)
-stale = [k for k, v in tab.items() if v.get('round') != tag]
+stale = [k for k, v in tab.items() if v.get('round') != tag and not k.startswith('__')]      # '__train_step_*__': tools/train_hbm.sh totals
 for k in stale:
     del tab[k]
 if stale:
