@@ -728,7 +728,82 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     }
                 }
             }
-            if (!octet) {
+            bool wide16 = false;
+            if constexpr (C::OB16) {
+                // ---- bf16 output, whole 32-pixel rows at 16-byte aligned addresses (the forward outputs of the trunk): a lane takes
+                // EIGHT consecutive pixels of a cout row from the patch (two ds_read_b128) and stores them as ONE 16-byte word --
+                // 2 store instructions per 32 x 32 tile where the 4-pixel form below needs 4.  The epilogue is bound by the number
+                // of store instructions a CU can retire (~115 cycles each whatever their width: MI355X_MICROARCH.md "store tail",
+                // profiles/r05_dominant_cycle_account.md), so the 8-byte form was no faster than the fp32 output it replaced.
+                wide16 = p.osx == 1 && ox_off == 0 && ox0 + 32 <= p.OW &&
+                         ((p.o_rstride | (int)p.o_cstride | (int)p.o_nstride) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+                if (wide16) {
+                    const int prow8 = lane >> 2, pcol8 = (lane & 3) * 8;
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float s2[2] = {0.f, 0.f}, q2s[2] = {0.f, 0.f};
+                        float bv2[2];
+                        long long cb2[2];
+                        bool cok2[2];
+#pragma unroll
+                        for (int ps = 0; ps < 2; ++ps) {
+                            const int co = co_base + m * 32 + ps * 16 + prow8;
+                            cok2[ps] = co < p.Cout;
+                            bv2[ps] = (p.bias != nullptr && cok2[ps]) ? p.bias[co] : 0.f;
+                            cb2[ps] = (long long)n * p.o_nstride + (long long)co * p.o_cstride + ox0 + pcol8;
+                        }
+#pragma unroll
+                        for (int q0 = 0; q0 < NT; q0 += NP) {
+#pragma unroll
+                            for (int b = 0; b < NP; ++b)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    patch0[b * (32 * TS) + ((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q0 + b][r];
+#pragma unroll
+                            for (int b = 0; b < NP; ++b) {
+                                const int oy = oy0 + wpx * NT + q0 + b;
+                                const long long rowoff = (long long)(oy * p.osy + oy_off) * p.o_rstride;
+#pragma unroll
+                                for (int ps = 0; ps < 2; ++ps) {
+                                    const float* src = patch0 + b * (32 * TS) + (ps * 16 + prow8) * TS + pcol8;
+                                    const float4 va = *reinterpret_cast<const float4*>(src), vb = *reinterpret_cast<const float4*>(src + 4);
+                                    const float bv = bv2[ps];
+                                    const float vv[8] = {va.x + bv, va.y + bv, va.z + bv, va.w + bv, vb.x + bv, vb.y + bv, vb.z + bv, vb.w + bv};
+                                    if (cok2[ps] && oy < p.OH) {
+                                        s2[ps] += ((vv[0] + vv[1]) + (vv[2] + vv[3])) + ((vv[4] + vv[5]) + (vv[6] + vv[7]));
+                                        q2s[ps] += ((vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3])) +
+                                                   ((vv[4] * vv[4] + vv[5] * vv[5]) + (vv[6] * vv[6] + vv[7] * vv[7]));
+                                        uint4 pk;
+                                        auto pack2 = [&](float a, float b2) {
+                                            return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(a)) |
+                                                   ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)actf(b2)) << 16);
+                                        };
+                                        pk.x = pack2(vv[0], vv[1]); pk.y = pack2(vv[2], vv[3]); pk.z = pack2(vv[4], vv[5]); pk.w = pack2(vv[6], vv[7]);
+                                        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(p.y) + cb2[ps] + rowoff) = pk;
+                                    }
+                                }
+                            }
+                        }
+                        if (want_stats) {
+#pragma unroll
+                            for (int ps = 0; ps < 2; ++ps) {
+                                float s = s2[ps], q2 = q2s[ps];
+#pragma unroll
+                                for (int sh = 1; sh < 4; sh <<= 1) {
+                                    s += __shfl_xor(s, sh, 64);
+                                    q2 += __shfl_xor(q2, sh, 64);
+                                }
+                                if ((lane & 3) == 0) {
+                                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + ps * 16 + prow8) * 2;
+                                    d[0] = s;
+                                    d[1] = q2;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!octet && !wide16) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};

@@ -43,7 +43,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
 # what the chip SUSTAINS on this kernel's operand data: a register-only stream of v_mfma_f32_32x32x16_bf16 on all 256 CUs
 # with random bf16 heads + tails (tools/mfma_peak.hip; profiles/r06_power.md): the matrix pipe is power-limited on real data
-SUSTAINED_BF16_MFMA_TFLOPS = 1710.0
+SUSTAINED_BF16_MFMA_TFLOPS = 1800.0
 BATCH = 16
 
 

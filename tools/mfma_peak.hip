@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -134,9 +136,52 @@ static void run(const char* label, int blocks, int threads, size_t ldsbytes) {
     hipFree(out);
 }
 
-int main() {
+// `mfma_peak loop <seconds> <data: 0 ones / 1 random / 2 real split>`: the register-only stream back to back for that long
+// (tools/power_record.py reads the chip's throttle accumulators around it).  Prints READY, then RESULT with the mean rate.
+template <int DATA>
+static void loop_for(int cus, double seconds) {
+    float* out;
+    hipMalloc(&out, 64);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&mfma_stream<0, DATA, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const int iters = 4000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((mfma_stream<0, DATA, 0>), dim3(cus), dim3(256), 150 * 1024, 0, out, iters);
+    hipDeviceSynchronize();
+    printf("READY\n");
+    fflush(stdout);
+    double total_ms = 0.0, first_ms = 0.0, last_ms = 0.0;
+    long n = 0;
+    while (total_ms < seconds * 1e3) {
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((mfma_stream<0, DATA, 0>), dim3(cus), dim3(256), 150 * 1024, 0, out, iters);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (n == 0) first_ms = ms / 10;
+        last_ms = ms / 10;
+        total_ms += ms;
+        n += 10;
+    }
+    const double flops = (double)cus * 4 * iters * 8 * 24 * 2.0 * 32 * 32 * 16;
+    printf("RESULT mfma_peak loop data=%d: %ld launches in %.2f s, mean %.1f TFLOP/s executed (first ten %.1f, last ten %.1f)\n", DATA, n,
+           total_ms * 1e-3, flops * n / (total_ms * 1e-3) / 1e12, flops / (first_ms * 1e-3) / 1e12, flops / (last_ms * 1e-3) / 1e12);
+    hipFree(out);
+}
+
+int main(int argc, char** argv) {
     int cus = 0;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
+    if (argc >= 3 && std::string(argv[1]) == "loop") {
+        const double seconds = atof(argv[2]);
+        const int data = argc >= 4 ? atoi(argv[3]) : 2;
+        if (data == 0) loop_for<0>(cus, seconds);
+        else if (data == 1) loop_for<1>(cus, seconds);
+        else loop_for<2>(cus, seconds);
+        return 0;
+    }
     printf("CUs: %d\n", cus);
     run<0, 0>("1 wave/SIMD, registers only, all-ones data", cus, 256, 150 * 1024);
     run<1, 0>("1 wave/SIMD, 12 ds_read_b128 / 24 MFMA, ones", cus, 256, 150 * 1024);
