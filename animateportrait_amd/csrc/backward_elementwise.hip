@@ -346,7 +346,8 @@ __device__ __forceinline__ float bf16_tail(float v) { return v - (float)(__bf16)
 
 // YB16: y holds bf16 values (the raw output ap_conv2d_fwd_bf16out stored); G16: g1 holds bf16 values (a data gradient stored by
 // ap_conv2d_fwd_view_bf16out) -- same element offsets, 2-byte elements
-template <int NT, bool YB16 = false, bool G16 = false>
+// FOLD: g1 is the gradient of a reflection-padded (pad 1) layer, still in padded coordinates (p.p1 == 1)
+template <int NT, bool YB16 = false, bool G16 = false, bool FOLD = false>
 __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplitParams p) {
     constexpr int NW = NT / 64;
     __shared__ float red[16][NW];
@@ -354,7 +355,6 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
     const int tid0 = threadIdx.x;
     const int H = p.H, W = p.W, HW = H * W, W4 = W >> 2;
     const bool live = tid0 < HW / 4;
-    const bool fold1 = p.p1 == 1;
     const int CG = p.C >> 3, items = p.N * CG;
     // A workgroup holds one (image, channel octet) in registers -- a CU has room for one such workgroup -- so it walks several of
     // them: the loads of the next item are issued right behind the stores of the current one (which are not waited for), so reads
@@ -371,68 +371,137 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
     asm volatile("" : "+v"(tid));
     const int row = tid / W4, x4 = (tid - row * W4) * 4;
     float xh[32], gv[32];
+    float rvl;                   // lane c (< 8) holds rstd of channel c0 + c
     {
-        float4 yv[8], gq[8];
+        // ---- load phase (round 6): NOTHING but loads -- raw words into registers, addresses clamped instead of branched on, the
+        // fold's border terms taken from a 6-element window of the padded row (its two outer elements ARE the reflected columns of
+        // the first / last group) and, in the two waves that hold rows 1 and H - 2, from a second window of padded row 0 / H + 1.
+        // Before, every channel's loads were followed by their conversion (bf16 -> fp32 shifts) or sat in the arms of the
+        // run-time `fold1` branch, and the compiler waited for each channel before it asked for the next: 16 serial memory round
+        // trips per item plus one per border term, 2.8-3.9 TB/s (profiles/r06_stream_readers.md).
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        using YRaw = std::conditional_t<YB16, u32x2, float4>;
+        using GRaw = std::conditional_t<G16, std::conditional_t<FOLD, u32x3, u32x2>, std::conditional_t<FOLD, float4u, float4>>;
+        const int ltid = live ? tid : 0;
+        const int lrow = ltid / W4, lx4 = (ltid - lrow * W4) * 4;
+        const long long nc0 = (long long)n * p.C + c0;
+        const int PW = W + 2, PHW = (H + 2) * PW;
+        // lanes of rows 1 / H - 2 fold padded row 0 / H + 1 in; everybody else reads its own row again (a cache hit), masked out later
+        const bool brow = FOLD && (lrow == 1 || lrow == H - 2);
+        const bool wave_brow = FOLD && __builtin_amdgcn_readfirstlane((int)(__ballot(brow && live) != 0ull));
+        const int prow = lrow == 1 ? 0 : (lrow == H - 2 ? H + 1 : lrow + 1);
+        const int ecol = lx4 == 0 ? 0 : (lx4 == W - 4 ? W + 1 : lx4 + 1);          // fp32 fold: the reflected column of the group, if any
+        YRaw yr[8];
+        GRaw gr[8], br[8];
+        float ge[8], be[8];
+        const float mvl = p.mean[nc0 + (tid & 7)];
+        rvl = p.rstd[nc0 + (tid & 7)];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const long long nc = (long long)n * p.C + c0 + c;
-            yv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            gq[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (live) {
-                if constexpr (YB16) {
-                    const uint2 t = reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.y) + nc * HW)[tid];
-                    yv[c] = make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
-                                        __uint_as_float(t.y & 0xffff0000u));
-                } else {
-                    yv[c] = reinterpret_cast<const float4*>(p.y + nc * HW)[tid];
-                }
-                if constexpr (G16) {
-                    const unsigned short* g16 = reinterpret_cast<const unsigned short*>(p.g1);
-                    gq[c] = fold1 ? ld4_bf16_odd(g16 + nc * (H + 2) * (W + 2) + (row + 1) * (W + 2) + x4 + 1) : ld4_bf16(g16 + nc * HW + tid * 4);
-                } else if (fold1) {         // the padded row itself; its reflected border terms follow
-                    const float4u t = *reinterpret_cast<const float4u*>(p.g1 + nc * (H + 2) * (W + 2) + (row + 1) * (W + 2) + x4 + 1);
-                    gq[c] = make_float4(t.x, t.y, t.z, t.w);
-                } else {
-                    gq[c] = reinterpret_cast<const float4*>(p.g1 + nc * HW)[tid];
-                }
-            }
-        }
-        if (fold1 && live) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                if constexpr (G16) {
-                    const unsigned short* gp = reinterpret_cast<const unsigned short*>(p.g1) + ((long long)n * p.C + c0 + c) * (H + 2) * (W + 2);
-                    const unsigned short* rp = gp + (row + 1) * (W + 2);
-                    if (x4 == 0) gq[c].y += bf16_val(rp[0]);
-                    if (x4 == W - 4) gq[c].z += bf16_val(rp[W + 1]);
-                    if (row == 1) { const float4 t = fold1_row4_bf16(gp, W, 0, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
-                    if (row == H - 2) { const float4 t = fold1_row4_bf16(gp, W, H + 1, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
-                } else {
-                const float* gp = p.g1 + ((long long)n * p.C + c0 + c) * (H + 2) * (W + 2);
-                const float* rp = gp + (row + 1) * (W + 2);
-                if (x4 == 0) gq[c].y += rp[0];
-                if (x4 == W - 4) gq[c].z += rp[W + 1];
-                if (row == 1) { const float4 t = fold1_row4(gp, W, 0, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
-                if (row == H - 2) { const float4 t = fold1_row4(gp, W, H + 1, x4); gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w; }
-                }
-            }
-        }
-        if (p.g2 != nullptr && live) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const float4 t = reinterpret_cast<const float4*>(p.g2 + ((long long)n * p.C + c0 + c) * HW)[tid];
-                gq[c].x += t.x; gq[c].y += t.y; gq[c].z += t.z; gq[c].w += t.w;
-            }
+            if constexpr (YB16) yr[c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.y) + (nc0 + c) * HW)[ltid];
+            else yr[c] = reinterpret_cast<const float4*>(p.y + (nc0 + c) * HW)[ltid];
         }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float m = p.mean[n * p.C + c0 + c], r = p.rstd[n * p.C + c0 + c];
-            const float yy[4] = {yv[c].x, yv[c].y, yv[c].z, yv[c].w}, gg[4] = {gq[c].x, gq[c].y, gq[c].z, gq[c].w};
+            if constexpr (G16 && FOLD) {
+                gr[c] = *reinterpret_cast<const u32x3*>(reinterpret_cast<const unsigned short*>(p.g1) + (nc0 + c) * PHW + (lrow + 1) * PW + lx4);
+            } else if constexpr (G16) {
+                gr[c] = reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(p.g1) + (nc0 + c) * HW)[ltid];
+            } else if constexpr (FOLD) {
+                const float* rp = p.g1 + (nc0 + c) * PHW + (lrow + 1) * PW;
+                gr[c] = *reinterpret_cast<const float4u*>(rp + lx4 + 1);
+                ge[c] = rp[ecol];
+            } else {
+                gr[c] = reinterpret_cast<const float4*>(p.g1 + (nc0 + c) * HW)[ltid];
+            }
+        }
+        constexpr bool BR_EARLY = false;      // (with the border windows in the first phase the bf16 form spilled 11 registers between its loads: a second phase for the two waves that hold rows 1 and H - 2)
+        auto load_border = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if constexpr (!FOLD) {
+                } else if constexpr (G16) {
+                    br[c] = *reinterpret_cast<const u32x3*>(reinterpret_cast<const unsigned short*>(p.g1) + (nc0 + c) * PHW + prow * PW + lx4);
+                } else {
+                    const float* rp = p.g1 + (nc0 + c) * PHW + prow * PW;
+                    br[c] = *reinterpret_cast<const float4u*>(rp + lx4 + 1);
+                    be[c] = rp[ecol];
+                }
+            }
+        };
+        if constexpr (BR_EARLY) {
+            if (wave_brow) load_border();
+        }
+        // ---- conversion and arithmetic
+        const bool first = lx4 == 0, last = lx4 == W - 4;
+        auto window = [&](const GRaw& w, float e) -> float4 {          // the folded group of a padded row from its raw words
+            float4 v;
+            if constexpr (G16) {
+                const float e0 = __uint_as_float(w[0] << 16), e5 = __uint_as_float(w[2] & 0xffff0000u);
+                v = make_float4(__uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u),
+                                __uint_as_float(w[2] << 16));
+                v.y += first ? e0 : 0.f;
+                v.z += last ? e5 : 0.f;
+            } else {
+                v = make_float4(w[0], w[1], w[2], w[3]);
+                v.y += first ? e : 0.f;
+                v.z += last ? e : 0.f;
+            }
+            return v;
+        };
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mvl), c)), r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rvl), c));
+            float4 yv, gq;
+            if constexpr (YB16) yv = make_float4(__uint_as_float(yr[c][0] << 16), __uint_as_float(yr[c][0] & 0xffff0000u),
+                                                 __uint_as_float(yr[c][1] << 16), __uint_as_float(yr[c][1] & 0xffff0000u));
+            else yv = yr[c];
+            if constexpr (FOLD) {
+                gq = window(gr[c], G16 ? 0.f : ge[c]);
+                if constexpr (BR_EARLY) {
+                    if (wave_brow) {
+                        const float4 t = window(br[c], 0.f);
+                        gq.x += brow ? t.x : 0.f; gq.y += brow ? t.y : 0.f; gq.z += brow ? t.z : 0.f; gq.w += brow ? t.w : 0.f;
+                    }
+                }
+            } else if constexpr (G16) {
+                gq = make_float4(__uint_as_float(gr[c][0] << 16), __uint_as_float(gr[c][0] & 0xffff0000u),
+                                 __uint_as_float(gr[c][1] << 16), __uint_as_float(gr[c][1] & 0xffff0000u));
+            } else {
+                gq = gr[c];
+            }
+            const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, gg[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float x = live ? (yy[j] - m) * r : 0.f;
                 xh[c * 4 + j] = x;
-                gv[c * 4 + j] = gg[j] * act_grad_from_xhat(x, p.act);
+                gv[c * 4 + j] = live ? gg[j] * act_grad_from_xhat(x, p.act) : 0.f;
+            }
+        }
+        // ---- second phases (their own round trip, taken by few launches / few waves): the border rows where they did not fit the
+        // first phase, and a second gradient contribution
+        if constexpr (FOLD && !BR_EARLY) {
+            if (wave_brow) {
+                load_border();
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float4 t = window(br[c], G16 ? 0.f : be[c]);
+                    const float tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gv[c * 4 + j] += (brow && live) ? tt[j] * act_grad_from_xhat(xh[c * 4 + j], p.act) : 0.f;
+                }
+            }
+        }
+        if (p.g2 != nullptr) {
+            float4 g2r[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) g2r[c] = reinterpret_cast<const float4*>(p.g2 + (nc0 + c) * HW)[ltid];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float tt[4] = {g2r[c].x, g2r[c].y, g2r[c].z, g2r[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[c * 4 + j] += live ? tt[j] * act_grad_from_xhat(xh[c * 4 + j], p.act) : 0.f;
             }
         }
     }
@@ -474,7 +543,7 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const float r = p.rstd[n * p.C + c0 + c], a1 = tot[c], a2 = tot[8 + c];
+        const float r = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rvl), c)), a1 = tot[c], a2 = tot[8 + c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) gv[c * 4 + j] = r * (gv[c * 4 + j] - a1 - xh[c * 4 + j] * a2);
     }
@@ -864,10 +933,23 @@ int ap_instnorm_bwd_split(const float* g1, int32_t g1_pad, const float* g2, cons
     const dim3 grid(items < slots ? items : slots);
     auto launch = [&](auto nt) {
         constexpr int NTH = decltype(nt)::value;
-        if (yb16 && g16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, true, true>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
-        else if (yb16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, true, false>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
-        else if (g16) hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, false, true>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, false, false>), grid, dim3(NTH), 0, (hipStream_t)stream, p);
+        auto go = [&](auto yt, auto gt_, auto ft) {
+            hipLaunchKernelGGL((instnorm_bwd_split_kernel<NTH, decltype(yt)::value, decltype(gt_)::value, decltype(ft)::value>), grid, dim3(NTH), 0,
+                               (hipStream_t)stream, p);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        const int sel = (yb16 ? 4 : 0) | (g16 ? 2 : 0) | (g1_pad == 1 ? 1 : 0);
+        switch (sel) {
+            case 0: go(F{}, F{}, F{}); break;
+            case 1: go(F{}, F{}, T{}); break;
+            case 2: go(F{}, T{}, F{}); break;
+            case 3: go(F{}, T{}, T{}); break;
+            case 4: go(T{}, F{}, F{}); break;
+            case 5: go(T{}, F{}, T{}); break;
+            case 6: go(T{}, T{}, F{}); break;
+            default: go(T{}, T{}, T{}); break;
+        }
     };
     if (small) launch(std::integral_constant<int, 256>{});
     else launch(std::integral_constant<int, 1024>{});

@@ -607,14 +607,23 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
     p.xs_relu = (flags & 2) ? 1 : 0;
     p.N = N; p.C = src->C; p.HW = H * W;
     const bool xb16 = (flags & 8) != 0;       // src->data holds bf16 values (a raw output of ap_conv2d_fwd_bf16out)
+    const int res_kind = p.res_xs ? 2 : (p.res ? 1 : 0);
+    auto launch = [&](auto vt, auto xt, auto rt, dim3 grid) {
+        hipLaunchKernelGGL((norm_split_kernel<decltype(vt)::value, decltype(xt)::value, decltype(rt)::value>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    };
+    auto by_res = [&](auto vt, auto xt, dim3 grid) {
+        if (res_kind == 0) launch(vt, xt, std::integral_constant<int, 0>{}, grid);
+        else if (res_kind == 1) launch(vt, xt, std::integral_constant<int, 1>{}, grid);
+        else launch(vt, xt, std::integral_constant<int, 2>{}, grid);
+    };
     if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
         dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);
-        if (xb16) hipLaunchKernelGGL((norm_split_kernel<4, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((norm_split_kernel<4, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (xb16) by_res(std::integral_constant<int, 4>{}, std::true_type{}, grid);
+        else by_res(std::integral_constant<int, 4>{}, std::false_type{}, grid);
     } else {
         dim3 grid((p.HW + 255) / 256, src->C / 8, N);
-        if (xb16) hipLaunchKernelGGL((norm_split_kernel<1, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL((norm_split_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+        if (xb16) by_res(std::integral_constant<int, 1>{}, std::true_type{}, grid);
+        else by_res(std::integral_constant<int, 1>{}, std::false_type{}, grid);
     }
     return check_launch("norm_split_kernel");
 }

@@ -44,7 +44,9 @@ struct NormSplitParams {
 
 // grid: (ceil(HW / (256 * VEC)), C/8, N); VEC pixels per thread (4 when HW % 4 == 0)
 // XB16: x holds bf16 values (a raw convolution output stored by ap_conv2d_fwd_bf16out): same element offsets, 2-byte elements
-template <int VEC, bool XB16 = false>
+// RES: 0 = no residual, 1 = fp32 residual (p.res, optionally with statistics), 2 = the residual as its split copy (p.res_xs) -- a
+// template parameter so that the load phase has no branch around its loads
+template <int VEC, bool XB16 = false, int RES = 0>
 __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p) {
     __shared__ float s_m[8], s_r[8];
     __shared__ int s_bad[8];
@@ -52,14 +54,68 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
     const int cg = blockIdx.y, n = blockIdx.z, C = p.C, HW = p.HW, CG = C >> 3;
     const int tid = threadIdx.x;
     const bool normed = p.partials != nullptr || p.mean != nullptr;
+    // ---- every global load of the thread is issued BEFORE the statistics are finalised (round 6): the block used to wait for the
+    // partial sums, reduce them, synchronise and only then ask for its data -- two dependent HBM round trips per block, and a
+    // workgroup lives for little more than that (profiles/r06_stream_readers.md).  The first partial of wave 0 goes out ahead of
+    // the data, so the in-order vmcnt wait of the reduction does not wait for the data as well.
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // (scalar: the branches on it do not touch EXEC)
+    // (no branch around it -- every thread loads 8 bytes from a clamped address, x itself when there are no partials: a load under
+    // a branch came back through a phi copy, and the copy was waited for on the spot)
+    const float2 part0 = *(p.partials != nullptr
+        ? reinterpret_cast<const float2*>(p.partials) + ((long long)n * C + cg * 8 + ((tid >> 3) & 7)) * p.tiles + ((tid & 7) < p.tiles ? (tid & 7) : 0)
+        : reinterpret_cast<const float2*>(p.x));
+    const int pix = (blockIdx.x * 256 + tid) * VEC;
+    const bool live = pix < HW;
+    // The load phase holds nothing but loads: raw words into registers, addresses clamped instead of branched on (a dead thread
+    // reads pixel 0 of its plane: a cache hit), conversions and arithmetic after the
+    // statistics.  With the bf16 -> fp32 shifts (or the residual statistics' loads) inside this loop the compiler waited for
+    // every channel's data before it asked for the next one's: 8 serial HBM round trips per thread (the 4.4 TB/s of round 5).
+    typedef unsigned XRaw __attribute__((ext_vector_type(XB16 ? (VEC == 4 ? 2 : 1) : VEC)));
+    typedef float RRaw __attribute__((ext_vector_type(VEC)));
+    XRaw xraw[8];
+    RRaw rraw[8];
+    constexpr bool has_res = RES == 1, has_res_xs = RES == 2;
+    {
+        const int lpix = live ? pix : 0;
+        const long long off0 = ((long long)n * C + cg * 8) * HW + lpix;
+        const unsigned char* xb = reinterpret_cast<const unsigned char*>(p.x);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if constexpr (XB16 && VEC == 1) {
+                xraw[c][0] = *reinterpret_cast<const unsigned short*>(xb + (off0 + (long long)c * HW) * 2);
+            } else {
+                xraw[c] = *reinterpret_cast<const XRaw*>(xb + (off0 + (long long)c * HW) * (XB16 ? 2 : 4));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if constexpr (has_res) rraw[c] = *reinterpret_cast<const RRaw*>(p.res + off0 + (long long)c * HW);
+            else rraw[c] = RRaw(0.f);
+        }
+    }
+    uint4 hq[VEC], lq[VEC];
+    if constexpr (has_res_xs) {
+        const uint4* rh = p.res_xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1) + (live ? pix : 0);
+        const uint4* rl = p.res_xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1) + (live ? pix : 0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { hq[j] = rh[j]; lq[j] = rl[j]; }
+    }
+    // statistics of the residual (a virtual feature): eight threads fetch them into LDS, everybody reads them after the barrier
+    __shared__ float s_rm[8], s_rr[8];
+    if (RES == 1 && wave == 1) {
+        const int c = tid & 7;
+        const bool rs = has_res && p.res_mean != nullptr;
+        const float m_ = rs ? p.res_mean[n * C + cg * 8 + c] : 0.f, r_ = rs ? p.res_rstd[n * C + cg * 8 + c] : 1.f;
+        if (tid < 72) { s_rm[c] = m_; s_rr[c] = r_; }
+    }
     if (p.partials != nullptr) {
         // wave 0: lane = (channel, 8-way tile split); fp64 sums of fp32 partials are exact, so the grouping
         // does not change the result
-        if (tid < 64) {
+        if (wave == 0) {
             const int c = tid >> 3, sub = tid & 7;
             const float2* pp = reinterpret_cast<const float2*>(p.partials) + ((long long)n * C + cg * 8 + c) * p.tiles;
-            double s = 0.0, q = 0.0;
-            for (int t = sub; t < p.tiles; t += 8) {
+            double s = sub < p.tiles ? (double)part0.x : 0.0, q = sub < p.tiles ? (double)part0.y : 0.0;
+            for (int t = sub + 8; t < p.tiles; t += 8) {
                 const float2 v = pp[t];
                 s += (double)v.x;
                 q += (double)v.y;
@@ -114,76 +170,51 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
             p.mean_out[n * C + cg * 8 + tid] = s_m[tid];
             p.rstd_out[n * C + cg * 8 + tid] = s_r[tid];
         }
-    } else if (p.mean != nullptr) {
-        if (tid < 8) {
+    } else {
+        if (p.mean != nullptr && tid < 8) {
             s_m[tid] = p.mean[n * C + cg * 8 + tid];
             s_r[tid] = p.rstd[n * C + cg * 8 + tid];
         }
         __syncthreads();
     }
+    // ---- now the data: raw words -> fp32
+    float v[8][VEC], rv[8][VEC];
+    float rm[8], rr[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        rm[c] = RES == 1 ? s_rm[c] : 0.f;
+        rr[c] = RES == 1 ? s_rr[c] : 1.f;
+        if constexpr (XB16 && VEC == 4) {          // a bf16 is the upper half of the fp32 of the same value
+            v[c][0] = __uint_as_float(xraw[c][0] << 16); v[c][1] = __uint_as_float(xraw[c][0] & 0xffff0000u);
+            v[c][2] = __uint_as_float(xraw[c][1] << 16); v[c][3] = __uint_as_float(xraw[c][1] & 0xffff0000u);
+        } else if constexpr (XB16) {
+            v[c][0] = __uint_as_float(xraw[c][0] << 16);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[c][j] = __uint_as_float(xraw[c][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) rv[c][j] = rraw[c][j];
+    }
+    if constexpr (has_res_xs) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const unsigned hw_[4] = {hq[j].x, hq[j].y, hq[j].z, hq[j].w}, lw_[4] = {lq[j].x, lq[j].y, lq[j].z, lq[j].w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const unsigned hb = (c & 1) ? (hw_[c >> 1] & 0xffff0000u) : (hw_[c >> 1] << 16);
+                const unsigned lb = (c & 1) ? (lw_[c >> 1] & 0xffff0000u) : (lw_[c >> 1] << 16);
+                rv[c][j] = __uint_as_float(hb) + __uint_as_float(lb);
+            }
+        }
+    }
+    if (VEC == 1 && !live) return;
     uint4* ph = nullptr;
     uint4* pl = nullptr;
     if (p.xs != nullptr) {
         ph = p.xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1);
         pl = p.xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1);
         if (blockIdx.x == 0 && tid == 0) ph[HW] = pl[HW] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    const int pix = (blockIdx.x * 256 + tid) * VEC;
-    const bool live = pix < HW;
-    if (VEC == 1 && !live) return;
-    // Every load of the thread is issued before the first store: x, res and y are not declared disjoint, so the compiler
-    // keeps a load behind any earlier store -- written channel by channel this loop was 16 serial memory round trips.
-    float v[8][VEC], rv[8][VEC];
-    float rm[8], rr[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) v[c][j] = rv[c][j] = 0.f;
-        rm[c] = 0.f; rr[c] = 1.f;
-        if (!live) continue;
-        const long long off = ((long long)n * C + cg * 8 + c) * HW + pix;
-        if constexpr (XB16) {
-            const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + off;
-            if constexpr (VEC == 4) {
-                const uint2 t = *reinterpret_cast<const uint2*>(xb);           // a bf16 is the upper half of the fp32 of the same value
-                v[c][0] = __uint_as_float(t.x << 16); v[c][1] = __uint_as_float(t.x & 0xffff0000u);
-                v[c][2] = __uint_as_float(t.y << 16); v[c][3] = __uint_as_float(t.y & 0xffff0000u);
-            } else {
-                v[c][0] = __uint_as_float((unsigned)xb[0] << 16);
-            }
-        } else if constexpr (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p.x + off);
-            v[c][0] = t.x; v[c][1] = t.y; v[c][2] = t.z; v[c][3] = t.w;
-        } else {
-            v[c][0] = p.x[off];
-        }
-        if (p.res != nullptr) {
-            if (p.res_mean != nullptr) { rm[c] = p.res_mean[n * C + cg * 8 + c]; rr[c] = p.res_rstd[n * C + cg * 8 + c]; }
-            if constexpr (VEC == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(p.res + off);
-                rv[c][0] = t.x; rv[c][1] = t.y; rv[c][2] = t.z; rv[c][3] = t.w;
-            } else {
-                rv[c][0] = p.res[off];
-            }
-        }
-    }
-    if (p.res_xs != nullptr && live) {
-        const uint4* rh = p.res_xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1) + pix;
-        const uint4* rl = p.res_xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1) + pix;
-        uint4 hq[VEC], lq[VEC];
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { hq[j] = rh[j]; lq[j] = rl[j]; }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const unsigned hw_[4] = {hq[j].x, hq[j].y, hq[j].z, hq[j].w}, lw_[4] = {lq[j].x, lq[j].y, lq[j].z, lq[j].w};
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                // a bf16 is the upper half of the fp32 with the same value
-                const unsigned hb = (c & 1) ? (hw_[c >> 1] & 0xffff0000u) : (hw_[c >> 1] << 16);
-                const unsigned lb = (c & 1) ? (lw_[c >> 1] & 0xffff0000u) : (lw_[c >> 1] << 16);
-                rv[c][j] = __uint_as_float(hb) + __uint_as_float(lb);
-            }
-        }
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -194,7 +225,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
         for (int j = 0; j < VEC; ++j) {
             float t = normed ? (v[c][j] - m) * r : v[c][j];
             t = p.act == 1 ? fmaxf(t, 0.f) : (p.act == 2 ? (t > 0.f ? t : 0.2f * t) : t);
-            if (p.res != nullptr || p.res_xs != nullptr) t += (rv[c][j] - rm[c]) * rr[c];
+            if (has_res || has_res_xs) t += (rv[c][j] - rm[c]) * rr[c];
             v[c][j] = t;
         }
         if (p.y != nullptr) {

@@ -31,6 +31,8 @@ extern "C" hipError_t launch_count_diff(const void* a, const void* ref, size_t n
 extern "C" int ap_warp_concat_fwd_ex(const float* x, const float* x_mean, const float* x_rstd, int32_t x_act, const float* motion, const float* flow,
                                      const float* ifmask, float* out, void* xs, int32_t N, int32_t C, int32_t H, int32_t W, int32_t S,
                                      float flow_scale, int32_t flags, void* stream);
+#define DECL_K(n) extern "C" hipError_t launch_victim_k##n(const float*, const float*, const float*, const float*, const float*, const float*, float*, int, int, int, int, int, float, hipStream_t);
+DECL_K(0) DECL_K(1) DECL_K(2) DECL_K(3) DECL_K(4) DECL_K(5) DECL_K(6)
 namespace apamd {
 static char g_err[512];
 char* last_error_buf() { return g_err; }
@@ -132,14 +134,26 @@ int main(int argc, char** argv) {
     int bad_cells = 0;
     printf("\n| victim level | arrangement | wrong victim launches | of | wrong 32-bit words | lanes (index mod 64) with wrong words | ms: aggressor batches / victim batches / overlap |\n|---|---|---|---|---|---|---|\n");
     const char* arrangements[] = {"shared", "control", "masked:half", "masked:xcd", "masked:cu", "masked:same"};
+    // victims: id 3 = the product's translation unit; 10 + k = its kernel copied into victim_product.hip with -DKNOB=k (pieces
+    // removed step by step); 0 / 1 / 2 = the hand-reduced kernel of victim.hip
     auto run_victim = [&](int level, float* out, hipStream_t st) -> hipError_t {
-        if (level < 3) return launch_victim(level, dx, dm, dr, dmo, df, dk, out, N, C, H, W, S, 0.25f, st);
-        return ap_warp_concat_fwd_ex(dx, dm, dr, 1, dmo, df, dk, out, nullptr, N, C, H, W, S, 0.25f, 0, (void*)st) == 0 ? hipSuccess : hipErrorUnknown;
+        if (level < 3 || level >= 20) return launch_victim(level, dx, dm, dr, dmo, df, dk, out, N, C, H, W, S, 0.25f, st);
+        if (level == 3) return ap_warp_concat_fwd_ex(dx, dm, dr, 1, dmo, df, dk, out, nullptr, N, C, H, W, S, 0.25f, 0, (void*)st) == 0 ? hipSuccess : hipErrorUnknown;
+        decltype(&launch_victim_k0) ks[] = {launch_victim_k0, launch_victim_k1, launch_victim_k2, launch_victim_k3, launch_victim_k4, launch_victim_k5, launch_victim_k6};
+        return ks[level - 10](dx, dm, dr, dmo, df, dk, out, N, C, H, W, S, 0.25f, st);
+    };
+    auto victim_name = [](int level) -> std::string {
+        if (level == 3) return "product warp.hip (its own translation unit)";
+        if (level == 20) return "SGPR-pair lane mask alone: v_cmp_e64 -> gather chain -> v_cndmask_e64";
+        if (level == 21) return "SGPR-pair lane mask alone: v_cmp_e64 -> v_cndmask_e64 back to back";
+        if (level >= 10) return "product kernel copy, KNOB=" + std::to_string(level - 10);
+        return "hand-reduced, level " + std::to_string(level);
     };
     hipEvent_t ev[4];
     for (auto& e : ev) CK(hipEventCreate(&e));
-    for (int level = 3; level >= 0; --level) {
-        const size_t nout = victim_out_floats(level == 3 ? 0 : level, N, C, H, W);
+    const int order[] = {3, 10, 13, 16, 20, 21, 0, 1, 2};
+    for (int level : order) {
+        const size_t nout = victim_out_floats((level >= 3 && level < 20) ? 0 : level, N, C, H, W);
         float* dref;
         CK(hipMalloc(&dref, nout * 4));
         std::vector<float*> douts(K);
@@ -152,9 +166,10 @@ int main(int argc, char** argv) {
         CK(launch_count_diff(douts[0], dref, nout, dcount, dhist, plainA));
         unsigned long long self = 0;
         CK(hipMemcpy(&self, dcount, 8, hipMemcpyDeviceToHost));
-        if (self) { printf("victim level %d does not agree with itself when run alone (%llu words)\n", level, self); return 98; }
+        if (self) { printf("victim %s does not agree with itself when run alone (%llu words)\n", victim_name(level).c_str(), self); return 98; }
         for (const char* arr : arrangements) {
             const std::string a(arr);
+            if (level != 3 && level != 16 && a.rfind("masked:", 0) == 0) continue;       // the CU-mask arrangements: the product victim only
             hipStream_t sv = plainA, sa = plainB;
             const bool masked = a.rfind("masked:", 0) == 0;
             if (masked) {
@@ -202,7 +217,7 @@ int main(int argc, char** argv) {
                 if (on && lo < 0) lo = l;
                 if (!on && lo >= 0) { lanes += (lanes.empty() ? "" : ", ") + std::to_string(lo) + "-" + std::to_string(l - 1); lo = -1; }
             }
-            printf("| %s | %s | %d | %d | %llu | %s | %.1f / %.1f / %.1f |\n", level == 3 ? "3 (product warp.hip)" : std::to_string(level).c_str(), arr, wrong, total, words,
+            printf("| %s | %s | %d | %d | %llu | %s | %.1f / %.1f / %.1f |\n", victim_name(level).c_str(), arr, wrong, total, words,
                    lanes.empty() ? "-" : lanes.c_str(), aggr_ms, vict_ms, overlap_ms);
             fflush(stdout);
             if (wrong && a != "control" && a != "masked:same") ++bad_cells;

@@ -132,11 +132,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+
+// ---- LEVEL 20 / 21: the suspected core of the hazard alone.  What separates the failing kernels from the clean ones on BOTH sides is
+// VOP3 instructions that take a lane mask from an SGPR pair (v_cndmask_b32_e64 ..., s[n:n+1]); the wrong lanes are 16-31 and 48-63,
+// i.e. the upper halves of the pair's two dwords.  Here a lane mask is made by v_cmp_lt_f32_e64 into an SGPR pair, kept there
+// (level 20: across a chain of dependent gathers, as `keep` is in the product kernel; level 21: used at once, 64 times in a row)
+// and consumed by v_cndmask_b32_e64.  in: 2^19 floats in [0, 1); out: 2^21 floats.
+template <int LEVEL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void mask_victim_kernel(const float* __restrict__ in, float* __restrict__ out, int iters) {
+    const int tid = blockIdx.x * 256 + threadIdx.x, n = 1 << 19;
+    const float mk = in[tid & (n - 1)];
+    if (LEVEL == 20) {
+        unsigned long long m;
+        asm volatile("v_cmp_lt_f32_e64 %0, 0.5, %1" : "=s"(m) : "v"(mk));
+        float acc = 0.f;
+        int idx = tid;
+        for (int it = 0; it < iters; ++it) {
+            idx = (idx * 1103515245 + 12345) & (n - 1);
+            acc += in[idx];
+        }
+        float r;
+        asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(-1.0f), "v"(acc), "s"(m));
+        out[tid] = r;
+    } else {
+        float r = 0.f, thr = 0.25f;
+        for (int it = 0; it < 64; ++it) {
+            unsigned long long m;
+            float t;
+            asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(thr), "v"(mk));
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(t) : "v"(-1.0f), "v"(thr), "s"(m));
+            r += t;
+            thr += 0.0078125f;
+        }
+        out[tid] = r;
+    }
+}
+
 extern "C" size_t victim_out_floats(int level, int N, int C, int H, int W) {
+    if (level >= 20) return (size_t)1 << 21;
     return (size_t)N * H * W * (level == 0 ? 2 * C : (level == 1 ? C : (C / 8) * 10));
 }
 extern "C" hipError_t launch_victim(int level, const float* x, const float* mean, const float* rstd, const float* motion, const float* flow,
                                     const float* ifmask, float* out, int N, int C, int H, int W, int S, float flow_scale, hipStream_t stream) {
+    if (level == 20) { hipLaunchKernelGGL(mask_victim_kernel<20>, dim3(8192), dim3(256), 0, stream, ifmask, out, 12); return hipGetLastError(); }
+    if (level == 21) { hipLaunchKernelGGL(mask_victim_kernel<21>, dim3(8192), dim3(256), 0, stream, ifmask, out, 0); return hipGetLastError(); }
     dim3 grid(H * W / 256, C / 8, N);
     if (level == 0) hipLaunchKernelGGL(victim_kernel<0>, grid, dim3(256), 0, stream, x, mean, rstd, motion, flow, ifmask, out, C, H, W, S, flow_scale);
     else if (level == 1) hipLaunchKernelGGL(victim_kernel<1>, grid, dim3(256), 0, stream, x, mean, rstd, motion, flow, ifmask, out, C, H, W, S, flow_scale);
