@@ -395,6 +395,14 @@ class GraphedFrozen(nn.Module):
         self.pick = pick
         self._graphs = {}
         self._in_flight = set()       # shapes whose graph ran forward and has not yet run backward
+        self._warned = False
+
+    def new_step(self):
+        """Step boundary (the model calls it from set_input): a grad-enabled forward whose backward never reached the input -- an
+        exception in between, a loss term that was dropped, an evaluation pass under grad -- would otherwise keep its shape marked
+        for ever, and every later call of that shape would silently run eagerly.  Nothing of the previous step's graph
+        can still be needed once the next batch is set."""
+        self._in_flight.clear()
 
     def _eager(self, x):
         out = self.net(x)
@@ -406,6 +414,10 @@ class GraphedFrozen(nn.Module):
             return self._eager(x)
         key = (tuple(x.shape), x.dtype)
         if key in self._in_flight:
+            if not self._warned:
+                self._warned = True
+                print('[aux] GraphedFrozen(%s): a second grad-requiring call of shape %s before the first one\'s backward runs eagerly '
+                      '(new_step() at the step boundary clears forwards whose backward never ran)' % (type(self.net).__name__, key[0]))
             return self._eager(x)
         g = self._graphs.get(key)
         if g is None:

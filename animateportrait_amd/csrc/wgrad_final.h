@@ -26,7 +26,8 @@ struct WgradFinalParams {
 constexpr int kFinalStrips = 2;          // 1 x 4 strips per lane and staged tile: pixel tile = 16 kFinalStrips x 64
 
 // grid: (P, C), 256 threads
-static __global__ __launch_bounds__(256) void wgrad_final_kernel(const WgradFinalParams p) {
+template <bool WVEC>
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_final_kernel(const WgradFinalParams p) {
     constexpr int K = 7, R = 3, NS = kFinalStrips, TH = 16 * NS, TW = 64, LPAD = 1, IH = TH + K - 1, IWS = 72, PLANE = IH * IWS, T = K * K;
     constexpr int NE = (PLANE + 255) / 256;
     __shared__ __attribute__((aligned(16))) float xbuf[2][PLANE];
@@ -53,10 +54,30 @@ static __global__ __launch_bounds__(256) void wgrad_final_kernel(const WgradFina
             lyx[k] = (ly << 8) | (e - ly * IWS);
         }
         float m = 0.f, rs = 1.f;
+        // The gradient strips of a tile are fetched WITH its window, one tile ahead (round 6).  They used to be loaded inside the
+        // strip loop and consumed at once: two exposed global round trips per tile, ~2 us of a tile's ~2.2 us -- the kernel ran
+        // at 1.03 TB/s (553 us for 0.57 GB, profiles/r05_train_hbm_per_kernel.md) with its vector ALUs idle.
+        // (raw words only in the prefetch: a select on the loaded value is a use, and the compiler waits for the load right there)
+        float4 gq[NS];
+        float g1[NS][4];
+        auto strip_ok = [&](int t, int s, int j) {
+            const int r = t % per_img;
+            return (r / p.tiles_x) * TH + s * 16 + ty < H && (r % p.tiles_x) * TW + tx * 4 + j < W;
+        };
         // fetch the window of tile t into registers (normalisation applied at commit: m / rs belong to the tile's image)
         auto issue = [&](int t) {
             const int n = t / per_img, r = t - n * per_img;
             const int oy0 = (r / p.tiles_x) * TH, ox0 = (r % p.tiles_x) * TW;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int oy = oy0 + s * 16 + ty, ox = ox0 + tx * 4;
+                if constexpr (WVEC) {                               // whole 16-byte groups (W % 4 == 0); a dead lane reads pixel 0
+                    gq[s] = *reinterpret_cast<const float4*>(p.g + (long long)n * HW + ((oy < H && ox + 3 < W) ? oy * W + ox : 0));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g1[s][j] = p.g[(long long)n * HW + ((oy < H && ox + j < W) ? oy * W + ox + j : 0)];
+                }
+            }
             const float* base = p.src.data + ((long long)n * p.C + ci) * HW;
             if (p.src.mean != nullptr) { m = p.src.mean[n * p.C + ci]; rs = p.src.rstd[n * p.C + ci]; }
 #pragma unroll
@@ -89,22 +110,18 @@ static __global__ __launch_bounds__(256) void wgrad_final_kernel(const WgradFina
         for (int t = t0; t < t1; ++t) {
             const int cur = (t - t0) & 1;
             const bool more = t + 1 < t1;
-            if (more) issue(t + 1);
-            const int n = t / per_img, r = t - n * per_img;
-#pragma unroll 1
-            for (int s = 0; s < NS; ++s) {                       // this lane's NS gradient strips of the tile
-            const int oy = (r / p.tiles_x) * TH + s * 16 + ty, ox = (r % p.tiles_x) * TW + tx * 4;
-            float gv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (oy < H) {
-                const float* gp = p.g + (long long)n * HW + oy * W + ox;
-                if (ox + 3 < W && (W & 3) == 0) {
-                    const float4 q = *reinterpret_cast<const float4*>(gp);
-                    gv[0] = q.x; gv[1] = q.y; gv[2] = q.z; gv[3] = q.w;
-                } else {
+            float gc[NS][4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gv[j] = ox + j < W ? gp[j] : 0.f;
-                }
+            for (int s = 0; s < NS; ++s) {
+                const float raw[4] = {WVEC ? gq[s].x : g1[s][0], WVEC ? gq[s].y : g1[s][1], WVEC ? gq[s].z : g1[s][2], WVEC ? gq[s].w : g1[s][3]};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gc[s][j] = strip_ok(t, s, WVEC ? 3 : j) ? raw[j] : 0.f;
             }
+            if (more) issue(t + 1);
+            static_assert(NS == 2, "the strip's gradient is picked with a select");
+#pragma unroll 1
+            for (int s = 0; s < NS; ++s) {                       // this lane's NS gradient strips of the tile (rolled: one 84-register window)
+            const float gv[4] = {s ? gc[1][0] : gc[0][0], s ? gc[1][1] : gc[0][1], s ? gc[1][2] : gc[0][2], s ? gc[1][3] : gc[0][3]};
             // window rows: whole 16-byte lanes, all in flight before one wait (see conv_direct.h)
             typedef float f4v __attribute__((ext_vector_type(4)));
             f4v q[K][3];

@@ -19,6 +19,12 @@
 
 namespace apamd {
 
+// A/B switches are integers on both sides of the boundary: APAMD_X=0 means "off", as ops.py reads it
+static int env_int(const char* name, int dflt) {
+    const char* s = getenv(name);
+    return s ? atoi(s) : dflt;
+}
+
 struct WgradKernel {
     int S, K, M_TILE, Q_TILE, PR;
     const void* fn;
@@ -304,7 +310,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
         return check_launch("split_transpose_kernel");
     }
-    if (any_b16 && !(!getenv("APAMD_NO_SPLIT_ROWS") && (W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
+    if (any_b16 && !(!env_int("APAMD_NO_SPLIT_ROWS", 0) && (W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
         return fail(AP_ERR_UNSUPPORTED, "split_transpose: a bf16 source needs the padded-row form (pad 1, W in {32, 64, 128, 256})");
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
     if (nseg == 1 && pad == 0 && s2d_c == 0 && X8 * 8 == W && !getenv("APAMD_NO_SPLIT_VEC")) {
@@ -320,7 +326,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         hipLaunchKernelGGL(split_transpose_vec_kernel, dim3((Hp * X8 + 31) / 32, Cp / 64, N), dim3(256), lds, stream, p);
         return check_launch("split_transpose_vec_kernel");
     }
-    const bool rows_ok = !getenv("APAMD_NO_SPLIT_ROWS") && (W == 64 || W == 128 || W == 256 || (W == 32 && s2d_c == 0));
+    const bool rows_ok = !env_int("APAMD_NO_SPLIT_ROWS", 0) && (W == 64 || W == 128 || W == 256 || (W == 32 && s2d_c == 0));
     if (rows_ok && s2d_c == 0 && pad == 1) {
         // padded rows, 16-byte loads (split_transpose_pad_kernel)
         const int R = 256 / W;
@@ -366,7 +372,7 @@ static int launch_xs_transpose(const void* const* xs, const int* seg_c, int nseg
 
 // can the shifted operand of this plan come from the forward split copies the descriptor carries?
 static bool wgrad_xs_route(const ap_wgrad_desc* d, const WgradPlan& pl) {
-    if (!pl.bf3 || pl.rows || getenv("APAMD_NO_XS_WGRAD")) return false;
+    if (!pl.bf3 || pl.rows || env_int("APAMD_NO_XS_WGRAD", 0)) return false;
     if (d->precision != AP_PRECISION_BF16 && d->xs_parts != 2) return false;      // a split-bf16 product reads the tail planes
     if (d->xs_parts != 1 && d->xs_parts != 2) return false;
     if (pl.s2d) return (d->src_xs_s2d != nullptr || d->src_xs[0] != nullptr) && d->nsrc == 1 && pl.Cin % 8 == 0;
@@ -394,7 +400,7 @@ using namespace apamd;
 
 // ---- both operands straight from the convolutions' split copies (wgrad_xs.h): no operand preparation at all
 static bool wgrad_xs_direct_ok(const ap_wgrad_desc* d, const WgradPlan& pl) {
-    if (!pl.bf3 || pl.rows || getenv("APAMD_NO_XS_DIRECT")) return false;
+    if (!pl.bf3 || pl.rows || env_int("APAMD_NO_XS_DIRECT", 0)) return false;
     if (d->M % 8 != 0) return false;
     if (pl.s2d) {
         // the space-to-depth form of a stride-2 layer: the 2 x 2 layer over the forward pass's space-to-depth copy (split-bf16 only)
@@ -548,7 +554,8 @@ int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H,
     int P;
     final_split(N, src->C, H, W, p.tiles_x, p.tiles_y, p.tiles_per_block, P);
     p.partial = workspace;
-    hipLaunchKernelGGL(wgrad_final_kernel, dim3(P, src->C), dim3(256), 0, stream, p);
+    if ((W & 3) == 0) hipLaunchKernelGGL(wgrad_final_kernel<true>, dim3(P, src->C), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(wgrad_final_kernel<false>, dim3(P, src->C), dim3(256), 0, stream, p);
     int rc = check_launch("wgrad_final_kernel");
     if (rc) return rc;
     const long long n = (long long)src->C * 49;

@@ -149,40 +149,49 @@ __global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarro
         s_dst[k] = on ? rr * WP + 1 + x4 : -1;
         s_edge[k] = (x4 == 0 ? 1 : 0) | (x4 == p.W - 4 ? 2 : 0);
     }
+    // fetch = raw loads only, from clamped addresses (round 6): with the normalisation inside the row test and the gradient values
+    // behind a select, every one of the ~8 loads of an iteration was waited for before the next was issued -- eight serial round
+    // trips against the 128 FMAs they were meant to hide under (118 us per launch at 1.07 TB/s, profiles/r05_train_hbm_per_kernel.md).
+    // The row test, InstanceNorm, activation and the zeroing of inactive values happen in stage() / at the copy of the gradient.
+    float mraw[CIN], rraw[CIN];
     auto fetch = [&](int rowb) __attribute__((always_inline)) {
         const int n = rowb / p.GH, oy0 = rowb - n * p.GH;
         const float* base = p.src.data + (long long)n * CIN * HW + 2 * oy0 * p.W;
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
-            sv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int iy = oy0 * 2 - 1 + s_j[k];
-            if (iy >= 0 && iy < p.H) {
-                float4 v = *reinterpret_cast<const float4*>(base + s_src[k]);
-                if (p.src.mean != nullptr) {
-                    const float m = p.src.mean[n * CIN + s_ci[k]], r = p.src.rstd[n * CIN + s_ci[k]];
-                    v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
-                }
-                v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
-                v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
-                sv[k] = v;
-            }
+            sv[k] = *reinterpret_cast<const float4*>((iy >= 0 && iy < p.H) ? base + s_src[k] : p.src.data);
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+            mraw[ci] = p.src.mean != nullptr ? p.src.mean[n * CIN + ci] : 0.f;
+            rraw[ci] = p.src.mean != nullptr ? p.src.rstd[n * CIN + ci] : 1.f;
         }
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
             const int row = rowb + u * p.rpi + ty;
 #pragma unroll
             for (int c = 0; c < COB; ++c)
-                gn[u][c] = (row < r1 && co0 + c < p.M)
-                               ? p.g[((long long)n * p.M + co0 + c) * GHW + (oy0 + u * p.rpi + ty) * p.GW + tx] : 0.f;
+                gn[u][c] = p.g[(row < r1 && co0 + c < p.M) ? ((long long)n * p.M + co0 + c) * GHW + (oy0 + u * p.rpi + ty) * p.GW + tx : 0];
         }
     };
-    auto stage = [&](int buf) __attribute__((always_inline)) {
+    auto stage = [&](int buf, int rowb) __attribute__((always_inline)) {
         float* xb = xs + buf * BUF;
+        const int oy0 = rowb % p.GH;
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) {
             if (s_dst[k] >= 0) {
+                const int iy = oy0 * 2 - 1 + s_j[k];
+                const bool ok = iy >= 0 && iy < p.H;
+                float m = mraw[0], r = rraw[0];
+#pragma unroll
+                for (int ci = 1; ci < CIN; ++ci) { m = s_ci[k] == ci ? mraw[ci] : m; r = s_ci[k] == ci ? rraw[ci] : r; }
+                float4 v = sv[k];
+                v.x = (v.x - m) * r; v.y = (v.y - m) * r; v.z = (v.z - m) * r; v.w = (v.w - m) * r;
+                v.x = v.x > 0.f ? v.x : slope * v.x; v.y = v.y > 0.f ? v.y : slope * v.y;
+                v.z = v.z > 0.f ? v.z : slope * v.z; v.w = v.w > 0.f ? v.w : slope * v.w;
                 float* d = xb + s_dst[k];                          // staged column = image column + 1
-                d[0] = sv[k].x; d[1] = sv[k].y; d[2] = sv[k].z; d[3] = sv[k].w;
+                d[0] = ok ? v.x : 0.f; d[1] = ok ? v.y : 0.f; d[2] = ok ? v.z : 0.f; d[3] = ok ? v.w : 0.f;
                 if (s_edge[k] & 1) d[-1] = 0.f;
                 if (s_edge[k] & 2) d[4] = 0.f;
             }
@@ -191,7 +200,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarro
     int buf = 0;
     if (r0 < r1) {
         fetch(r0);
-        stage(0);
+        stage(0, r0);
     }
     __syncthreads();
     for (int rowb = r0; rowb < r1; rowb += RPI, buf ^= 1) {
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarro
 #pragma unroll
         for (int u = 0; u < PPT; ++u)
 #pragma unroll
-            for (int c = 0; c < COB; ++c) gv[u][c] = gn[u][c];
+            for (int c = 0; c < COB; ++c) gv[u][c] = (rowb + u * p.rpi + ty < r1 && co0 + c < p.M) ? gn[u][c] : 0.f;
         const bool more = rowb + RPI < r1;
         if (more) fetch(rowb + RPI);
         const float* xb = xs + buf * BUF;
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(256) void wgrad_narrow_s2k4_kernel(const WgradNarro
 #pragma unroll
                         for (int c = 0; c < COB; ++c) acc[c][(ci * K + ky) * K + kx] += gv[u][c] * xw[kx];
                 }
-        if (more) stage(buf ^ 1);
+        if (more) stage(buf ^ 1, rowb + RPI);
         __syncthreads();                                           // next buffer written; this one free for the one after
     }
     // block sums (fixed order: lanes by halving exchanges, then the four waves)

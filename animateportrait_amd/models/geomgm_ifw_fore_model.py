@@ -182,16 +182,27 @@ class GeomGMIFWForeModel(BaseModel):
             self.real_B1, self.real_B2 = dev('B1'), dev('B2')
             if self.opt.coh_use_more:
                 self.real_B3, self.real_B4 = dev('B3'), dev('B4')
+        # step boundary: graphed aux nets forget forwards of the previous step whose backward never ran (aux_nets.GraphedFrozen)
+        for a in self.aux.values():
+            for m in ((a.modules() if isinstance(a, torch.nn.Module) else ()) if a is not None else ()):
+                if hasattr(m, 'new_step'):
+                    m.new_step()
         if self.aux['netF'] is not None:                                         # :503-505
             nf = self.aux['netF']                 # the frozen FlowUnet module itself; pre / post stages run on the device
-            # the reference calls flow_network_warp twice (photo -> target, photo -> second target); the frozen net is
-            # sample-independent (eval mode), so both calls run as ONE 2B batch: half the launches on its small maps
-            b = self.real_A.shape[0]
             lm_a = self.real_A_lm_68[:, :68]
-            flow2, mask2 = losses.flow_network_warp(nf, self.real_A, torch.cat([lm_a, lm_a], 0),
-                                                    torch.cat([self.target_B_lm_68[:, :68], self.target_B2_lm_68[:, :68]], 0))
-            self.iw_flow, self.iw_flow2 = flow2[:b].contiguous(), flow2[b:].contiguous()
-            self.real_A_if_mask, self.real_A_if_mask2 = mask2[:b].contiguous(), mask2[b:].contiguous()
+            b = self.real_A.shape[0]
+            if getattr(nf, 'training', False):
+                # a net in train mode (BatchNorm batch statistics, dropout) is not sample-independent: two B-sized calls, as the
+                # reference makes them (the reference itself calls netF.eval(), :387; attach_flow_network does too -- ADVICE r5)
+                self.iw_flow, self.real_A_if_mask = losses.flow_network_warp(nf, self.real_A, lm_a, self.target_B_lm_68[:, :68])
+                self.iw_flow2, self.real_A_if_mask2 = losses.flow_network_warp(nf, self.real_A, lm_a, self.target_B2_lm_68[:, :68])
+            else:
+                # the reference calls flow_network_warp twice (photo -> target, photo -> second target); the frozen net is
+                # sample-independent (eval mode), so both calls run as ONE 2B batch: half the launches on its small maps
+                flow2, mask2 = losses.flow_network_warp(nf, self.real_A, torch.cat([lm_a, lm_a], 0),
+                                                        torch.cat([self.target_B_lm_68[:, :68], self.target_B2_lm_68[:, :68]], 0))
+                self.iw_flow, self.iw_flow2 = flow2[:b].contiguous(), flow2[b:].contiguous()
+                self.real_A_if_mask, self.real_A_if_mask2 = mask2[:b].contiguous(), mask2[b:].contiguous()
         else:
             self._notice('netF', 'no intrinsic-flow network: iw_flow / if_mask are read from the batch')
             self.iw_flow, self.real_A_if_mask = dev('iw_flow'), dev('if_mask')

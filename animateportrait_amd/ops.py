@@ -1006,8 +1006,18 @@ def wgrad_xs_ok(k, stride, pad, pad_mode, g_shape, srcs, precision=None):
     """Is this weight gradient served with both operands as split copies (ap_conv2d_wgrad_xs)?  Needs the sources' forward copies."""
     if not XS_DIRECT or g_shape[1] <= 4:
         return False
-    d = _wgrad_desc(k, stride, pad, pad_mode, g_shape, None, srcs, precision)
-    return C.lib().ap_conv2d_wgrad_xs_ok(ctypes.byref(d)) == 1
+    # the answer depends on the layer geometry and on WHICH forward copies the sources carry, not on their contents: cached, so
+    # that the backward pass of a launch-bound train step does not rebuild a descriptor and re-plan per layer and step (ADVICE r5)
+    key = (k, stride, pad, pad_mode, tuple(g_shape), precision,
+           tuple((tuple(f.data.shape), f.xs is not None, f.s2d is not None, f.is_split_only) for f in srcs))
+    hit = _WGRAD_XS_OK.get(key)
+    if hit is None:
+        d = _wgrad_desc(k, stride, pad, pad_mode, g_shape, None, srcs, precision)
+        hit = _WGRAD_XS_OK[key] = C.lib().ap_conv2d_wgrad_xs_ok(ctypes.byref(d)) == 1
+    return hit
+
+
+_WGRAD_XS_OK = {}
 
 
 def wgrad_gt_dims(k, stride, pad, pad_mode, g_shape, srcs, precision=None):
@@ -1077,8 +1087,15 @@ def _split_contribs(contribs):
     return plain[0], 0, (plain[1] if len(plain) > 1 else None)
 
 
+def _as_fp32_grad(t):
+    """A gradient stored as bf16 (conv2d_dgrad_strip(out_bf16=...)) has ONE reader that understands it, ap_instnorm_bwd_split.
+    Every fp32 kernel that is handed such a tensor would read a half-sized buffer as floats: convert (once) instead."""
+    return t.float() if (t is not None and t.dtype == torch.bfloat16) else t
+
+
 def fold_add(g1, pad, g2):
     """out = fold(g1) + g2 (reflection-pad backward fused)."""
+    g1, g2 = _as_fp32_grad(g1), _as_fp32_grad(g2)
     n, c, hp, wp = g1.shape
     h, w = hp - 2 * pad, wp - 2 * pad
     out = torch.empty((n, c, h, w), dtype=torch.float32, device=g1.device)
@@ -1089,6 +1106,7 @@ def fold_add(g1, pad, g2):
 def instnorm_bwd(contribs, f):
     """Gradient w.r.t. the raw conv output y of the virtual feature f = act(IN(y))."""
     g1, pad, g2 = _split_contribs(contribs)
+    g1, g2 = _as_fp32_grad(g1), _as_fp32_grad(g2)
     n, c, h, w = f.data.shape
     dy = torch.empty_like(f.data)
     ws = torch.empty(n * c * 2, dtype=torch.float32, device=dy.device)
@@ -1141,6 +1159,7 @@ def instnorm_bwd_split(red, f, gt_dims=None, want_xs=True, want_strip=False, wan
 def act_bwd(contribs, out, act):
     """Gradient w.r.t. the pre-activation of a plain layer output ``out = act(pre)``."""
     g1, pad, g2 = _split_contribs(contribs)
+    g1, g2 = _as_fp32_grad(g1), _as_fp32_grad(g2)
     if act == ACT_NONE and pad == 0 and g2 is None:
         return g1
     n, c, h, w = out.shape
