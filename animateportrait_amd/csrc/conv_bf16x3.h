@@ -735,8 +735,10 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 // 2 store instructions per 32 x 32 tile where the 4-pixel form below needs 4.  The epilogue is bound by the number
                 // of store instructions a CU can retire (~115 cycles each whatever their width: MI355X_MICROARCH.md "store tail",
                 // profiles/r05_dominant_cycle_account.md), so the 8-byte form was no faster than the fp32 output it replaced.
-                wide16 = p.osx == 1 && ox_off == 0 && ox0 + 32 <= p.OW &&
-                         ((p.o_rstride | (int)p.o_cstride | (int)p.o_nstride) & 7) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+                // (every cout and row of the tile inside the tensor as well: the path below is straight-line code -- see fast32)
+                wide16 = __builtin_amdgcn_readfirstlane((int)(p.osx == 1 && ox_off == 0 && ox0 + 32 <= p.OW && co_base + MT * 32 <= p.Cout &&
+                         oy0 + C::TH <= p.OH && ((p.o_rstride | (int)p.o_cstride | (int)p.o_nstride) & 7) == 0 &&
+                         (reinterpret_cast<uintptr_t>(p.y) & 15) == 0)) != 0;
                 if (wide16) {
                     const int prow8 = lane >> 2, pcol8 = (lane & 3) * 8;
 #pragma unroll
@@ -769,7 +771,9 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                                     const float4 va = *reinterpret_cast<const float4*>(src), vb = *reinterpret_cast<const float4*>(src + 4);
                                     const float bv = bv2[ps];
                                     const float vv[8] = {va.x + bv, va.y + bv, va.z + bv, va.w + bv, vb.x + bv, vb.y + bv, vb.z + bv, vb.w + bv};
-                                    if (cok2[ps] && oy < p.OH) {
+                                    if (cok2[ps] && oy < p.OH) {   // (always true here.  Without the lane test the compiler hoists every patch read of the
+                                                                   // round -- and this instantiation, 128 accumulators in VGPRs under a 256-register
+                                                                   // cap for two workgroups per CU, spills 175 registers: measured, kept as is)
                                         s2[ps] += ((vv[0] + vv[1]) + (vv[2] + vv[3])) + ((vv[4] + vv[5]) + (vv[6] + vv[7]));
                                         q2s[ps] += ((vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3])) +
                                                    ((vv[4] * vv[4] + vv[5] * vv[5]) + (vv[6] * vv[6] + vv[7] * vv[7]));
@@ -803,7 +807,68 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     }
                 }
             }
-            if (!octet && !wide16) {
+            // ---- fp32 output, the common case as STRAIGHT-LINE code (round 6): whole 32-pixel rows, every cout and every row of the
+            // tile inside the tensor, no bias -- wave-uniform, tested once.  The general loop below keeps a lane-divergent
+            // `cout valid && row valid` test around every 16-byte group; inside it the compiler waits for each ds_read_b128 of the
+            // transposition before it issues the next one: 32 serial LDS round trips + ~130 branches per wave and tile, 14.9 k of
+            // the tile's ~150 k cycles WITH OR WITHOUT the global stores (profiles/r06_epilogue_account.md: APAMD_ABLATE=16 removes
+            // the stores and the segment stays at 14.9 k) -- the epilogue was bound by its own control flow, not by store issue.
+            bool fast32 = false;
+            if constexpr (!C::OB16) {
+                fast32 = __builtin_amdgcn_readfirstlane((int)(!octet && full && p.bias == nullptr && ACT == 0 && p.osy == 1 &&
+                                                              co_base + MT * 32 <= p.Cout && oy0 + C::TH <= p.OH)) != 0;
+                if (fast32) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+                        float* dst0[4];
+#pragma unroll
+                        for (int ps = 0; ps < 4; ++ps)
+                            dst0[ps] = p.y + (long long)n * p.o_nstride + (long long)(co_base + m * 32 + ps * 8 + prow) * p.o_cstride + oxv +
+                                       (long long)(oy0 + wpx * NT + oy_off) * p.o_rstride;
+#pragma unroll
+                        for (int q0 = 0; q0 < NT; q0 += NP) {
+#pragma unroll
+                            for (int b = 0; b < NP; ++b)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    patch0[b * (32 * TS) + ((r & 3) + 8 * (r >> 2) + 4 * half) * TS + l32] = acc[m][q0 + b][r];
+                            float4 v[NP][4];
+#pragma unroll
+                            for (int b = 0; b < NP; ++b)
+#pragma unroll
+                                for (int ps = 0; ps < 4; ++ps)
+                                    v[b][ps] = *reinterpret_cast<const float4*>(patch0 + b * (32 * TS) + (ps * 8 + prow) * TS + pcol);
+#pragma unroll
+                            for (int b = 0; b < NP; ++b)
+#pragma unroll
+                                for (int ps = 0; ps < 4; ++ps) {
+                                    const float4 t = v[b][ps];
+                                    s4[ps] += (t.x + t.y) + (t.z + t.w);
+                                    q4[ps] += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+                                    if (!AP_ABLATE(p, 16)) *reinterpret_cast<float4*>(dst0[ps] + (long long)(q0 + b) * p.o_rstride) = t;
+                                }
+                        }
+                        if (want_stats) {
+#pragma unroll
+                            for (int ps = 0; ps < 4; ++ps) {
+                                float s = s4[ps], q2 = q4[ps];
+#pragma unroll
+                                for (int sh = 1; sh < 8; sh <<= 1) {
+                                    s += __shfl_xor(s, sh, 64);
+                                    q2 += __shfl_xor(q2, sh, 64);
+                                }
+                                if ((lane & 7) == 0) {
+                                    float* d = sred + ((wpx * CO_TILE) + wco * MT * 32 + m * 32 + ps * 8 + prow) * 2;
+                                    d[0] = s;
+                                    d[1] = q2;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!octet && !wide16 && !fast32) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -861,6 +926,9 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                                 } else if (full) {
                                     s4[ps] += (vv[0] + vv[1]) + (vv[2] + vv[3]);
                                     q4[ps] += (vv[0] * vv[0] + vv[1] * vv[1]) + (vv[2] * vv[2] + vv[3] * vv[3]);
+                                    // (experiment build, APAMD_ABLATE bit 16: the epilogue without its global stores -- what is left is
+                                    // the LDS transposition + statistics; profiles/r06_epilogue_account.md)
+                                    if (!AP_ABLATE(p, 16))
                                     *reinterpret_cast<float4*>(dst) =
                                         make_float4(actf(vv[0]), actf(vv[1]), actf(vv[2]), actf(vv[3]));
                                 } else {

@@ -341,15 +341,33 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     fid = torch.randn(204, generator=g) * 0.1
     streamer = stream.ClipStreamer(model, batch=batch)
 
+    front = {}
+    _convert_raw = convert
+
+    def convert(mel):                      # (the AutoVC stage inside clip_audio_features, timed on its own when profiling)
+        t1 = time.perf_counter()
+        out = _convert_raw(mel)
+        torch.cuda.synchronize()
+        front['autovc_converter'] = time.perf_counter() - t1
+        return out
+
     def clip(profile=False):
         # Module1 over the whole clip: both networks + the landmark post-processing of Audio2landmark_model.test and
         # main_end2end_module2.py:262-272 (timed; its output is not fed on -- random weights do not draw faces -- the
         # synthetic sequence of the same length is)
         # audio front end on the host, as in the reference: wav -> loudness -> mel (62.5 frames/s) -> 18-frame windows
+        t0 = time.perf_counter()
         au = audio.clip_audio_features(wav, max_frames=frames, converter=convert)
         assert au.shape == (frames, 18, 80)
+        if profile:
+            torch.cuda.synchronize()
+            front['audio_host_mel_windows'] = time.perf_counter() - t0 - front.get('autovc_converter', 0.0)
+            t0 = time.perf_counter()
         fl = module1.predict_landmarks_speaker_aware(pose, content, au, spk, fid)
         module1.to_image_landmarks(fl, scale=0.01, shift=(-128.0, -128.0), rng=np.random.RandomState(0))
+        if profile:
+            torch.cuda.synchronize()
+            front['module1_landmarks'] = time.perf_counter() - t0
         return streamer.run(photo, lm0, seq, matte=matte, profile=profile)
     clip()                                                   # warm-up (first-use compilation of torch LSTM kernels etc.)
     torch.cuda.synchronize()
@@ -359,7 +377,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     wall = time.perf_counter() - t0
     assert bool(torch.isfinite(out).all())
     clip(profile=True)
-    stages = {k: round(v, 4) for k, v in streamer.timing.items()}
+    stages = {k: round(v, 4) for k, v in list(front.items()) + list(streamer.timing.items())}      # front end + the streamer's stages
     # ---- reference-style CPU path on a bounded sample
     from oracle import generator as og, static_generator as osg, motion as om, aux_glue as oa
     cores = host_cores()

@@ -19,7 +19,7 @@ def load(f):
             d[k] = (c + int(m.group(2)), t + float(m.group(3)))
     return d
 a, b = load(sys.argv[1]), load(sys.argv[2])
-steps = 3
+steps = 5          # tools/train_bench.py 16 3 under train_prof.sh: 2 warm-up + 3 timed steps, all profiled
 ta, tb = sum(v[1] for v in a.values()) / steps / 1e3, sum(v[1] for v in b.values()) / steps / 1e3
 print('| kernel | launches / step A | ms / step A | launches / step B | ms / step B | delta ms |\n|---|---|---|---|---|---|')
 rows = []
