@@ -160,7 +160,7 @@ def _split_backward_plan(tape, layer, srcs, out, contribs):
     # per layer and step otherwise)
     key = (n, c, h, w, bool(pads), layer.weight.requires_grad, tuple(tape.tracked(f) for f in srcs),
            tuple(tuple(f.data.shape) for f in srcs), s.precision, ops.DEFAULT_PRECISION,
-           tuple(os.environ.get(v) for v in ('APAMD_NO_INBWD_SPLIT', 'APAMD_NO_DGRAD_STRIP', 'APAMD_NO_BF16X3', 'APAMD_NO_S2D')),
+           tuple(os.environ.get(v) for v in ('APAMD_NO_INBWD_SPLIT', 'APAMD_NO_BF16X3', 'APAMD_NO_S2D')),
            ops.XS_DIRECT, all(f.xs is not None for f in srcs))
     cache = layer.__dict__.setdefault('_split_bwd_plans', {})
     if key not in cache:

@@ -846,7 +846,7 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
     if (!y || !mean || !rstd || !sums_ws || !dy) return fail(AP_ERR_INVALID, "instnorm_bwd: null pointer");
     if (act < 0 || act > 2) return fail(AP_ERR_INVALID, "instnorm_bwd: act %d", act);
     if (NC < 1 || NC > 65535) return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: N*C=%d", NC);
-    static const bool fused_ok = !(getenv("APAMD_NO_FUSED_INBWD") && atoi(getenv("APAMD_NO_FUSED_INBWD")));
+    constexpr bool fused_ok = true;
     if (fused_ok && H * W <= 4096) {
         hipLaunchKernelGGL((instnorm_bwd_fused_kernel<256, 16>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2,
                            y, mean, rstd, act, H, W, dy);
@@ -965,7 +965,7 @@ int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* ou
     if (NC < 1 || NC > 65535) return fail(AP_ERR_UNSUPPORTED, "act_bwd: N*C=%d", NC);
     int bx = (H * W + 1023) / 1024;
     if (bx > 32) bx = 32;
-    if (g1_pad == 1 && (W & 3) == 0 && H >= 3 && W >= 4 && !getenv("APAMD_NO_FOLD1")) {
+    if (g1_pad == 1 && (W & 3) == 0 && H >= 3 && W >= 4) {
         hipLaunchKernelGGL(act_bwd_fold1_kernel, dim3((H * W / 4 + 511) / 512, NC), dim3(256), 0, (hipStream_t)stream, g1,
                            g2, out, act, H, W, dy);
         return check_launch("act_bwd_fold1_kernel");

@@ -178,14 +178,14 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     }
     // 1..4 output channels, 7x7 'same' convolution: vector-ALU direct kernel (conv_direct.h)
     if (rowk) {
-        const bool two_per_cu = env_int("APAMD_STEM_SMALL", 1) != 0;
+        const bool two_per_cu = true;
         for (const auto& k : bf3_registry())
             if (k.ROW && k.K == K && (!pl.bk || (two_per_cu ? k.TH < pl.bk->TH : k.TH > pl.bk->TH))) pl.bk = &k;
         if (!pl.bk) return fail(AP_ERR_UNSUPPORTED, "no 1x%d row kernel", K);
     }
     // (the PatchGAN's 4x4 pad-1 head, 512 -> 1 on 30 x 30 outputs, was tried here too: 160 workgroups of 128 chunks
     // each run 0.60 ms against 0.39 ms on the MFMA kernel with a 1-of-32 filled tile)
-    if (!rowk && !d->transposed && d->stride == 1 && K == 7 && d->pad == 3 && d->Cout <= 4 && !env_int("APAMD_NO_DIRECT", 0)) {
+    if (!rowk && !d->transposed && d->stride == 1 && K == 7 && d->pad == 3 && d->Cout <= 4) {
         pl.direct_cop = d->Cout == 1 ? 1 : 4;
         const int ci = 4;
         pl.nchunks = 0;
@@ -203,11 +203,11 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
     // and maps narrow enough for the half-wave row kernel use those.
     const bool head_w = !rowk && !d->transposed && d->stride == 1 && K == 4 && d->Cout == 1 && d->nsrc == 1 && pl.Cin >= 64 &&
                         d->w_layout == AP_W_OIHW && !d->w_flip && d->pad == 1;
-    pl.head = head_w && d->W <= kHeadMaxW && !env_int("APAMD_NO_HEAD", 0);
+    pl.head = head_w && d->W <= kHeadMaxW;
     // ConvTranspose2d(C, 1..4, 4, 2, 1): the data gradient of the PatchGAN's first layer w.r.t. the frame (conv_tsmall.h);
     // same arrangement -- the IOHW weights ride behind the regular image
     pl.tsmall = !rowk && d->transposed && d->stride == 2 && K == 4 && d->pad == 1 && d->output_padding == 0 && d->Cout <= 4 &&
-                d->nsrc == 1 && d->w_layout == AP_W_IOHW && !d->w_flip && !env_int("APAMD_NO_TSMALL", 0);
+                d->nsrc == 1 && d->w_layout == AP_W_IOHW && !d->w_flip;
     // narrow 3x3 layers (landmark encoder): memory streams, one lane per output pixel (conv_small.h)
     if (!rowk && !d->transposed && K == 3 && d->nsrc == 1 && pl.Cin <= 16 && (d->Cout == 8 || d->Cout == 16) &&
         d->w_layout == AP_W_OIHW && !d->w_flip && !env_int("APAMD_NO_SMALL", 0)) {
@@ -238,13 +238,12 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
             pl.bk = tall;
             if (KT == 0) {
                 // every launch of these plans has 4 taps (2x2 layers, 4x4 phases, fused 3x3 phases of an even output)
-                const bool all4 = K == 2 || K == 4 || (d->transposed && K == 3 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 &&
-                                                        !env_int("APAMD_NO_FUSED_PHASES", 0));
-                pl.k0_small = all4 && env_int("APAMD_K0_SMALL", 1) != 0;
+                const bool all4 = K == 2 || K == 4 || (d->transposed && K == 3 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0);
+                pl.k0_small = all4;
                 if (pl.k0_small) pl.bk = small;
                 // stride-2 transposed 3x3 / 4x4 with pad 1 and an even output: all four phases in one tile
                 if (d->transposed && (K == 3 || K == 4) && d->pad == 1 && d->stride == 2 && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 &&
-                    !env_int("APAMD_NO_FUSED_PHASES", 0) && !env_int("APAMD_NO_PH4", 0)) {
+                    true) {
                     pl.ph4 = K;
                     pl.bk = ph4_kernel(K);
                 }
@@ -339,7 +338,7 @@ static int make_plan(const ap_conv_desc* d, Plan& pl) {
         // Split-bf16 path, even output size: the four phases share one pixel-tile grid and run as ONE launch whose
         // cout tiles enumerate (phase, cout tile) -- the activation tile is fetched from HBM once instead of four
         // times and the interleaved output lines of the phases meet in the XCD's L2 (conv_bf16x3.h, ConvKParams.nphase).
-        const bool fuse = pl.bk != nullptr && pl.Hout % 2 == 0 && pl.Wout % 2 == 0 && !env_int("APAMD_NO_FUSED_PHASES", 0);
+        const bool fuse = pl.bk != nullptr && pl.Hout % 2 == 0 && pl.Wout % 2 == 0;
         for (int phy = 0; phy < 2; ++phy)
             for (int phx = 0; phx < 2; ++phx) {
                 Launch L;
@@ -616,7 +615,7 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
         else if (res_kind == 1) launch(vt, xt, std::integral_constant<int, 1>{}, grid);
         else launch(vt, xt, std::integral_constant<int, 2>{}, grid);
     };
-    if ((p.HW & 3) == 0 && !env_int("APAMD_NS_SCALAR", 0)) {
+    if ((p.HW & 3) == 0) {
         dim3 grid((p.HW / 4 + 255) / 256, src->C / 8, N);
         if (xb16) by_res(std::integral_constant<int, 4>{}, std::true_type{}, grid);
         else by_res(std::integral_constant<int, 4>{}, std::false_type{}, grid);
@@ -946,9 +945,9 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         // rows per workgroup: the tallest band that still gives every CU a workgroup (N x bands >= ~200) -- with 10-row bands a
         // B = 16 launch is 48 workgroups on 256 CUs (53 us for 50 MB); shorter bands re-read 3 halo rows each, which is cheap here
         const int rb10 = d->N * ((pl.Hout + 9) / 10), rb5 = d->N * ((pl.Hout + 4) / 5);
-        if (rb10 >= 200 || env_int("APAMD_HEAD_BAND", 0) == 10)
+        if (rb10 >= 200)
             hipLaunchKernelGGL(conv_head_fwd_kernel<10>, dim3(d->N, (pl.Hout + 9) / 10), dim3(1024), 0, (hipStream_t)stream, p);
-        else if (rb5 >= 200 || env_int("APAMD_HEAD_BAND", 0) == 5)
+        else if (rb5 >= 200)
             hipLaunchKernelGGL(conv_head_fwd_kernel<5>, dim3(d->N, (pl.Hout + 4) / 5), dim3(1024), 0, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL(conv_head_fwd_kernel<3>, dim3(d->N, (pl.Hout + 2) / 3), dim3(1024), 0, (hipStream_t)stream, p);
@@ -1027,7 +1026,6 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                     p.ph_tapmask[ph] = 0;
                     for (size_t t = 0; t < Lp.taps.size() && t < 4; ++t)
                         if (Lp.taps[t].ky >= 0) p.ph_tapmask[ph] |= 1u << t;
-                    if (env_int("APAMD_NO_TAP_SKIP", 0)) p.ph_tapmask[ph] = 0xFu;
                 }
                 if (pl.ph4) {
                     // conv_ph4 walks cout tiles only and derives the phase geometry from K: check the plan agrees
@@ -1053,8 +1051,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 }
             }
             p.tap_bits = 0;
-            if (d->s2d_k == 3 && !d->transposed && pl.bk->K == 0 && d->KW == 2 && d->nsrc == 1 && d->src[0].C % 64 == 0 &&
-                !env_int("APAMD_NO_TAP_SKIP", 0)) {
+            if (d->s2d_k == 3 && !d->transposed && pl.bk->K == 0 && d->KW == 2 && d->nsrc == 1 && d->src[0].C % 64 == 0) {
                 // space-to-depth form of a 3x3 stride-2 layer: input phase (ry, rx) = 16-channel chunks [r C/16, (r+1) C/16)
                 p.s2d_div = d->src[0].C / 64;
                 for (int r = 0; r < 4; ++r) {
@@ -1068,8 +1065,7 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
                 for (int t = 0; t < p.ntaps; ++t)
                     p.tap_bits |= (unsigned)((L.taps[t].ly & 1) | ((L.taps[t].lx & 1) << 1)) << (2 * t);
             }
-            if (p.s2d_div > 0 && (p.s2d_div & 1) == 0 && p.nchunks == 4 * p.s2d_div && kern->kernel_s2d3(d->precision) &&
-                !env_int("APAMD_NO_S2D3_TAPSETS", 0)) {
+            if (p.s2d_div > 0 && (p.s2d_div & 1) == 0 && p.nchunks == 4 * p.s2d_div && kern->kernel_s2d3(d->precision)) {
                 // even chunk count per input phase: the instantiation with compile-time tap sets (no fragment reads for absent taps)
                 kfn = kern->kernel_s2d3(d->precision);
                 rc = ensure_lds_attr(kfn);

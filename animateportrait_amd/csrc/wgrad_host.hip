@@ -140,9 +140,8 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
     pl.Q = pl.Cin * K * K;
     // 1..2 input channels (landmark encoder / PatchGAN first layer): one streaming pass, no operand copies (wgrad_narrow.h)
     {
-        const char* nn = getenv("APAMD_NO_NARROW_WGRAD");
         int cob = 0;
-        if (d->nsrc == 1 && d->g.mean == nullptr && d->g.act == AP_ACT_NONE && !(nn && atoi(nn))) {
+        if (d->nsrc == 1 && d->g.mean == nullptr && d->g.act == AP_ACT_NONE) {
             if (K == 3 && S == 1 && pl.Cin == 1) cob = 8;
             else if (K == 4 && S == 2 && pl.Cin == 1) cob = 4;
             else if (K == 4 && S == 2 && pl.Cin == 2) cob = 4;
@@ -160,7 +159,7 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
             // form (one output pixel per thread and iteration: 2 and 4 measured slower, 277 registers) (wgrad_narrow_s2k4_kernel)
             constexpr int kNarrowPPT = 1;
             if (K == 4 && S == 2 && d->pad == 1 && d->pad_mode == AP_PAD_ZERO && gwc == d->GW && d->W == 2 * d->GW &&
-                d->H == 2 * d->GH && (d->GH % (pl.rpi * kNarrowPPT)) == 0 && !getenv("APAMD_NO_NARROW_LDS"))
+                d->H == 2 * d->GH && (d->GH % (pl.rpi * kNarrowPPT)) == 0)
                 pl.narrow_ppt = kNarrowPPT;
             const int rit = pl.rpi * (pl.narrow_ppt ? pl.narrow_ppt : 1);
             rpb = (rpb + rit - 1) / rit * rit;
@@ -199,9 +198,8 @@ static int make_wgrad_plan(const ap_wgrad_desc* d, WgradPlan& pl) {
         pl.nstages = d->N * pl.tiles_y * pl.tiles_x;
         // split-bf16 arithmetic on 128-output multiples: the 8-wave workgroup (two waves per SIMD where the 4-wave one, whose
         // head + tail stages fill the LDS, has one)
-        const char* now_ = getenv("APAMD_NO_WIDE_WGRAD");
         // (plain bf16 keeps two 4-wave workgroups per CU: the 8-wave form measured the same, 160.9 against 160.0 us per 3x3 layer)
-        pl.wide = d->precision == AP_PRECISION_BF16X3 && !pl.rows && pl.Kb <= 3 && d->M % 128 == 0 && !(now_ && atoi(now_));
+        pl.wide = d->precision == AP_PRECISION_BF16X3 && !pl.rows && pl.Kb <= 3 && d->M % 128 == 0;
         const int mtile = pl.wide ? 128 : 64;
         pl.m_tiles = (d->M + mtile - 1) / mtile;
         pl.c_tiles = (pl.Cb + 63) / 64;
@@ -310,10 +308,10 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         hipLaunchKernelGGL(split_transpose_kernel, dim3((Hp * X8 + 7) / 8, Cp / 64, N), dim3(256), 0, stream, p);
         return check_launch("split_transpose_kernel");
     }
-    if (any_b16 && !(!env_int("APAMD_NO_SPLIT_ROWS", 0) && (W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
+    if (any_b16 && !((W == 64 || W == 128 || W == 256 || W == 32) && s2d_c == 0 && pad == 1))
         return fail(AP_ERR_UNSUPPORTED, "split_transpose: a bf16 source needs the padded-row form (pad 1, W in {32, 64, 128, 256})");
     if (N > 65535 || Cp / 64 > 65535) return fail(AP_ERR_UNSUPPORTED, "split_transpose: N=%d C=%d", N, C);
-    if (nseg == 1 && pad == 0 && s2d_c == 0 && X8 * 8 == W && !getenv("APAMD_NO_SPLIT_VEC")) {
+    if (nseg == 1 && pad == 0 && s2d_c == 0 && X8 * 8 == W) {
         // unpadded operand with whole octet rows: 16-byte loads, 1 KiB per wave (split_transpose_vec_kernel)
         static bool attr = false;
         const size_t lds = 64 * 257 * sizeof(float);
@@ -326,7 +324,7 @@ static int launch_split_transpose(const ap_src* segs, int nseg, int N, int C, in
         hipLaunchKernelGGL(split_transpose_vec_kernel, dim3((Hp * X8 + 31) / 32, Cp / 64, N), dim3(256), lds, stream, p);
         return check_launch("split_transpose_vec_kernel");
     }
-    const bool rows_ok = !env_int("APAMD_NO_SPLIT_ROWS", 0) && (W == 64 || W == 128 || W == 256 || (W == 32 && s2d_c == 0));
+    const bool rows_ok = (W == 64 || W == 128 || W == 256 || (W == 32 && s2d_c == 0));
     if (rows_ok && s2d_c == 0 && pad == 1) {
         // padded rows, 16-byte loads (split_transpose_pad_kernel)
         const int R = 256 / W;

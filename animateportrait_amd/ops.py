@@ -382,7 +382,7 @@ def stem_rows_eligible(spec):
     over the row expansion of their input."""
     return (spec.precision != PRECISION_FP32 and spec.k == 7 and spec.stride == 1 and spec.pad == 3 and
             not spec.transposed and len(spec.cin_segments) == 1 and spec.cin_segments[0] <= 4 and spec.cout >= 32 and
-            spec.w_layout == W_OIHW and not spec.w_flip and not os.environ.get('APAMD_NO_STEM_ROWS'))
+            spec.w_layout == W_OIHW and not spec.w_flip)
 
 
 def stem_rows_spec(spec):
@@ -635,9 +635,9 @@ def _zero_counters(n, device):
 FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
 
 
-# Inference: the ResNet trunk's residual stream kept only as split copies (materialize keep_fp32=False).  APAMD_RESIDUAL_FP32=1
-# restores the fp32 stream (A/B).
-RESIDUAL_AS_SPLIT = os.environ.get('APAMD_RESIDUAL_FP32', '0') != '1'
+# Inference: the ResNet trunk's residual stream is kept only as split copies (materialize keep_fp32=False; HISTORY.md section 3.10).
+# (tests flip the flag to compare with the fp32 stream)
+RESIDUAL_AS_SPLIT = True
 
 
 def fused_norm_ok(spec, srcs):
@@ -740,7 +740,7 @@ def dgrad_strip_eligible(spec, g):
     gradient Feat.  True when the padded-coordinate output is 32 m + 2 columns wide (the 64 x 64 maps of the ResNet
     blocks: 66) and the operator runs on the split-bf16 path: see conv2d_dgrad_strip."""
     if (spec.precision == PRECISION_FP32 or spec.k != 3 or spec.stride != 1 or spec.pad != 2 or spec.transposed or
-            len(spec.cin_segments) != 1 or g.virtual or os.environ.get('APAMD_NO_DGRAD_STRIP')):
+            len(spec.cin_segments) != 1 or g.virtual):
         return False
     n, c, h, w = g.data.shape
     if (w + 2) % 32 != 2 or w < 32 or h < 4 or c % 8:
@@ -912,7 +912,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
     cin = sum(f.data.shape[1] for f in srcs)
     if (m == 1 and k == 4 and stride == 1 and len(srcs) == 1 and cin >= 64 and not g.virtual and g.act == ACT_NONE and
             tuple(out_shape) == (1, cin, k, k) and srcs[0].data.shape[2] <= 32 and srcs[0].data.shape[3] <= 31 and
-            pad == 1 and pad_mode == PAD_ZERO and not os.environ.get('APAMD_NO_HEAD')):
+            pad == 1 and pad_mode == PAD_ZERO):
         # PatchGAN output layer: one workgroup per input channel (conv_head.h)
         f = srcs[0]
         _require_device(f.data, 'wgrad source')
@@ -926,7 +926,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
                                            _ptr(dw), _stream()), 'conv_head_wgrad')
         return dw
     if (m == 1 and k == 7 and stride == 1 and pad == 3 and len(srcs) == 1 and cin >= 16 and not g.virtual and
-            g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k) and not os.environ.get('APAMD_NO_FINAL_WGRAD')):
+            g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k)):
         # the generator's last layer: vector-ALU kernel, window through LDS (wgrad_final.h)
         f = srcs[0]
         _require_device(f.data, 'wgrad source')

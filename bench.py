@@ -329,7 +329,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     vc = autovc.Generator(16, 256, 512, 16).to(dev).eval()
     e_src = np.abs(np.random.RandomState(3).randn(256)).astype(np.float32) * 0.1
     e_trg = np.abs(np.random.RandomState(4).randn(256)).astype(np.float32) * 0.1
-    convert = lambda mel: autovc.convert_mel(vc, mel, 0.5 + 0.4 * np.sin(np.arange(mel.shape[0]) / 9.0), e_src, e_trg, dev)   # noqa: E731
+    convert = lambda mel: autovc.convert_mel(vc, mel, 0.5 + 0.4 * np.sin(np.arange(mel.shape[0]) / 9.0), e_src, e_trg, dev, use_graph=True)   # noqa: E731
     g = torch.Generator().manual_seed(1234)
     photo = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')
@@ -426,6 +426,7 @@ def main():
     ap.add_argument('--no-exact-fp32', action='store_true', help='skip the exact-fp32 comparison leg')
     ap.add_argument('--train-steps', type=int, default=3, help='timed train steps (0 = skip the train-step leg)')
     ap.add_argument('--no-stream', action='store_true', help='skip the 10 s clip sub-record (BASELINE configs[4]) of the default run')
+    ap.add_argument('--stream-batch', type=int, default=16, help='frames per batch of the clip leg (the reference runs batch 1)')
     ap.add_argument('--stream', action='store_true',
                     help='BASELINE configs[4] instead of the default legs: wall-clock of a 10 s (625-frame) clip through the '
                          'in-process pipeline, next to the reference-style CPU path (prints its own JSON line)')
@@ -434,7 +435,7 @@ def main():
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: the HIP path has no CPU fallback')
         torch.cuda.set_device(0)
-        print(json.dumps(stream_leg(torch.device('cuda', 0))))
+        print(json.dumps(stream_leg(torch.device('cuda', 0), batch=a.stream_batch)))
         return
 
     if not torch.cuda.is_available():
@@ -646,7 +647,7 @@ def main():
     stream_rec = None
     if world == 1 and not a.no_stream:
         torch.cuda.empty_cache()
-        stream_rec = stream_leg(dev)
+        stream_rec = stream_leg(dev, batch=a.stream_batch)
 
     if rank == 0:
         fps = world * BATCH * a.steps / dt
