@@ -131,50 +131,9 @@ def _pad_seq(x, base=PAD_BASE):
     return np.pad(x, ((0, pad), (0, 0)), 'constant'), pad
 
 
-def _graphed_piece(G, x, e_src, f, e_trg):
-    """One converter forward as a hipGraph replay, one graph per piece shape (cached on ``G``).  The two LSTM stacks run ~830 time
-    steps of a few tiny kernels each: ~11 k launches per 10 s clip, 0.20 s of host launch time for ~30 ms of device work
-    (bench.py stream leg, `autovc_converter`).  Capture starts from a synchronised device and warms up on a side stream with
-    nothing else in flight.  Any failure to capture (a library that allocates inside the capture) is
-    remembered and the piece runs eagerly."""
-    cache = G.__dict__.setdefault('_apamd_graphs', {})
-    key = (tuple(x.shape), str(x.device))
-    ent = cache.get(key)
-    if ent is None:
-        try:
-            # (hipBLASLt synchronises inside its GEMM call, which aborts a capturing process: rocBLAS for this module's GEMMs)
-            torch.backends.cuda.preferred_blas_library('cublas')
-            torch.cuda.synchronize()
-            sx, se, sf, st = x.clone(), e_src.clone(), f.clone(), e_trg.clone()
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    G(sx, se, sf, st, sf)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = G(sx, se, sf, st, sf)[1]
-            torch.cuda.synchronize()
-            ent = (g, sx, se, sf, st, out)
-        except Exception as e:            # noqa: BLE001 -- whatever the capture raised, the eager path is always correct
-            print('[autovc] hipGraph capture of the converter failed (%s: %s): running it eagerly' % (type(e).__name__, str(e).splitlines()[0] if str(e) else ''))
-            torch.cuda.synchronize()
-            ent = False
-        cache[key] = ent
-    if ent is False:
-        return G(x, e_src, f, e_trg, f)[1]
-    g, sx, se, sf, st, out = ent
-    sx.copy_(x); se.copy_(e_src); sf.copy_(f); st.copy_(e_trg)
-    g.replay()
-    return out.clone()
-
-
-def convert_mel(G, mel, f0_norm, emb_src, emb_trg, device=None, use_graph=False):
+def convert_mel(G, mel, f0_norm, emb_src, emb_trg, device=None):
     """AutoVC_mel_Convertor_retrain_version.py:246-274: (T, 80) mel + (T,) normalised f0 (-1e10 / negative where unvoiced; None:
-    an all-unvoiced track) + the two 256-d speaker embeddings -> the converted (T, 80) mel ``x_identic_psnt``.
-    use_graph: replay each piece's forward as a hipGraph (one per piece shape, cached on ``G``): same kernels, no host launch time."""
+    an all-unvoiced track) + the two 256-d speaker embeddings -> the converted (T, 80) mel ``x_identic_psnt``."""
     device = device or next(G.parameters()).device
     mel = np.asarray(mel)
     f0 = np.full(mel.shape[0], -1e10) if f0_norm is None else np.asarray(f0_norm)
@@ -188,10 +147,7 @@ def convert_mel(G, mel, f0_norm, emb_src, emb_trg, device=None, use_graph=False)
         for i in range(0, mel.shape[0], PIECE):
             x, pad = _pad_seq(mel[i:i + PIECE].astype('float32'))
             f, _ = _pad_seq(f0q[i:i + PIECE].astype('float32'))
-            if use_graph and torch.device(device).type == 'cuda':
-                out.append(_graphed_piece(G, to(x), e_src, to(f), e_trg))
-            else:
-                out.append(G(to(x), e_src, to(f), e_trg, to(f))[1])
+            out.append(G(to(x), e_src, to(f), e_trg, to(f))[1])
     y = torch.cat(out, 1)[0]
     return (y if pad == 0 else y[:-pad]).cpu().numpy()        # only the last piece can carry padding (4096 = 128 * 32)
 

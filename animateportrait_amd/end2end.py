@@ -79,7 +79,7 @@ def landmarks_from_audio(a, device):
         if f0 is None:
             print('WARNING: no --f0_npy: the converter runs on an all-unvoiced f0 track (the reference extracts RAPT f0 with '
                   'pysptk, which is not in this image)')
-        converter = lambda mel: autovc.convert_mel(G, mel, None if f0 is None else f0[:mel.shape[0]], emb, emb_trg, device, use_graph=True)   # noqa: E731
+        converter = lambda mel: autovc.convert_mel(G, mel, None if f0 is None else f0[:mel.shape[0]], emb, emb_trg, device)   # noqa: E731
     windows = audio.clip_audio_features(a.wav, max_frames=a.max_frames, converter=converter)
     fl = module1.predict_landmarks_speaker_aware(net_g, net_c, windows, emb, face_id.reshape(-1))
     seq = module1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]

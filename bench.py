@@ -329,7 +329,7 @@ def stream_leg(dev, frames=625, batch=16, cpu_frames=6):
     vc = autovc.Generator(16, 256, 512, 16).to(dev).eval()
     e_src = np.abs(np.random.RandomState(3).randn(256)).astype(np.float32) * 0.1
     e_trg = np.abs(np.random.RandomState(4).randn(256)).astype(np.float32) * 0.1
-    convert = lambda mel: autovc.convert_mel(vc, mel, 0.5 + 0.4 * np.sin(np.arange(mel.shape[0]) / 9.0), e_src, e_trg, dev, use_graph=True)   # noqa: E731
+    convert = lambda mel: autovc.convert_mel(vc, mel, 0.5 + 0.4 * np.sin(np.arange(mel.shape[0]) / 9.0), e_src, e_trg, dev)   # noqa: E731
     g = torch.Generator().manual_seed(1234)
     photo = torch.rand(1, 3, 256, 256, generator=g) * 2 - 1
     yy, xx = torch.meshgrid(torch.linspace(-1, 1, 256), torch.linspace(-1, 1, 256), indexing='ij')

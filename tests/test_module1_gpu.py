@@ -155,22 +155,3 @@ def test_end2end_cli_from_wav(dev, golden, tmp_path, monkeypatch):
     seq = m1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
     assert np.isfinite(seq).all() and np.abs(seq.mean(0) - m1.photo_landmarks_in_pixels(fid, scale, shift)).max() < 400
 
-
-def test_autovc_converter_as_a_hipgraph_replay_equals_the_eager_forward(dev):
-    """autovc.convert_mel(use_graph=True): each piece's forward replays as a hipGraph (one per piece shape, cached on the module) --
-    the same kernels, so the same numbers as the eager forward; a second call on other data replays the cached graph."""
-    import numpy as np
-    from animateportrait_amd import autovc
-    torch.manual_seed(5)
-    G = autovc.Generator(16, 256, 512, 16).to(dev).eval()
-    rs = np.random.RandomState(0)
-    e1, e2 = rs.randn(256).astype(np.float32) * 0.1, rs.randn(256).astype(np.float32) * 0.1
-    for t in (70, 70, 200):
-        mel = rs.rand(t, 80).astype(np.float32)
-        f0 = 0.5 + 0.4 * np.sin(np.arange(t) / 7.0)
-        f0[::9] = -1e10
-        eager = autovc.convert_mel(G, mel, f0, e1, e2, dev)
-        graph = autovc.convert_mel(G, mel, f0, e1, e2, dev, use_graph=True)
-        assert eager.shape == graph.shape == (t, 80)
-        assert np.abs(eager - graph).max() <= 1e-5 * max(1.0, np.abs(eager).max())
-    assert len(G._apamd_graphs) == 2            # padded piece lengths 96 and 224: one graph each
