@@ -62,7 +62,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 11     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 12     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -184,6 +184,10 @@ SIGNATURES = {
     'ap_landmark_discs': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_float, ctypes.c_float, c_f32p, ctypes.c_void_p]),
     'ap_circle_rows': (ctypes.c_int, [ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    'ap_lstm_workspace_bytes': (ctypes.c_int64, [ctypes.c_int32]),
+    'ap_lstm_recurrence': (ctypes.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32,
+                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
+    'ap_lstm_timed_out': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     'ap_pixel_shuffle2': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p,
                                          ctypes.c_void_p]),
     'ap_lip_line_mask': (ctypes.c_int, [c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),

@@ -8,7 +8,8 @@ The reference feeds Module1 the CONVERTED spectrogram ``x_identic_psnt`` (main_e
 checkpoints were trained on it.  What is not in this image and enters as arguments: the RAPT f0 track (pysptk; ``f0_norm`` of
 extract_f0_func_audiofile, -1e10 where unvoiced), the resemblyzer speaker embedding (256-d), and the target-speaker embedding
 (the reference reads ``src/autovc/retrain_version/obama_emb.txt``: a data file of the user's checkout, ``load_target_embedding``).
-Small LSTM / conv1d network (~0.1 GFLOP per frame): cuDNN-style library kernels through torch, no hand kernels.
+Small LSTM / conv1d network (~0.1 GFLOP per frame): library kernels through torch, except the LSTM recurrences on the device,
+whose time loops run inside one kernel each (lstm_hip.py, csrc/lstm.hip).
 Pinned to the reference class and functions by tests/golden/make_autovc_golden.py.
 """
 import math
@@ -23,6 +24,14 @@ DIM_ENC = DIM_DEC = 512
 DIM_FREQ, DIM_F0, GROUPS = 80, 257, 32
 PIECE, PAD_BASE = 4096, 32                     # AutoVC_mel_Convertor_retrain_version.py:250, :201-205
 TARGET_EMB_PATHS = ('src/autovc/retrain_version/obama_emb.txt', 'Module1/src/autovc/retrain_version/obama_emb.txt')   # :211-214
+
+
+def _lstm(lstm, x):
+    """``lstm(x)[0]``; on the device (inference) with the time loop in one kernel per layer and direction (lstm_hip.py)."""
+    if x.is_cuda:
+        from . import lstm_hip
+        return lstm_hip.lstm_forward(lstm, x.contiguous())
+    return lstm(x)[0]
 
 
 class _Linear(nn.Module):
@@ -61,7 +70,7 @@ class _Encoder(nn.Module):
     def forward(self, x):
         for conv in self.convolutions:
             x = F.relu(conv(x))
-        out, _ = self.lstm(x.transpose(1, 2))
+        out = _lstm(self.lstm, x.transpose(1, 2))
         fwd, bwd = out[:, :, :self.dim_neck], out[:, :, self.dim_neck:]
         # one code per ``freq`` frames: the forward state at the END of the segment, the backward state at its START
         return [torch.cat((fwd[:, i + self.freq - 1], bwd[:, i]), -1) for i in range(0, out.size(1), self.freq)]
@@ -74,7 +83,7 @@ class _Decoder(nn.Module):
         self.linear_projection = _Linear(DIM_DEC, DIM_FREQ)
 
     def forward(self, x):
-        return self.linear_projection(self.lstm(x)[0])
+        return self.linear_projection(_lstm(self.lstm, x))
 
 
 class _Postnet(nn.Module):

@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 11
+#define AP_ABI_VERSION 12
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -502,6 +502,19 @@ int ap_lip_line_mask(const float* lands, int32_t N, int32_t P, const int32_t* se
 int ap_landmark_discs(const float* lm, int32_t N, int32_t P, int32_t H, int32_t W, int32_t radius, float lo, float hi,
                       float* out, ap_stream_t stream);
 int ap_circle_rows(int32_t radius, int32_t* hw);
+
+/* The recurrence of one direction of one nn.LSTM layer over a whole sequence, time loop inside the kernel (lstm.hip): replaces the
+ * per-time-step library kernels behind nn.LSTM in the AutoVC content converter (Module1/src/autovc/retrain_version/model_vc_37_1.py:
+ * 75 `self.lstm = nn.LSTM(dim_enc, dim_neck, 2, batch_first=True, bidirectional=True)` and :98 `nn.LSTM(..., dim_dec, 3)`).
+ * xproj [B][T][4H] = W_ih x_t + b_ih + b_hh for every t (gate order i, f, g, o; a library GEMM on the caller's side), whh [4H][H],
+ * h0 / c0 [B][H] or null (zeros), out [B][T][out_stride] with this direction's H values at column out_off, hn / cn the final state
+ * or null.  H <= 64 at any B, or H in {256, 512} at B == 1 (workspace of ap_lstm_workspace_bytes(H) bytes); otherwise
+ * AP_ERR_UNSUPPORTED.  ap_lstm_timed_out(workspace, H): 1 when the last H > 64 launch gave up waiting for its peer workgroups. */
+int64_t ap_lstm_workspace_bytes(int32_t H);
+int ap_lstm_recurrence(const float* xproj, const float* whh, const float* h0, const float* c0, float* out, float* hn, float* cn,
+                       int32_t B, int32_t T, int32_t H, int32_t reverse, int32_t out_stride, int32_t out_off, void* workspace,
+                       ap_stream_t stream);
+int ap_lstm_timed_out(const void* workspace, int32_t H);
 
 #ifdef __cplusplus
 }

@@ -155,3 +155,39 @@ def test_end2end_cli_from_wav(dev, golden, tmp_path, monkeypatch):
     seq = m1.to_image_landmarks(fl, scale=scale, shift=shift)[:, :, :2]
     assert np.isfinite(seq).all() and np.abs(seq.mean(0) - m1.photo_landmarks_in_pixels(fid, scale, shift)).max() < 400
 
+
+
+@pytest.mark.parametrize('cfg', [(512, 16, 2, True, 96), (545, 512, 3, False, 96), (80, 256, 1, False, 40), (40, 48, 2, True, 33)])
+def test_lstm_recurrence_kernel_equals_the_library_lstm(dev, cfg):
+    """ap_lstm_recurrence (csrc/lstm.hip) through lstm_hip.lstm_forward against nn.LSTM on the device: the AutoVC encoder's 2-layer
+    bidirectional LSTM (16 hidden units), its 3-layer decoder LSTM (512), and two other sizes of both kernels."""
+    from animateportrait_amd import lstm_hip
+    i, h, layers, bi, t = cfg
+    torch.manual_seed(i + h)
+    lstm = torch.nn.LSTM(i, h, layers, batch_first=True, bidirectional=bi).to(dev).eval()
+    x = torch.randn(1, t, i, device=dev)
+    with torch.no_grad():
+        assert lstm_hip.supported(lstm, x)
+        ref = lstm(x)[0]
+        got = lstm_hip.lstm_forward(lstm, x)
+    torch.cuda.synchronize()
+    lstm_hip.check_timeouts()
+    assert got.shape == ref.shape
+    assert linf(got, ref) < 2e-5
+
+
+def test_autovc_converter_on_the_lstm_kernels_matches_the_reference_golden(dev):
+    """convert_mel on the device (LSTM time loops in ap_lstm_recurrence) against the output of the reference's own Generator
+    (tests/golden/autovc.npz, made by make_autovc_golden.py on the CPU with the same seeded weights and inputs)."""
+    from animateportrait_amd import autovc
+    from make_autovc_golden import SEED, make_inputs
+    from make_auxnets_golden import seeded_state_scaled, keys_of
+    g = np.load(os.path.join(GOLDEN, 'autovc.npz'))
+    G = autovc.Generator(16, 256, 512, 16).eval()
+    G.load_state_dict(seeded_state_scaled(keys_of(G), SEED), strict=True)
+    G = G.to(dev)
+    mel, f0, e_src, e_trg = make_inputs()
+    got = autovc.convert_mel(G, mel, f0, e_src, e_trg, dev)
+    ref = g['converted']
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-4 * float(np.abs(ref).max()) + 1e-5
