@@ -158,7 +158,11 @@ def convert_mel(G, mel, f0_norm, emb_src, emb_trg, device=None):
             f, _ = _pad_seq(f0q[i:i + PIECE].astype('float32'))
             out.append(G(to(x), e_src, to(f), e_trg, to(f))[1])
     y = torch.cat(out, 1)[0]
-    return (y if pad == 0 else y[:-pad]).cpu().numpy()        # only the last piece can carry padding (4096 = 128 * 32)
+    res = (y if pad == 0 else y[:-pad]).cpu().numpy()        # only the last piece can carry padding (4096 = 128 * 32)
+    if torch.device(device).type == 'cuda':
+        from . import lstm_hip
+        lstm_hip.check_timeouts()                            # (after the copy's synchronisation: a recurrence whose workgroups never met fails loudly)
+    return res
 
 
 def load_generator(path, device):
