@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
             const int prow = lane >> 3, pcol = (lane & 7) * 4;
             const int oxv = ox0 + pcol;
             bool octet = false;
-            if constexpr (C::K == 0 || C::ROW) {
+            if constexpr (C::K == 0 || C::ROW || (C::K == 3 && C::S == 1 && C::PARTS == 2 && !C::OB16 && !C::FNORM)) {
                 // ---- channel-octet output y[n][Cout/8][OH*OW][8] (ap_conv2d_fwd_octet; the run-time-tap and row families
                 // only: the producers of the warp kernel's input).  The MFMA layout already holds 4 consecutive couts of
                 // one pixel per lane and register quad (row = (r & 3) + 8 (r >> 2) + 4 half), and the two halves of a wave
@@ -667,11 +667,34 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                 if (octet) {
                     const int ox = ox0 + l32;
                     const long long ohw = (long long)p.OH * p.OW;
+                    // (round 6) every cout, row and column of the tile inside the tensor, no bias, no activation -- tested once, wave-uniform:
+                    // the stores and sums below then run without the per-lane test (see fast32)
+                    const bool allv = __builtin_amdgcn_readfirstlane((int)(p.bias == nullptr && ACT == 0 && co_base + MT * 32 <= p.Cout &&
+                                                                           oy0 + C::TH <= p.OH && ox0 + 32 <= p.OW)) != 0;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
                         float s16[16], q16[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) { s16[r] = 0.f; q16[r] = 0.f; }
+                        if (allv) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int co = co_base + m * 32 + g * 8 + 4 * half;
+                                float* const ob = p.y + (long long)n * p.o_nstride + (long long)(co >> 3) * ohw * 8 + (co & 7) +
+                                                  ((long long)(oy0 + wpx * NT) * p.OW + ox) * 8;
+#pragma unroll
+                                for (int q = 0; q < NT; ++q) {
+                                    float vv[4];
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) {
+                                        vv[j] = acc[m][q][g * 4 + j];
+                                        s16[g * 4 + j] += vv[j];
+                                        q16[g * 4 + j] += vv[j] * vv[j];
+                                    }
+                                    *reinterpret_cast<float4*>(ob + (long long)q * p.OW * 8) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                                }
+                            }
+                        } else
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int co = co_base + m * 32 + g * 8 + 4 * half;          // 4 consecutive couts (Cout % 8 == 0)

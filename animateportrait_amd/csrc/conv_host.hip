@@ -607,6 +607,14 @@ int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_
     p.N = N; p.C = src->C; p.HW = H * W;
     const bool xb16 = (flags & 8) != 0;       // src->data holds bf16 values (a raw output of ap_conv2d_fwd_bf16out)
     const int res_kind = p.res_xs ? 2 : (p.res ? 1 : 0);
+    if (flags & 16) {           // src->data is the channel-octet raw output of ap_conv2d_fwd_octet; the only output is the split copy
+        if (y || !xs || res_kind == 1 || xb16)
+            return fail(AP_ERR_UNSUPPORTED, "norm_apply_split: a channel-octet source gives a split copy only, with no residual or a split-copy one");
+        dim3 grid((p.HW + 511) / 512, src->C / 8, N);
+        if (res_kind == 2) hipLaunchKernelGGL(norm_split_oct_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(norm_split_oct_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, p);
+        return check_launch("norm_split_oct_kernel");
+    }
     auto launch = [&](auto vt, auto xt, auto rt, dim3 grid) {
         hipLaunchKernelGGL((norm_split_kernel<decltype(vt)::value, decltype(xt)::value, decltype(rt)::value>), grid, dim3(256), 0, (hipStream_t)stream, p);
     };
@@ -801,7 +809,7 @@ int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const flo
 static bool octet_plan_ok(const ap_conv_desc* d, const Plan& pl) {
     if (!pl.bf3 || pl.fused_phases || pl.ph4 || pl.launches.size() != 1 || (d->Cout & 7)) return false;
     const Bf3Kernel* kern = bf3_for_taps(pl.bk, (int)pl.launches[0].taps.size());
-    return kern && (kern->K == 0 || kern->ROW);
+    return kern && (kern->K == 0 || kern->ROW || (kern->K == 3 && kern->S == 1 && d->precision == AP_PRECISION_BF16X3));
 }
 
 int32_t ap_conv2d_octet_ok(const ap_conv_desc* d) {

@@ -279,6 +279,154 @@ __global__ __launch_bounds__(256) void norm_split_kernel(const NormSplitParams p
     }
 }
 
+// ---- norm_split on a CHANNEL-OCTET raw output (round 6): x is [N][C/8][HW][8] fp32 as ap_conv2d_fwd_octet writes it -- straight from
+// the MFMA accumulator layout, no LDS transposition in the convolution's epilogue -- and the only output is the split copy.  A lane
+// pair owns a pixel (lane = 2 * pixel + half: four channels each), so a wave's loads are 1 KiB contiguous; the 8-channel slot of a
+// pixel is put together with two quad-permute exchanges: the even lane stores the head slot, the odd lane the tail slot -- 512
+// contiguous bytes per plane and wave-instruction, no LDS staging.  Residual: none (RES = 0) or the previous block's split copy
+// (RES = 2: the even lane loads the head slot, the odd lane the tail slot, halves exchanged the same way).  The inference trunk:
+// convolution -> this pass -> convolution (networks.py:2329-2361), 15 of its 24 passes.   grid: (ceil(HW / 512), C / 8, N)
+template <int RES>
+__global__ __launch_bounds__(256) void norm_split_oct_kernel(const NormSplitParams p) {
+    __shared__ float s_m[8], s_r[8];
+    __shared__ int s_bad[8];
+    __shared__ double s_red[2][4];
+    const int cg = blockIdx.y, n = blockIdx.z, C = p.C, HW = p.HW, CG = C >> 3;
+    const int tid = threadIdx.x, half = tid & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float4* xo = reinterpret_cast<const float4*>(p.x) + ((long long)n * CG + cg) * HW * 2;
+    // ---- load phase: nothing but loads (section "load-phase rule" of DESIGN.md)
+    const float2 part0 = *(p.partials != nullptr
+        ? reinterpret_cast<const float2*>(p.partials) + ((long long)n * C + cg * 8 + ((tid >> 3) & 7)) * p.tiles + ((tid & 7) < p.tiles ? (tid & 7) : 0)
+        : reinterpret_cast<const float2*>(p.x));
+    constexpr int VP = 4;
+    float4 xv[VP];
+    uint4 rq[VP];
+    const int pbase = blockIdx.x * (128 * VP) + (tid >> 1);
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        const int px = pbase + j * 128;
+        xv[j] = xo[(long long)(px < HW ? px : 0) * 2 + half];
+    }
+    if constexpr (RES == 2) {
+        const uint4* rp = p.res_xs + ((long long)(n * 2 + half) * CG + cg) * (HW + 1);        // even lane: head plane, odd lane: tail plane
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            const int px = pbase + j * 128;
+            rq[j] = rp[px < HW ? px : 0];
+        }
+    }
+    // ---- statistics from the convolution's partial tiles (as norm_split_kernel; ill-conditioned planes from the data)
+    if (p.partials != nullptr) {
+        if (wave == 0) {
+            const int c = tid >> 3, sub = tid & 7;
+            const float2* pp = reinterpret_cast<const float2*>(p.partials) + ((long long)n * C + cg * 8 + c) * p.tiles;
+            double s = sub < p.tiles ? (double)part0.x : 0.0, q = sub < p.tiles ? (double)part0.y : 0.0;
+            for (int t = sub + 8; t < p.tiles; t += 8) {
+                const float2 v = pp[t];
+                s += (double)v.x;
+                q += (double)v.y;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 8; sh <<= 1) {
+                s += __shfl_xor(s, sh, 64);
+                q += __shfl_xor(q, sh, 64);
+            }
+            if (sub == 0) {
+                const double m = s * p.inv_count;
+                double var = q * p.inv_count - m * m;
+                var = var > 0.0 ? var : 0.0;
+                s_m[c] = (float)m;
+                s_r[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+                s_bad[c] = (m * m > (double)kInstNormRefineRatio * var) ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        for (int c = 0; c < 8; ++c) {
+            if (!s_bad[c]) continue;                           // block-uniform
+            const float m0 = s_m[c];
+            const float* px = p.x + ((long long)n * CG + cg) * HW * 8 + c;
+            double s = 0.0, q = 0.0;
+            for (int k = tid; k < HW; k += 256) {
+                const float d = px[(long long)k * 8] - m0;
+                s += (double)d;
+                q += (double)d * (double)d;
+            }
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                s += __shfl_xor(s, sh, 64);
+                q += __shfl_xor(q, sh, 64);
+            }
+            if ((tid & 63) == 0) { s_red[0][tid >> 6] = s; s_red[1][tid >> 6] = q; }
+            __syncthreads();
+            if (tid == 0) {
+                const double S = (s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]);
+                const double Q = (s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]);
+                const double dm = S * p.inv_count;
+                double var = Q * p.inv_count - dm * dm;
+                var = var > 0.0 ? var : 0.0;
+                s_m[c] = (float)((double)m0 + dm);
+                s_r[c] = (float)(1.0 / sqrt(var + (double)p.eps));
+            }
+            __syncthreads();
+        }
+        if (blockIdx.x == 0 && tid < 8) {
+            p.mean_out[n * C + cg * 8 + tid] = s_m[tid];
+            p.rstd_out[n * C + cg * 8 + tid] = s_r[tid];
+        }
+    } else {
+        if (tid < 8) {
+            s_m[tid] = p.mean != nullptr ? p.mean[n * C + cg * 8 + tid] : 0.f;
+            s_r[tid] = p.mean != nullptr ? p.rstd[n * C + cg * 8 + tid] : 1.f;
+        }
+        __syncthreads();
+    }
+    uint4* const ph = p.xs + ((long long)(n * 2 + 0) * CG + cg) * (HW + 1);
+    uint4* const pl = p.xs + ((long long)(n * 2 + 1) * CG + cg) * (HW + 1);
+    if (blockIdx.x == 0 && tid == 0) ph[HW] = pl[HW] = make_uint4(0u, 0u, 0u, 0u);
+    float m4[4], r4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { m4[i] = s_m[half * 4 + i]; r4[i] = s_r[half * 4 + i]; }
+    const float slope = p.act == 1 ? 0.f : (p.act == 2 ? 0.2f : 1.f);
+    auto swap1 = [](unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); };   // quad_perm [1,0,3,2]: the partner lane's value
+#pragma unroll
+    for (int j = 0; j < VP; ++j) {
+        const int px = pbase + j * 128;
+        float v[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float t = (v[i] - m4[i]) * r4[i];
+            v[i] = fmaxf(t, slope * t);
+        }
+        if constexpr (RES == 2) {
+            // even lane holds the 8 heads (dwords x, y = channels 0-3; z, w = 4-7), odd lane the 8 tails: each needs the head AND tail
+            // dwords of ITS four channels -- the even lane gives away its heads of channels 4-7, the odd lane its tails of channels 0-3
+            const unsigned g0 = swap1(half ? rq[j].x : rq[j].z), g1 = swap1(half ? rq[j].y : rq[j].w);
+            const unsigned hd0 = half ? g0 : rq[j].x, hd1 = half ? g1 : rq[j].y;
+            const unsigned tl0 = half ? rq[j].z : g0, tl1 = half ? rq[j].w : g1;
+            v[0] += __uint_as_float(hd0 << 16) + __uint_as_float(tl0 << 16);
+            v[1] += __uint_as_float(hd0 & 0xffff0000u) + __uint_as_float(tl0 & 0xffff0000u);
+            v[2] += __uint_as_float(hd1 << 16) + __uint_as_float(tl1 << 16);
+            v[3] += __uint_as_float(hd1 & 0xffff0000u) + __uint_as_float(tl1 & 0xffff0000u);
+        }
+        unsigned hw_[2], tw_[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __bf16 h0, l0, h1, l1;
+            split_bf16(p.xs_relu ? fmaxf(v[2 * i], 0.f) : v[2 * i], h0, l0);
+            split_bf16(p.xs_relu ? fmaxf(v[2 * i + 1], 0.f) : v[2 * i + 1], h1, l1);
+            hw_[i] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            tw_[i] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        // the even lane stores the pixel's head slot (its channels 0-3 + the partner's 4-7), the odd lane the tail slot
+        const unsigned o0 = swap1(half ? hw_[0] : tw_[0]), o1 = swap1(half ? hw_[1] : tw_[1]);
+        if (px < HW) {
+            if (!half) ph[px] = make_uint4(hw_[0], hw_[1], o0, o1);
+            else if (!p.heads_only) pl[px] = make_uint4(o0, o1, tw_[0], tw_[1]);
+        }
+    }
+}
+
 // ---- row expansion for the K x K stems with <= 4 input channels (Bf3Cfg ROW mode): the split tensor of the
 // 32-channel map  R[ky * C + c][y][x] = act(IN(x))[c][y + ky - pad][x]   (vertical zero / reflection padding applied
 // here, channels >= K * C zero); the horizontal taps and padding are the 1 x K convolution's.  One lane per pixel;

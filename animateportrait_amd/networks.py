@@ -149,8 +149,12 @@ class ResnetBlock(nn.Module):
             return c5.run_norm(y, act=ACT_NONE, residual=x, want_oct=True)
         # (raw16: c1's raw output is read by c5's split pass, its own InstanceNorm backward and c5's weight gradient; c5's by the
         # residual pass and its InstanceNorm backward -- all of which read bf16: plain-bf16 training stores them as bf16)
-        y = conv_forward(tape, c1, x, norm_act=ACT_RELU, raw16=True)
-        y = conv_forward(tape, c5, y, norm_act=ACT_NONE, raw16=True)
+        # inference: the raw outputs leave in the channel-octet layout where their one reader is a split-only norm pass (ops.trunk_octet_ok)
+        dim = c1.spec.cout
+        keep = consumer is not None and not consumer.stages_split(x.data.shape)
+        y = conv_forward(tape, c1, x, norm_act=ACT_RELU, raw16=True, out_octet=tape is None and ops.trunk_octet_ok(dim))
+        y = conv_forward(tape, c5, y, norm_act=ACT_NONE, raw16=True,
+                         out_octet=tape is None and ops.trunk_octet_ok(dim, residual=x, keep_fp32=keep))
         return materialize_forward(tape, y, residual=x, consumer=consumer)
 
 
@@ -170,7 +174,7 @@ class ResnetBlock2(nn.Module):
             s = sc.run_norm(srcs, act=ACT_NONE, want_oct=True, want_xs=False)
             y = c1.run_norm(srcs, act=ACT_RELU)
             return c5.run_norm(y, act=ACT_NONE, residual=s, want_oct=True)
-        y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU, raw16=True)
+        y = conv_forward(tape, c1, srcs, norm_act=ACT_RELU, raw16=True, out_octet=tape is None and ops.trunk_octet_ok(c1.spec.cout))
         y = conv_forward(tape, c5, y, norm_act=ACT_NONE, raw16=True)
         s = conv_forward(tape, sc, srcs, norm_act=ACT_NONE)            # (the shortcut's raw output is read as a normalised RESIDUAL: fp32)
         return materialize_forward(tape, y, residual=s, consumer=consumer)

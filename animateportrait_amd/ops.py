@@ -483,9 +483,15 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
     split copy is f's own and is cached on it."""
     x = f.data
     n, c, h, w = x.shape
-    _require_device(x, 'norm/split source', allow_bf16=True)
+    oct_src = f.oct is not None          # a channel-octet raw output (conv2d out_octet=True): split copy only, residual none / split-only
+    if oct_src:
+        if want_y or not want_xs or (residual is not None and not residual.is_split_only):
+            raise RuntimeError('a channel-octet raw output is read as a split copy only (no fp32 result, no fp32 residual)')
+        _require_device(f.oct, 'norm/split source')
+    else:
+        _require_device(x, 'norm/split source', allow_bf16=True)
     s = C.ApSrc()
-    s.data, s.C, s.act = x.data_ptr(), c, f.act
+    s.data, s.C, s.act = (f.oct if oct_src else x).data_ptr(), c, f.act
     partial, tiles, mo, ro = None, 0, None, None
     if f.pending is not None:
         partial, tiles = f.pending
@@ -516,7 +522,8 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
     xs = _alloc_xs(x) if want_xs else None
     # plain-bf16 mode: no kernel reads tail planes, so they are not written (the package-wide mode decides: split
     # copies are shared by every consumer of a feature)
-    flags = (1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0) | res_flag | (8 if x.dtype == torch.bfloat16 else 0)
+    flags = ((1 if DEFAULT_PRECISION == PRECISION_BF16 else 0) | (2 if xs_relu else 0) | res_flag |
+             (8 if (x.dtype == torch.bfloat16 and not oct_src) else 0) | (16 if oct_src else 0))
     C.check(C.lib().ap_norm_apply_split_ex(ctypes.byref(s), _ptr(partial), tiles, EPS, _ptr(mo), _ptr(ro),
                                            ctypes.byref(r) if r is not None else None, n, h, w, _ptr(y), _ptr(xs),
                                            flags, _stream()), 'norm_apply_split')
@@ -525,6 +532,20 @@ def _norm_apply_split(f, residual, want_y, want_xs, xs_relu=False):
         f.xs = xs
         f.xs_heads_only = bool(flags & 1)
     return y, xs
+
+
+def trunk_octet_ok(c, residual=None, keep_fp32=False):
+    """Inference: may a trunk convolution whose raw output is read by ONE ap_norm_apply_split pass -- split copy out, residual none
+    or the previous block's split copy -- write the channel-octet layout (no LDS transposition in its epilogue, no LDS staging in
+    the pass)?  Mirrors the conditions under which materialize() keeps only the split copy."""
+    if (DEFAULT_PRECISION != PRECISION_BF16X3 or FUSED_NORM or not RESIDUAL_AS_SPLIT or not OCTET_TRUNK or keep_fp32 or
+            not wants_split(c) or c % 8):
+        return False
+    return residual is None or (residual.is_split_only and residual.xs is not None and not residual.xs_heads_only and residual.oct is None)
+
+
+# the inference trunk's raw outputs in the channel-octet layout (round 6; tests flip it to compare with the NCHW route)
+OCTET_TRUNK = os.environ.get('APAMD_NO_OCTET_TRUNK', '0') != '1'
 
 
 def wants_split(c):

@@ -253,6 +253,39 @@ def test_generator_ngf64_at_the_reported_batch(dev, batch, fused, monkeypatch):
     assert linf(y1, ref[:1]) < 1e-3
 
 
+def test_trunk_raw_outputs_in_the_channel_octet_layout(dev, monkeypatch):
+    """Inference, round 6: the trunk convolutions whose raw output is read by one split-only norm pass write the channel-octet layout
+    (ap_conv2d_fwd_octet on the 3x3 kernel; ap_norm_apply_split_ex flags bit 4 -> norm_split_oct_kernel, residual none or the
+    previous block's split copy).  Same values as the NCHW route up to the order of the statistics' row sums, both within the
+    path's budget of the oracle; B = 2 (4-row tiles) and B = 8 (16-row tiles)."""
+    from animateportrait_amd import networks as N, ops
+    from animateportrait_amd.synthetic import make_generator_inputs, generator_args
+    from oracle import generator as og
+    sd = og.init_params(og.generator_param_shapes(3, 1, 64, 9, 3, 3), seed=21)
+    G = N.define_G(3, 1, 64, 'resnet_9blocks_rcatland32_full_ifw', 'instance', False, 'normal', 0.02, [0], div=3, disp=3)
+    G.load_state_dict(sd, strict=True)
+    for b in (2, 8):
+        args = generator_args(make_generator_inputs(b, seed=21))
+        outs = {}
+        for flag in (True, False):
+            monkeypatch.setattr(ops, 'OCTET_TRUNK', flag)
+            calls = []
+            real = ops._norm_apply_split
+
+            def spy(f, *a, **k):
+                calls.append(f.oct is not None)
+                return real(f, *a, **k)
+            monkeypatch.setattr(ops, '_norm_apply_split', spy)
+            with torch.no_grad():
+                outs[flag] = G(*[a.to(dev) for a in args])
+            monkeypatch.setattr(ops, '_norm_apply_split', real)
+            assert (sum(calls) == 15) if flag else (sum(calls) == 0), (flag, sum(calls), len(calls))
+        with torch.no_grad():
+            ref = og.generator_forward(sd, *args, div=3, disp=3)
+        assert linf(outs[True], outs[False]) < 2e-4            # (InstanceNorm statistics summed in another order: ~6e-5 at ngf 64)
+        assert linf(outs[True], ref) < 1e-3 and linf(outs[False], ref) < 1e-3
+
+
 @pytest.mark.parametrize('ngf', [16, 20])
 def test_generator_width_whose_upconvolution_reads_fp32(dev, ngf):
     """at 4 * ngf in {48, 64, 80} the trunk output qualifies for the split-only residual stream (c >= 48, c % 16 == 0)
@@ -1215,13 +1248,20 @@ def test_conv_channel_octet_output(dev, case):
 
 
 def test_conv_octet_falls_back_to_nchw_where_unsupported(dev):
-    """out_octet is a request: a layer whose kernel has no octet epilogue (3x3 stride-1, fp32 plans) returns NCHW."""
+    """out_octet is a request: a layer whose kernel has no octet epilogue (4x4 stride-1, fp32 plans) returns NCHW; the 3x3 stride-1
+    split-bf16 kernel has one since round 6 (the inference trunk, test_trunk_raw_outputs_in_the_channel_octet_layout)."""
     from animateportrait_amd import ops
     g = torch.Generator().manual_seed(32)
-    l = _layer(dev, torch.randn(64, 64, 3, 3, generator=g) * 0.05, None, stride=1, pad=1, pad_mode=ops.PAD_REFLECT)
+    l = _layer(dev, torch.randn(64, 64, 4, 4, generator=g) * 0.05, None, stride=1, pad=1, pad_mode=ops.PAD_ZERO)
     x = torch.randn(1, 64, 32, 32, generator=g).to(dev)
     out = l.run([ops.Feat(x)], norm_act=ops.ACT_RELU, out_octet=True)
     assert out.oct is None and out.data.is_contiguous()
+    l3 = _layer(dev, torch.randn(64, 64, 3, 3, generator=g) * 0.05, None, stride=1, pad=1, pad_mode=ops.PAD_REFLECT)
+    out3 = l3.run([ops.Feat(x)], norm_act=ops.ACT_RELU, out_octet=True)
+    ref3 = l3.run([ops.Feat(x)], norm_act=ops.ACT_RELU)
+    assert out3.oct is not None and out3.oct.shape == (1, 8, 32 * 32, 8)
+    assert torch.equal(out3.oct.permute(0, 1, 3, 2).reshape(1, 64, 32, 32), ref3.data)          # the same accumulators, another layout
+    assert linf(out3.mean, ref3.mean) < 1e-6 and linf(out3.rstd, ref3.rstd) < 1e-5
 
 
 @pytest.mark.parametrize('level', [0, 1, 2])
