@@ -669,7 +669,8 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
                     const long long ohw = (long long)p.OH * p.OW;
                     // (round 6) every cout, row and column of the tile inside the tensor, no bias, no activation -- tested once, wave-uniform:
                     // the stores and sums below then run without the per-lane test (see fast32)
-                    const bool allv = __builtin_amdgcn_readfirstlane((int)(p.bias == nullptr && ACT == 0 && co_base + MT * 32 <= p.Cout &&
+                    const bool allv = !(C::WG_PER_CU == 2 && (C::K == 0 || (C::ROW && C::MT == 2))) &&
+                                      __builtin_amdgcn_readfirstlane((int)(p.bias == nullptr && ACT == 0 && co_base + MT * 32 <= p.Cout &&
                                                                            oy0 + C::TH <= p.OH && ox0 + 32 <= p.OW)) != 0;
 #pragma unroll
                     for (int m = 0; m < MT; ++m) {
@@ -837,7 +838,11 @@ __global__ __launch_bounds__(256, C::WG_PER_CU) void conv_bf16x3(const ConvKPara
             // the tile's ~150 k cycles WITH OR WITHOUT the global stores (profiles/r06_epilogue_account.md: APAMD_ABLATE=16 removes
             // the stores and the segment stays at 14.9 k) -- the epilogue was bound by its own control flow, not by store issue.
             bool fast32 = false;
-            if constexpr (!C::OB16) {
+            // (not where two workgroups share a CU's registers and the instantiation is already at its 256-register cap: the
+            // run-time-tap family and the tall row tile of plain-bf16 arithmetic spilled 230-400 bytes with the extra path --
+            // tests/test_isa_cpu.py)
+            constexpr bool FAST_OK = !C::OB16 && !(C::WG_PER_CU == 2 && (C::K == 0 || (C::ROW && C::MT == 2)));
+            if constexpr (FAST_OK) {
                 fast32 = __builtin_amdgcn_readfirstlane((int)(!octet && full && p.bias == nullptr && ACT == 0 && p.osy == 1 &&
                                                               co_base + MT * 32 <= p.Cout && oy0 + C::TH <= p.OH)) != 0;
                 if (fast32) {

@@ -193,7 +193,9 @@ int ap_conv2d_fwd_view(const ap_conv_desc* d, const ap_out_view* view, const flo
  * layers in front of double_feature_warping (networks.py:1317-1328: model_tri00, model_tri11, model_tri22) write it in
  * inference, so that a bilinear tap of 8 channels is one 32-byte read instead of 8 reads from 8 planes.  Statistics as
  * ap_conv2d_fwd (finalise with ap_instnorm_finalize_octet).  Only where ap_conv2d_octet_ok(d) == 1: single-launch
- * split-bf16 layers of the run-time-tap (2x2 space-to-depth) and row (7x7 stem) kernel families, Cout % 8 == 0. */
+ * split-bf16 layers of the run-time-tap (2x2 space-to-depth) and row (7x7 stem) kernel families and (round 6) the dense 3x3
+ * stride-1 kernel in AP_PRECISION_BF16X3 -- the ResNet trunk's convolutions in inference (networks.py:2329-2361), whose raw output
+ * is then read by ap_norm_apply_split_ex with flags bit 4; Cout % 8 == 0. */
 int32_t ap_conv2d_octet_ok(const ap_conv_desc* d);
 int ap_conv2d_fwd_octet(const ap_conv_desc* d, const float* packed, const float* bias, float* y, float* stat_partials,
                         ap_stream_t stream);
@@ -245,7 +247,9 @@ int ap_norm_apply_split(const ap_src* src, const float* stat_partials, int32_t t
  * next layer of a pre-activation residual stream: ResidualBlock of intrinsic_flow_models/networks.py:26-60); bit 2 =
  * residual->data is the residual's SPLIT COPY (head + tail planes, ap_split_prepass layout; mean / rstd must be NULL): in
  * inference the residual stream of the ResNet trunk (x + conv_block(x), networks.py:2358-2360) then lives only in the form the
- * next convolution stages, and the fp32 output y is not needed (pass NULL) */
+ * next convolution stages, and the fp32 output y is not needed (pass NULL); bit 3 = src->data holds bf16 values
+ * (ap_conv2d_fwd_bf16out); bit 4 = src->data is the CHANNEL-OCTET raw output of ap_conv2d_fwd_octet ([N][C/8][H*W][8] fp32): the
+ * only output is then the split copy (y must be NULL), the residual absent or a split copy (bit 2) */
 int ap_norm_apply_split_ex(const ap_src* src, const float* stat_partials, int32_t tiles, float eps, float* mean_out,
                            float* rstd_out, const ap_src* residual, int32_t N, int32_t H, int32_t W, float* y, void* xs,
                            int32_t flags, ap_stream_t stream);
