@@ -62,7 +62,7 @@ class ApWgradDesc(ctypes.Structure):
 
 
 # name -> (restype, argtypes); every symbol include/animateportrait_amd.h declares
-ABI_VERSION = 12     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
+ABI_VERSION = 13     # AP_ABI_VERSION of include/animateportrait_amd.h this binding was written against
 
 SIGNATURES = {
     'ap_abi_version': (ctypes.c_int32, []),
@@ -131,6 +131,10 @@ SIGNATURES = {
     'ap_conv_final_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]),
     'ap_conv_final_wgrad': (ctypes.c_int, [ctypes.POINTER(ApSrc), c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p]),
+    'ap_wgrad_k7_bf16_ok': (ctypes.c_int32, [ctypes.c_int32] * 6),
+    'ap_wgrad_k7_bf16_workspace_floats': (ctypes.c_int64, [ctypes.c_int32] * 6),
+    'ap_wgrad_k7_bf16': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                        ctypes.c_int32, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.POINTER(ApWgradDesc)]),
     'ap_pad_materialize': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

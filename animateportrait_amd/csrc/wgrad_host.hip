@@ -10,6 +10,7 @@
 #include "wgrad_igemm.h"
 #include "wgrad_narrow.h"
 #include "wgrad_final.h"
+#include "wgrad_k7.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -559,6 +560,86 @@ int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H,
     const long long n = (long long)src->C * 49;
     launch_wgrad_reduce(stream, workspace, P, n, dw);
     return check_launch("wgrad_reduce_kernel");
+}
+
+// ---- the 7x7 edge layers at full resolution on the bf16 matrix pipe (wgrad_k7.h; plain-bf16 arithmetic)
+struct K7Plan {
+    int MT, NT, R, A, NW, RB, bpi, grid;
+    long long narrow_floats, part_floats;
+    size_t lds;
+};
+static bool k7_plan(int N, int MW, int CN, int H, int W, int final_form, K7Plan& k) {
+    if (N < 1 || H < 4 || W < 16 || W > 256 || (W & 15) || (MW != 32 && MW != 64)) return false;
+    if (final_form ? CN != 1 : (CN != 1 && CN != 3)) return false;
+    k.MT = MW / 32;
+    k.NT = (CN * 49 + 31) / 32;
+    k.R = final_form ? H + 6 : H;
+    k.A = k.R + 6;
+    k.NW = W + 16;
+    int bpi = std::max(1, (num_cus_w() + N - 1) / N);
+    if (bpi > k.R / 2) bpi = std::max(1, k.R / 2);
+    k.RB = (k.R + bpi - 1) / bpi;
+    k.RB += k.RB & 1;
+    k.bpi = (k.R + k.RB - 1) / k.RB;
+    k.grid = N * k.bpi;
+    k.narrow_floats = round4(((long long)N * CN * k.A * 2 * k.NW + 1) / 2);
+    k.part_floats = (long long)k.grid * k.MT * k.NT * 1024;
+    const size_t tiles = (size_t)k.MT * 32 * ((W + 8) * 2 + 16) + (size_t)8 * CN * 2 * (k.NW + 8) * 2;
+    const size_t red = (size_t)k.MT * k.NT * 16 * 64 * 4;
+    k.lds = std::max(tiles, red);
+    return true;
+}
+
+int32_t ap_wgrad_k7_bf16_ok(int32_t N, int32_t MW, int32_t CN, int32_t H, int32_t W, int32_t final_form) {
+    K7Plan k;
+    return k7_plan(N, MW, CN, H, W, final_form, k) ? 1 : 0;
+}
+
+int64_t ap_wgrad_k7_bf16_workspace_floats(int32_t N, int32_t MW, int32_t CN, int32_t H, int32_t W, int32_t final_form) {
+    K7Plan k;
+    if (!k7_plan(N, MW, CN, H, W, final_form, k)) return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: shape not served (see ap_wgrad_k7_bf16_ok)");
+    return k.narrow_floats + k.part_floats;
+}
+
+int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_t H, int32_t W, int32_t final_form, float* workspace,
+                     float* dw, ap_stream_t stream_) {
+    if (!wide || !wide->data || !narrow || !narrow->data || !workspace || !dw) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: null pointer");
+    if ((wide->mean == nullptr) != (wide->rstd == nullptr)) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: mean/rstd mismatch");
+    if (narrow->mean || narrow->rstd || narrow->act != AP_ACT_NONE)
+        return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: the narrow operand must be a plain tensor");
+    if (wide->act < 0 || wide->act > 2) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: act %d", wide->act);
+    if (!final_form && (wide->mean || wide->act != AP_ACT_NONE))
+        return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: the stem form takes a plain gradient");
+    K7Plan k;
+    if (!k7_plan(N, wide->C, narrow->C, H, W, final_form, k))
+        return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: N=%d wide C=%d narrow C=%d %dx%d form %d not served", N, wide->C, narrow->C, H, W, final_form);
+    hipStream_t stream = (hipStream_t)stream_;
+    K7NarrowParams np;
+    np.src = narrow->data; np.dst = reinterpret_cast<unsigned*>(workspace);
+    np.N = N; np.CN = narrow->C; np.H = H; np.W = W; np.A = k.A; np.NW = k.NW; np.final_form = final_form;
+    const long long ndw = (long long)N * narrow->C * k.A * (k.NW / 2);
+    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
+    int rc = check_launch("wgrad_k7_narrow_kernel");
+    if (rc) return rc;
+    WgradK7Params p;
+    memset(&p, 0, sizeof(p));
+    p.wide = wide->data; p.wmean = wide->mean; p.wrstd = wide->rstd; p.wact = wide->act;
+    p.narrow = reinterpret_cast<const unsigned short*>(workspace);
+    p.N = N; p.MW = wide->C; p.CN = narrow->C; p.H = H; p.W = W; p.R = k.R; p.A = k.A; p.NW = k.NW; p.RB = k.RB; p.blocks_per_img = k.bpi;
+    p.partial = workspace + k.narrow_floats;
+    const void* fn = nullptr;
+    if (final_form) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 2, true> : &wgrad_k7_kernel<1, 2, true>);
+    else if (k.NT == 5) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 5, false> : &wgrad_k7_kernel<1, 5, false>);
+    else fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 2, false> : &wgrad_k7_kernel<1, 2, false>);
+    rc = ensure_wattr(fn);
+    if (rc) return rc;
+    void* args[] = {&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(k.grid), dim3(256), args, k.lds, stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_k7 launch: %s", hipGetErrorString(e));
+    const int total = k.MT * k.NT * 1024;
+    hipLaunchKernelGGL(wgrad_k7_reduce_kernel, dim3(total / 64), dim3(256), 0, stream, p.partial, k.grid, total, k.NT, wide->C, narrow->C,
+                       final_form, dw);
+    return check_launch("wgrad_k7_reduce_kernel");
 }
 
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {

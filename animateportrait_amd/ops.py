@@ -659,6 +659,8 @@ FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
 # Inference: the ResNet trunk's residual stream is kept only as split copies (materialize keep_fp32=False; HISTORY.md section 3.10).
 # (tests flip the flag to compare with the fp32 stream)
 RESIDUAL_AS_SPLIT = True
+# plain-bf16 arithmetic: the 7x7 edge layers' weight gradients on the bf16 matrix pipe (wgrad_k7.h); 0: the fp32 / vector-ALU kernels (A/B)
+K7_WGRAD = os.environ.get('APAMD_NO_K7_WGRAD', '0') != '1'
 
 
 def fused_norm_ok(spec, srcs):
@@ -946,6 +948,34 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
         C.check(C.lib().ap_conv_head_wgrad(ctypes.byref(s), _ptr(g.data), n, f.data.shape[2], f.data.shape[3], k, pad,
                                            _ptr(dw), _stream()), 'conv_head_wgrad')
         return dw
+    prec = DEFAULT_PRECISION if precision is None else precision
+    if (K7_WGRAD and prec == PRECISION_BF16 and k == 7 and stride == 1 and pad == 3 and pad_mode == PAD_REFLECT and len(srcs) == 1 and
+            g_t is None and g_xs is None and not g.virtual and g.act == ACT_NONE and g.data.dtype == torch.float32 and
+            srcs[0].data.dtype == torch.float32):
+        # the 7x7 edge layers at full resolution, plain-bf16 arithmetic: one pass over the wide tensor on the bf16 matrix pipe
+        # (wgrad_k7.h) -- the stems (wide = the gradient) and the last layer (wide = the input)
+        f = srcs[0]
+        h, w = f.data.shape[2:]
+        final_form = 1 if (m == 1 and cin >= 32) else 0
+        wide, narrow = (f, g) if final_form else (g, f)
+        ok = ((final_form or not f.virtual and f.act == ACT_NONE) and tuple(out_shape) == (m, cin, k, k) and
+              C.lib().ap_wgrad_k7_bf16_ok(n, wide.data.shape[1], narrow.data.shape[1], h, w, final_form) == 1)
+        if ok:
+            _require_device(f.data, 'wgrad source')
+            _require_device(g.data, 'wgrad gradient')
+            sw, sn = C.ApSrc(), C.ApSrc()
+            sw.data, sw.C, sw.act = wide.data.data_ptr(), wide.data.shape[1], wide.act
+            if wide.virtual:
+                sw.mean, sw.rstd = wide.mean.data_ptr(), wide.rstd.data_ptr()
+            sn.data, sn.C, sn.act = narrow.data.data_ptr(), narrow.data.shape[1], ACT_NONE
+            ws = torch.empty(C.check(C.lib().ap_wgrad_k7_bf16_workspace_floats(n, sw.C, sn.C, h, w, final_form), 'wgrad_k7_ws'),
+                             dtype=torch.float32, device=g.data.device)
+            dw = _grad_out(out, out_shape, g.data.device)
+            if PROFILER is not None:
+                PROFILER.note('wgrad_k7<%s>' % ('final' if final_form else 'stem'))
+            C.check(C.lib().ap_wgrad_k7_bf16(ctypes.byref(sw), ctypes.byref(sn), n, h, w, final_form, _ptr(ws), _ptr(dw), _stream()),
+                    'wgrad_k7_bf16')
+            return dw
     if (m == 1 and k == 7 and stride == 1 and pad == 3 and len(srcs) == 1 and cin >= 16 and not g.virtual and
             g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k)):
         # the generator's last layer: vector-ALU kernel, window through LDS (wgrad_final.h)

@@ -101,7 +101,7 @@ typedef struct ap_conv_desc {
  * ap_instnorm_finalize and gave ap_conv_desc.reserved a meaning as s2d_k without one).  A binding compares
  * ap_abi_version() with the AP_ABI_VERSION it was written against at load time and refuses a mismatch
  * (animateportrait_amd/_capi.py does). */
-#define AP_ABI_VERSION 12
+#define AP_ABI_VERSION 13
 int32_t ap_abi_version(void);
 const char* ap_version(void);
 const char* ap_last_error(void);
@@ -367,6 +367,20 @@ int ap_conv_head_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, 
 int64_t ap_conv_final_wgrad_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
 int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H, int32_t W, int32_t K, int32_t pad,
                         int32_t pad_mode, float* workspace, float* dw, ap_stream_t stream);
+/* Weight gradients of the 7x7 pad-3 (reflection) edge layers at full resolution on the bf16 matrix pipe, plain-bf16 arithmetic
+ * (operands rounded to bf16, fp32 accumulation; csrc/wgrad_k7.h).  A WIDE tensor (C = 32 or 64 channels, read once) against the 49
+ * shifted views of a NARROW one:
+ *   final_form = 0 (the stems, networks.py:1251-1260): wide = the layer's output gradient [N][M][H][W] (plain), narrow = its
+ *       input [N][C][H][W] (C = 1 or 3, plain):  dw[m][c][ky][kx] = sum g[n,m,y,x] * reflpad3(in)[n,c,y+ky,x+kx];
+ *   final_form = 1 (the last layer, networks.py:1277-1279; replaces ap_conv_final_wgrad in this arithmetic): wide = the layer's
+ *       input (InstanceNorm + activation of wide->mean / rstd / act applied on the fly), narrow = the one-channel output gradient:
+ *       dw[0][c][ky][kx] = sum g[n,0,y,x] * reflpad3(act(IN(src)))[n,c,y+ky,x+kx].
+ * Served shapes: ap_wgrad_k7_bf16_ok() == 1 (W a multiple of 16 in 16..256, H >= 4); everything else AP_ERR_UNSUPPORTED.
+ * workspace: ap_wgrad_k7_bf16_workspace_floats() floats.  Fixed summation order. */
+int32_t ap_wgrad_k7_bf16_ok(int32_t N, int32_t wide_C, int32_t narrow_C, int32_t H, int32_t W, int32_t final_form);
+int64_t ap_wgrad_k7_bf16_workspace_floats(int32_t N, int32_t wide_C, int32_t narrow_C, int32_t H, int32_t W, int32_t final_form);
+int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_t H, int32_t W, int32_t final_form,
+                     float* workspace, float* dw, ap_stream_t stream);
 /* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
  * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);

@@ -319,3 +319,62 @@ def test_train_step_bf16_mode_vs_fp64_oracle(dev, monkeypatch, width, nb):
     assert all(np.isfinite(v) for v in losses.values()), losses
     step = float((model.netG_A.model_tri_merge.weight - w0).abs().max())
     assert 0 < step < 3 * 5e-5
+
+
+K7_CASES = [
+    # name, final form, wide channels, narrow channels, N, H, W
+    ('stem 3->64', 0, 64, 3, 2, 20, 48),
+    ('stem 3->32, odd rows', 0, 32, 3, 3, 37, 64),
+    ('stem 1->64', 0, 64, 1, 1, 16, 16),
+    ('stem 3->64 at 256 columns', 0, 64, 3, 1, 12, 256),
+    ('final 64->1', 1, 64, 1, 2, 24, 32),
+    ('final 32->1, odd rows', 1, 32, 1, 3, 19, 80),
+    ('final 64->1 at 256 columns', 1, 64, 1, 1, 9, 256),
+]
+
+
+@pytest.mark.parametrize('case', K7_CASES, ids=[c[0] for c in K7_CASES])
+def test_k7_edge_layer_wgrad_on_the_matrix_pipe(dev, case):
+    """ap_wgrad_k7_bf16 (csrc/wgrad_k7.h): the 7x7 reflection-padded edge layers' weight gradients in plain-bf16 arithmetic are the
+    fp32-accumulated sums of bf16-rounded operands -- stems (networks.py:1251-1260) and the last layer (networks.py:1277-1279,
+    whose input arrives with its InstanceNorm + ReLU still to be applied)."""
+    from animateportrait_amd import ops
+    name, final_form, mw, cn, n, H, W = case
+    gen = torch.Generator().manual_seed(11 + sum(map(ord, name)))
+    if final_form:
+        x = torch.randn(n, mw, H, W, generator=gen) * 1.3 + 0.2
+        mean = torch.randn(n * mw, generator=gen) * 0.1
+        rstd = torch.rand(n * mw, generator=gen) + 0.5
+        gy = torch.randn(n, 1, H, W, generator=gen)
+        src = ops.Feat(x.to(dev), mean.to(dev), rstd.to(dev), ops.ACT_RELU)
+        xin = F.relu((x.double() - mean.double().view(n, mw, 1, 1)) * rstd.double().view(n, mw, 1, 1))
+        xin32 = F.relu((x - mean.view(n, mw, 1, 1)) * rstd.view(n, mw, 1, 1))      # as the kernel forms it, in fp32
+        out_shape, cin = (1, mw, 7, 7), mw
+    else:
+        x = torch.randn(n, cn, H, W, generator=gen)
+        gy = torch.randn(n, mw, H, W, generator=gen)
+        src = ops.Feat(x.to(dev))
+        xin, xin32 = x.double(), x
+        out_shape, cin = (mw, cn, 7, 7), cn
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    try:
+        dw = ops.wgrad(7, 1, 3, ops.PAD_REFLECT, ops.Feat(gy.to(dev)), [src], out_shape, precision=ops.PRECISION_BF16)
+    finally:
+        ops.PROFILER = None
+    assert prof.calls.get('wgrad_k7<%s>' % ('final' if final_form else 'stem')) == 1, prof.calls
+
+    def wgrad_ref(xv, gv):
+        w = torch.zeros(out_shape, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(F.pad(xv, (3,) * 4, mode='reflect'), w) * gv).sum().backward()
+        return w.grad
+    ref16 = wgrad_ref(r16(xin32), r16(gy))
+    exact = wgrad_ref(xin, gy.double())
+    sc = float(ref16.abs().max())
+    e16, eex = linf(dw, ref16) / sc, linf(dw, exact) / sc
+    assert e16 < 3e-5, (name, e16, eex)
+    # the same layer on the exact kernels differs from the bf16 sums by the operands' rounding: the route is not a relabelled fp32 one
+    assert eex > 10 * e16, (name, e16, eex)
+    # and the call is deterministic (fixed summation order)
+    dw2 = ops.wgrad(7, 1, 3, ops.PAD_REFLECT, ops.Feat(gy.to(dev)), [src], out_shape, precision=ops.PRECISION_BF16)
+    assert torch.equal(dw, dw2)
