@@ -219,7 +219,11 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         if out.data.dtype != torch.float32:      # (a bf16 raw output whose backward takes the fp32 route after all: convert once)
             out = Feat(out.data.float(), out._mean, out._rstd, out.act)
             contribs = [(g.float() if g.dtype != torch.float32 else g, pd) for g, pd in contribs]
-        dy = ops.instnorm_bwd(contribs, out) if norm else ops.act_bwd(contribs, out.data, act)
+        # a stem (no data gradient: its input is an image) whose weight gradient runs on the bf16 matrix pipe: dy has one reader,
+        # which rounds it to bf16 -- it is stored that way (ops.instnorm_bwd out_bf16)
+        dy16 = (norm and layer.weight.requires_grad and not any(tape.tracked(f) for f in srcs) and
+                ops.k7_stem_wgrad_ok(s, tuple(out.data.shape), srcs))
+        dy = ops.instnorm_bwd(contribs, out, out_bf16=dy16) if norm else ops.act_bwd(contribs, out.data, act)
         gfeat = Feat(dy)
         # split-bf16 layers served by ap_conv2d_wgrad_xs (3x3, the PatchGAN's 4x4): the gradient's split copy -- which the data-gradient
         # convolution stages anyway (cached on the Feat) -- is the weight gradient's operand too: no operand preparation

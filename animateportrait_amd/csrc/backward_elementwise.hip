@@ -611,7 +611,9 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_split_kernel(const InBwdSplit
 // activated gradient of the first 8 groups stays in registers, the other 8 are parked in LDS (128 KiB); the normalised
 // activation is recomputed from a second read of y, which the plane's first pass left in the memory-side cache --
 // 2 + (1 cached) reads + 1 write per element instead of the 4 + 1 of the reduce / apply pair.  grid: (N*C)
-template <bool FOLD>
+// OB16: dy is stored as bf16 values (its one reader is the stems' weight gradient on the bf16 matrix pipe, wgrad_k7.h, which rounds
+// it to bf16 anyway: half the bytes written here and read there)
+template <bool FOLD, bool OB16 = false>
 __global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const float* __restrict__ g1, int p1,
                                                                      const float* __restrict__ g2,
                                                                      const float* __restrict__ y,
@@ -669,8 +671,10 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const floa
         const int i = k * 1024 + tid;
         if (i < Q) {
             const float4 yv = y4[i];
-            o4[i] = make_float4(r * (g.x - a1 - (yv.x - m) * r * a2), r * (g.y - a1 - (yv.y - m) * r * a2),
-                                r * (g.z - a1 - (yv.z - m) * r * a2), r * (g.w - a1 - (yv.w - m) * r * a2));
+            const float4 o = make_float4(r * (g.x - a1 - (yv.x - m) * r * a2), r * (g.y - a1 - (yv.y - m) * r * a2),
+                                         r * (g.z - a1 - (yv.z - m) * r * a2), r * (g.w - a1 - (yv.w - m) * r * a2));
+            if constexpr (OB16) reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(dy) + (long long)nc * HW)[i] = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+            else o4[i] = o;
         }
     };
 #pragma unroll
@@ -844,8 +848,12 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
     int rc = fold_args_ok(g1, g1_pad, H, W, "instnorm_bwd");
     if (rc) return rc;
     if (!y || !mean || !rstd || !sums_ws || !dy) return fail(AP_ERR_INVALID, "instnorm_bwd: null pointer");
+    const bool ob16 = (act & 0x100) != 0;       // bit 8: dy is stored as bf16 values (256 x 256-class planes without a fold only)
+    act &= 0xff;
     if (act < 0 || act > 2) return fail(AP_ERR_INVALID, "instnorm_bwd: act %d", act);
     if (NC < 1 || NC > 65535) return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: N*C=%d", NC);
+    if (ob16 && !(g1_pad == 0 && H * W > 16384 && H * W <= 65536 && (W % 4) == 0))
+        return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: a bf16 dy is written by the big-plane kernel only (%dx%d, fold %d)", H, W, g1_pad);
     constexpr bool fused_ok = true;
     if (fused_ok && H * W <= 4096) {
         hipLaunchKernelGGL((instnorm_bwd_fused_kernel<256, 16>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2,
@@ -866,10 +874,16 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
             if (e == hipSuccess)
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel<true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(&instnorm_bwd_fused_big_kernel<false, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr = true;
         }
-        if (g1_pad == 0)
+        if (ob16)
+            hipLaunchKernelGGL((instnorm_bwd_fused_big_kernel<false, true>), dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g1_pad,
+                               g2, y, mean, rstd, act, H, W, dy);
+        else if (g1_pad == 0)
             hipLaunchKernelGGL(instnorm_bwd_fused_big_kernel<false>, dim3(NC), dim3(1024), lds, (hipStream_t)stream, g1, g1_pad,
                                g2, y, mean, rstd, act, H, W, dy);
         else

@@ -607,9 +607,12 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
     if ((wide->mean == nullptr) != (wide->rstd == nullptr)) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: mean/rstd mismatch");
     if (narrow->mean || narrow->rstd || narrow->act != AP_ACT_NONE)
         return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: the narrow operand must be a plain tensor");
-    if (wide->act < 0 || wide->act > 2) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: act %d", wide->act);
-    if (!final_form && (wide->mean || wide->act != AP_ACT_NONE))
+    const bool wb16 = (wide->act & 0x100) != 0;                  // ap_src.act bit 8: the tensor holds bf16 values
+    const int wact = wide->act & 0xff;
+    if (wact < 0 || wact > 2) return fail(AP_ERR_INVALID, "wgrad_k7_bf16: act %d", wact);
+    if (!final_form && (wide->mean || wact != AP_ACT_NONE))
         return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: the stem form takes a plain gradient");
+    if (final_form && wb16) return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: a bf16-stored wide operand is read in the stem form only");
     K7Plan k;
     if (!k7_plan(N, wide->C, narrow->C, H, W, final_form, k))
         return fail(AP_ERR_UNSUPPORTED, "wgrad_k7_bf16: N=%d wide C=%d narrow C=%d %dx%d form %d not served", N, wide->C, narrow->C, H, W, final_form);
@@ -623,13 +626,15 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
     if (rc) return rc;
     WgradK7Params p;
     memset(&p, 0, sizeof(p));
-    p.wide = wide->data; p.wmean = wide->mean; p.wrstd = wide->rstd; p.wact = wide->act;
+    p.wide = wide->data; p.wmean = wide->mean; p.wrstd = wide->rstd; p.wact = wact;
     p.narrow = reinterpret_cast<const unsigned short*>(workspace);
     p.N = N; p.MW = wide->C; p.CN = narrow->C; p.H = H; p.W = W; p.R = k.R; p.A = k.A; p.NW = k.NW; p.RB = k.RB; p.blocks_per_img = k.bpi;
     p.partial = workspace + k.narrow_floats;
     const void* fn = nullptr;
     if (final_form) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 2, true> : &wgrad_k7_kernel<1, 2, true>);
+    else if (k.NT == 5 && wb16) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 5, false, true> : &wgrad_k7_kernel<1, 5, false, true>);
     else if (k.NT == 5) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 5, false> : &wgrad_k7_kernel<1, 5, false>);
+    else if (wb16) fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 2, false, true> : &wgrad_k7_kernel<1, 2, false, true>);
     else fn = reinterpret_cast<const void*>(k.MT == 2 ? &wgrad_k7_kernel<2, 2, false> : &wgrad_k7_kernel<1, 2, false>);
     rc = ensure_wattr(fn);
     if (rc) return rc;

@@ -32,6 +32,7 @@
 // Partial sums leave in accumulator order, partial[workgroup][tile][reg][lane]; wgrad_k7_reduce_kernel adds the workgroups in
 // fixed order and scatters into OIHW.
 #pragma once
+#include <type_traits>
 #include <utility>
 
 #include "conv_igemm.h"
@@ -79,7 +80,7 @@ static __global__ __launch_bounds__(256) void wgrad_k7_narrow_kernel(const K7Nar
 }
 
 struct WgradK7Params {
-    const float* wide;        // [N][MW][H][W]
+    const float* wide;        // [N][MW][H][W] (fp32, or bf16 values: wgrad_k7_kernel<.., WB16>)
     const float* wmean;       // [N*MW] or null: InstanceNorm of the wide operand ...
     const float* wrstd;
     int wact;                 // ... and its activation (AP_ACT_*)
@@ -88,9 +89,12 @@ struct WgradK7Params {
     float* partial;           // [gridDim.x][MT*NT][16][64]
 };
 
-template <int MT, int NT, bool FINAL>
+// WB16: the wide tensor holds bf16 values (the stems' gradient as ap_instnorm_bwd stores it on request): half the bytes, no conversion
+template <int MT, int NT, bool FINAL, bool WB16 = false>
 static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Params p) {
+    static_assert(!(FINAL && WB16), "bf16 wide operand: the stem form");
     constexpr int CPW = MT * 8;                                     // channel rows per wave and tile
+    using QT = std::conditional_t<WB16, uint2, float4>;             // four pixels of a channel row, as loaded
     extern __shared__ __attribute__((aligned(16))) unsigned char k7_smem[];
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,15 +154,18 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
     };
     auto narrow_dst = [&](int a) { return reinterpret_cast<uint4*>(nar_l + (a & 7) * SLOT + ncopyrow * NWLB) + nk; };
 
-    float4 q[2][CPW];
+    QT q[2][CPW];
     uint4 nq0, nq1;
     const bool wact_lane = 4 * lane < W;
     auto issue = [&](auto setc, int r) __attribute__((always_inline)) {
         constexpr int set = decltype(setc)::value;
         const int srow = FINAL ? reflect_clamp(r - 3, H) : r;
-        const float* base = p.wide + (((long long)n * p.MW + wave * CPW) * H + srow) * W + (wact_lane ? 4 * lane : 0);
+        const long long e0 = (((long long)n * p.MW + wave * CPW) * H + srow) * W + (wact_lane ? 4 * lane : 0);
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) q[set][i] = *reinterpret_cast<const float4*>(base + (long long)i * H * W);
+        for (int i = 0; i < CPW; ++i) {
+            if constexpr (WB16) q[set][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.wide) + e0 + (long long)i * H * W);
+            else q[set][i] = *reinterpret_cast<const float4*>(p.wide + e0 + (long long)i * H * W);
+        }
         if constexpr (set == 0) nq0 = *narrow_src(r + 6);
         else nq1 = *narrow_src(r + 6);
     };
@@ -166,20 +173,24 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
         constexpr int set = decltype(setc)::value;
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
-            float v[4] = {q[set][i].x, q[set][i].y, q[set][i].z, q[set][i].w};
-            if constexpr (FINAL) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float t = (v[k] - wm[i]) * wr[i];
-                    v[k] = t > 0.f ? t : slope * t;
-                }
-            }
             const int ch = wave * CPW + i;
-            if (wact_lane) *reinterpret_cast<uint2*>(wide_l + ch * WSB + 8 * lane) = make_uint2(k7_pack(v[0], v[1]), k7_pack(v[2], v[3]));
-            if constexpr (FINAL) {
-                // border block: k-slots 0..2 = columns 3, 2, 1 (q = 0, 1, 2); 4..6 = columns W-2, W-3, W-4 (q = W+3, W+4, W+5)
-                if (lane == 0) *reinterpret_cast<uint2*>(bord_l + ch * 16) = make_uint2(k7_pack(v[3], v[2]), k7_pack(v[1], 0.f));
-                if (lane == (W >> 2) - 1) *reinterpret_cast<uint2*>(bord_l + ch * 16 + 8) = make_uint2(k7_pack(v[2], v[1]), k7_pack(v[0], 0.f));
+            if constexpr (WB16) {
+                if (wact_lane) *reinterpret_cast<uint2*>(wide_l + ch * WSB + 8 * lane) = q[set][i];
+            } else {
+                float v[4] = {q[set][i].x, q[set][i].y, q[set][i].z, q[set][i].w};
+                if constexpr (FINAL) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = (v[k] - wm[i]) * wr[i];
+                        v[k] = t > 0.f ? t : slope * t;
+                    }
+                }
+                if (wact_lane) *reinterpret_cast<uint2*>(wide_l + ch * WSB + 8 * lane) = make_uint2(k7_pack(v[0], v[1]), k7_pack(v[2], v[3]));
+                if constexpr (FINAL) {
+                    // border block: k-slots 0..2 = columns 3, 2, 1 (q = 0, 1, 2); 4..6 = columns W-2, W-3, W-4 (q = W+3, W+4, W+5)
+                    if (lane == 0) *reinterpret_cast<uint2*>(bord_l + ch * 16) = make_uint2(k7_pack(v[3], v[2]), k7_pack(v[1], 0.f));
+                    if (lane == (W >> 2) - 1) *reinterpret_cast<uint2*>(bord_l + ch * 16 + 8) = make_uint2(k7_pack(v[2], v[1]), k7_pack(v[0], 0.f));
+                }
             }
         }
         if (nact) *narrow_dst(r + 6) = set == 0 ? nq0 : nq1;

@@ -950,8 +950,7 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
         return dw
     prec = DEFAULT_PRECISION if precision is None else precision
     if (K7_WGRAD and prec == PRECISION_BF16 and k == 7 and stride == 1 and pad == 3 and pad_mode == PAD_REFLECT and len(srcs) == 1 and
-            g_t is None and g_xs is None and not g.virtual and g.act == ACT_NONE and g.data.dtype == torch.float32 and
-            srcs[0].data.dtype == torch.float32):
+            g_t is None and g_xs is None and not g.virtual and g.act == ACT_NONE and srcs[0].data.dtype == torch.float32):
         # the 7x7 edge layers at full resolution, plain-bf16 arithmetic: one pass over the wide tensor on the bf16 matrix pipe
         # (wgrad_k7.h) -- the stems (wide = the gradient) and the last layer (wide = the input)
         f = srcs[0]
@@ -959,12 +958,14 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
         final_form = 1 if (m == 1 and cin >= 32) else 0
         wide, narrow = (f, g) if final_form else (g, f)
         ok = ((final_form or not f.virtual and f.act == ACT_NONE) and tuple(out_shape) == (m, cin, k, k) and
+              (g.data.dtype == torch.float32 or not final_form) and
               C.lib().ap_wgrad_k7_bf16_ok(n, wide.data.shape[1], narrow.data.shape[1], h, w, final_form) == 1)
         if ok:
             _require_device(f.data, 'wgrad source')
-            _require_device(g.data, 'wgrad gradient')
+            _require_device(g.data, 'wgrad gradient', allow_bf16=not final_form)
             sw, sn = C.ApSrc(), C.ApSrc()
-            sw.data, sw.C, sw.act = wide.data.data_ptr(), wide.data.shape[1], wide.act
+            # ap_src.act bit 8: the stems' gradient as instnorm_bwd(out_bf16=True) stored it
+            sw.data, sw.C, sw.act = wide.data.data_ptr(), wide.data.shape[1], wide.act | (0x100 if wide.data.dtype == torch.bfloat16 else 0)
             if wide.virtual:
                 sw.mean, sw.rstd = wide.mean.data_ptr(), wide.rstd.data_ptr()
             sn.data, sn.C, sn.act = narrow.data.data_ptr(), narrow.data.shape[1], ACT_NONE
@@ -976,6 +977,8 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
             C.check(C.lib().ap_wgrad_k7_bf16(ctypes.byref(sw), ctypes.byref(sn), n, h, w, final_form, _ptr(ws), _ptr(dw), _stream()),
                     'wgrad_k7_bf16')
             return dw
+    if g.data.dtype == torch.bfloat16 and g_t is None and g_xs is None:
+        g = Feat(g.data.float(), g._mean, g._rstd, g.act)       # (only wgrad_k7 reads a bf16-stored gradient)
     if (m == 1 and k == 7 and stride == 1 and pad == 3 and len(srcs) == 1 and cin >= 16 and not g.virtual and
             g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k)):
         # the generator's last layer: vector-ALU kernel, window through LDS (wgrad_final.h)
@@ -1154,16 +1157,29 @@ def fold_add(g1, pad, g2):
     return out
 
 
-def instnorm_bwd(contribs, f):
-    """Gradient w.r.t. the raw conv output y of the virtual feature f = act(IN(y))."""
+def instnorm_bwd(contribs, f, out_bf16=False):
+    """Gradient w.r.t. the raw conv output y of the virtual feature f = act(IN(y)).
+    out_bf16: the caller's ONLY reader of dy is the stems' weight gradient on the bf16 matrix pipe (k7_stem_wgrad_ok): where the
+    big-plane kernel serves the call, dy is stored as bf16 (half the bytes written and read back)."""
     g1, pad, g2 = _split_contribs(contribs)
     g1, g2 = _as_fp32_grad(g1), _as_fp32_grad(g2)
     n, c, h, w = f.data.shape
-    dy = torch.empty_like(f.data)
+    b16 = bool(out_bf16) and pad == 0 and 16384 < h * w <= 65536 and w % 4 == 0
+    dy = torch.empty(f.data.shape, dtype=torch.bfloat16 if b16 else torch.float32, device=f.data.device)
     ws = torch.empty(n * c * 2, dtype=torch.float32, device=dy.device)
-    C.check(C.lib().ap_instnorm_bwd(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act,
+    C.check(C.lib().ap_instnorm_bwd(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act | (0x100 if b16 else 0),
                                     n * c, h, w, _ptr(ws), _ptr(dy), _stream()), 'instnorm_bwd')
     return dy
+
+
+def k7_stem_wgrad_ok(spec, g_shape, srcs):
+    """Does wgrad() serve this layer's weight gradient in the stem form of ap_wgrad_k7_bf16 (which also reads a bf16-stored gradient)?"""
+    n, m, h, w = g_shape
+    f = srcs[0]
+    return (K7_WGRAD and DEFAULT_PRECISION == PRECISION_BF16 and spec.precision == PRECISION_BF16 and not spec.transposed and
+            spec.k == 7 and spec.stride == 1 and spec.pad == 3 and spec.pad_mode == PAD_REFLECT and len(srcs) == 1 and
+            not f.virtual and f.act == ACT_NONE and f.data.dtype == torch.float32 and tuple(f.data.shape[2:]) == (h, w) and
+            not (m == 1 and f.data.shape[1] >= 32) and C.lib().ap_wgrad_k7_bf16_ok(n, m, f.data.shape[1], h, w, 0) == 1)
 
 
 def instnorm_bwd_split_ok(f, pad):

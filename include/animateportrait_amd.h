@@ -370,7 +370,8 @@ int ap_conv_final_wgrad(const ap_src* src, const float* g, int32_t N, int32_t H,
 /* Weight gradients of the 7x7 pad-3 (reflection) edge layers at full resolution on the bf16 matrix pipe, plain-bf16 arithmetic
  * (operands rounded to bf16, fp32 accumulation; csrc/wgrad_k7.h).  A WIDE tensor (C = 32 or 64 channels, read once) against the 49
  * shifted views of a NARROW one:
- *   final_form = 0 (the stems, networks.py:1251-1260): wide = the layer's output gradient [N][M][H][W] (plain), narrow = its
+ *   final_form = 0 (the stems, networks.py:1251-1260): wide = the layer's output gradient [N][M][H][W] (plain; fp32, or bf16
+ *       values with wide->act bit 8 set: what ap_instnorm_bwd stores on request), narrow = its
  *       input [N][C][H][W] (C = 1 or 3, plain):  dw[m][c][ky][kx] = sum g[n,m,y,x] * reflpad3(in)[n,c,y+ky,x+kx];
  *   final_form = 1 (the last layer, networks.py:1277-1279; replaces ap_conv_final_wgrad in this arithmetic): wide = the layer's
  *       input (InstanceNorm + activation of wide->mean / rstd / act applied on the fly), narrow = the one-channel output gradient:
@@ -392,7 +393,9 @@ int ap_conv2d_wgrad(const ap_wgrad_desc* d, float* workspace, float* dw, ap_stre
 
 /* backward of a = act(InstanceNorm(y)) w.r.t. y.  The incoming gradient is fold(g1) + g2 where g1 has spatial
  * (H+2*g1_pad) x (W+2*g1_pad) (gradient of a reflection-padded consumer, nn.ReflectionPad2d backward fused) and g2
- * (optional) is plain.  sums_ws: N*C*2 floats of scratch. */
+ * (optional) is plain.  sums_ws: N*C*2 floats of scratch.
+ * act bit 8 (0x100): dy is STORED as bf16 values (N*C*H*W of them) -- for a gradient whose one reader is ap_wgrad_k7_bf16's stem
+ * form; served where the big-plane kernel runs (g1_pad == 0, 16384 < H*W <= 65536, W % 4 == 0), AP_ERR_UNSUPPORTED elsewhere. */
 int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* y, const float* mean,
                     const float* rstd, int32_t act, int32_t NC, int32_t H, int32_t W, float* sums_ws, float* dy,
                     ap_stream_t stream);

@@ -378,3 +378,31 @@ def test_k7_edge_layer_wgrad_on_the_matrix_pipe(dev, case):
     # and the call is deterministic (fixed summation order)
     dw2 = ops.wgrad(7, 1, 3, ops.PAD_REFLECT, ops.Feat(gy.to(dev)), [src], out_shape, precision=ops.PRECISION_BF16)
     assert torch.equal(dw, dw2)
+
+
+def test_stem_gradient_stored_as_bf16(dev):
+    """Plain-bf16 train step: the InstanceNorm backward of a stem stores dy as bf16 (ap_instnorm_bwd act bit 8) and the weight
+    gradient reads it (ap_wgrad_k7_bf16, wide->act bit 8) -- the same bits as rounding the fp32 dy, so both operators give
+    exactly what the fp32-stored route gives."""
+    from animateportrait_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    n, c, H, W = 2, 32, 144, 128                      # a plane of the big-plane kernel's class (16384 < H W <= 65536)
+    y = torch.randn(n, c, H, W, generator=gen) * 1.2 + 0.1
+    g = torch.randn(n, c, H, W, generator=gen)
+    x = torch.randn(n, 3, H, W, generator=gen)
+    yd = y.to(dev)
+    mean = yd.mean((2, 3)).flatten().contiguous()
+    rstd = (yd.var((2, 3), unbiased=False) + 1e-5).rsqrt().flatten().contiguous()
+    f = ops.Feat(yd, mean, rstd, ops.ACT_RELU)
+    dy32 = ops.instnorm_bwd([(g.to(dev), 0)], f)
+    dy16 = ops.instnorm_bwd([(g.to(dev), 0)], f, out_bf16=True)
+    assert dy32.dtype == torch.float32 and dy16.dtype == torch.bfloat16
+    assert torch.equal(dy16, dy32.bfloat16())
+    src = ops.Feat(x.to(dev))
+    dw32 = ops.wgrad(7, 1, 3, ops.PAD_REFLECT, ops.Feat(dy32), [src], (c, 3, 7, 7), precision=ops.PRECISION_BF16)
+    dw16 = ops.wgrad(7, 1, 3, ops.PAD_REFLECT, ops.Feat(dy16), [src], (c, 3, 7, 7), precision=ops.PRECISION_BF16)
+    assert torch.equal(dw16, dw32)
+    # a small plane is not the big-plane kernel's: the request is ignored, fp32 comes back
+    ys = torch.randn(1, 8, 32, 32, generator=gen).to(dev)
+    fs = ops.Feat(ys, ys.mean((2, 3)).flatten().contiguous(), (ys.var((2, 3), unbiased=False) + 1e-5).rsqrt().flatten().contiguous(), ops.ACT_RELU)
+    assert ops.instnorm_bwd([(torch.randn(1, 8, 32, 32, generator=gen).to(dev), 0)], fs, out_bf16=True).dtype == torch.float32
