@@ -254,6 +254,11 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         c = s.cin_segments[i]
         if tape.tracked(f):
             spec, fold_pad = _dgrad_spec(layer, c)
+            if len(srcs) == 1 and s.cout == 1 and ops.final_dgrad_k7_ok(s, gfeat, f):
+                # the generator's last layer in plain-bf16 arithmetic: the padded gradient on the bf16 matrix pipe (dgrad_k7.h)
+                tape.add(f, ops.final_dgrad_k7(gfeat, layer.weight), fold_pad)
+                c0 += c
+                continue
             w = layer.weight.detach()
             if len(srcs) > 1:
                 w = w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]       # a view: the packer takes strides

@@ -11,6 +11,7 @@
 #include "wgrad_narrow.h"
 #include "wgrad_final.h"
 #include "wgrad_k7.h"
+#include "dgrad_k7.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -645,6 +646,48 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
     hipLaunchKernelGGL(wgrad_k7_reduce_kernel, dim3(total / 64), dim3(256), 0, stream, p.partial, k.grid, total, k.NT, wide->C, narrow->C,
                        final_form, dw);
     return check_launch("wgrad_k7_reduce_kernel");
+}
+
+// ---- data gradient of the last layer on the bf16 matrix pipe (dgrad_k7.h)
+int32_t ap_conv_final_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W) {
+    return (N >= 1 && (C == 32 || C == 64) && H >= 1 && W >= 16 && W <= 256 && (W & 15) == 0) ? 1 : 0;
+}
+
+int64_t ap_conv_final_dgrad_bf16_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W) {
+    if (!ap_conv_final_dgrad_bf16_ok(N, C, H, W)) return fail(AP_ERR_UNSUPPORTED, "conv_final_dgrad_bf16: shape not served");
+    return round4(((long long)N * (H + 12) * 2 * (W + 16) + 1) / 2);
+}
+
+int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* workspace, float* gp,
+                             ap_stream_t stream_) {
+    if (!g || !w || !workspace || !gp) return fail(AP_ERR_INVALID, "conv_final_dgrad_bf16: null pointer");
+    if (!ap_conv_final_dgrad_bf16_ok(N, C, H, W))
+        return fail(AP_ERR_UNSUPPORTED, "conv_final_dgrad_bf16: N=%d C=%d %dx%d not served (C 32 / 64, W a multiple of 16 in 16..256)", N, C, H, W);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int A = H + 12, NW = W + 16;
+    K7NarrowParams np;
+    np.src = g; np.dst = reinterpret_cast<unsigned*>(workspace);
+    np.N = N; np.CN = 1; np.H = H; np.W = W; np.A = A; np.NW = NW; np.final_form = 1;
+    const long long ndw = (long long)N * A * (NW / 2);
+    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
+    int rc = check_launch("wgrad_k7_narrow_kernel");
+    if (rc) return rc;
+    DgradK7Params p;
+    memset(&p, 0, sizeof(p));
+    p.narrow = reinterpret_cast<const unsigned short*>(workspace);
+    p.w = w; p.gp = gp; p.N = N; p.C = C; p.H = H; p.W = W; p.HP = H + 6; p.WP = W + 6; p.A = A; p.NW = NW;
+    // one workgroup per CU (its LDS row buffers fill one): whole rounds of workgroups where the row count allows
+    int bpi = std::max(1, (num_cus_w() + N - 1) / N);
+    p.RB = (p.HP + bpi - 1) / bpi;
+    p.blocks_per_img = (p.HP + p.RB - 1) / p.RB;
+    const size_t lds = (size_t)2 * C * ((p.WP + 7) & ~7) * 4 + (size_t)(kDgradK7Rows + 7) * 2 * (NW + 8) * 2;
+    const void* fn = C == 64 ? reinterpret_cast<const void*>(&dgrad_k7_final_kernel<2>) : reinterpret_cast<const void*>(&dgrad_k7_final_kernel<1>);
+    rc = ensure_wattr(fn);
+    if (rc) return rc;
+    void* args[] = {&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(N * p.blocks_per_img), dim3(512), args, lds, stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "dgrad_k7 launch: %s", hipGetErrorString(e));
+    return AP_OK;
 }
 
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {

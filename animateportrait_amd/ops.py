@@ -1172,6 +1172,30 @@ def instnorm_bwd(contribs, f, out_bf16=False):
     return dy
 
 
+def final_dgrad_k7_ok(spec, g, f):
+    """Is the data gradient of this layer the last layer's, served on the bf16 matrix pipe (ap_conv_final_dgrad_bf16)?"""
+    n, m, h, w = g.data.shape
+    return (K7_WGRAD and DEFAULT_PRECISION == PRECISION_BF16 and spec.precision == PRECISION_BF16 and not spec.transposed and
+            spec.k == 7 and spec.stride == 1 and spec.pad == 3 and spec.pad_mode == PAD_REFLECT and m == 1 and not g.virtual and
+            g.act == ACT_NONE and g.data.dtype == torch.float32 and tuple(f.data.shape[2:]) == (h, w) and
+            C.lib().ap_conv_final_dgrad_bf16_ok(n, f.data.shape[1], h, w) == 1)
+
+
+def final_dgrad_k7(g, weight):
+    """Gradient w.r.t. the reflection-padded input of Conv2d(C, 1, 7): (N, C, H + 6, W + 6), to be folded with pad 3."""
+    n, _, h, w = g.data.shape
+    c = weight.shape[1]
+    _require_device(g.data, 'final dgrad gradient')
+    wt = weight.detach().contiguous()
+    ws = torch.empty(C.check(C.lib().ap_conv_final_dgrad_bf16_workspace_floats(n, c, h, w), 'conv_final_dgrad_ws'),
+                     dtype=torch.float32, device=g.data.device)
+    gp = torch.empty((n, c, h + 6, w + 6), dtype=torch.float32, device=g.data.device)
+    if PROFILER is not None:
+        PROFILER.note('dgrad_k7<final>')
+    C.check(C.lib().ap_conv_final_dgrad_bf16(_ptr(g.data), _ptr(wt), n, c, h, w, _ptr(ws), _ptr(gp), _stream()), 'conv_final_dgrad_bf16')
+    return gp
+
+
 def k7_stem_wgrad_ok(spec, g_shape, srcs):
     """Does wgrad() serve this layer's weight gradient in the stem form of ap_wgrad_k7_bf16 (which also reads a bf16-stored gradient)?"""
     n, m, h, w = g_shape

@@ -382,6 +382,15 @@ int32_t ap_wgrad_k7_bf16_ok(int32_t N, int32_t wide_C, int32_t narrow_C, int32_t
 int64_t ap_wgrad_k7_bf16_workspace_floats(int32_t N, int32_t wide_C, int32_t narrow_C, int32_t H, int32_t W, int32_t final_form);
 int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_t H, int32_t W, int32_t final_form,
                      float* workspace, float* dw, ap_stream_t stream);
+/* Data gradient of the same last layer (Conv2d(C, 1, 7) behind ReflectionPad2d(3), C = 32 or 64) in plain-bf16 arithmetic on the bf16
+ * matrix pipe (csrc/dgrad_k7.h): the gradient w.r.t. the PADDED input,
+ *   gp[n][c][py][px] = sum_{ky,kx} w[0][c][ky][kx] * g[n][0][py-ky][px-kx],  py < H+6, px < W+6 (g zero outside),
+ * to be folded over the reflection by its consumer (ap_instnorm_bwd / ap_fold_add with g1_pad = 3).  w: the layer's weight
+ * [1][C][7][7].  Served: ap_conv_final_dgrad_bf16_ok() == 1 (W a multiple of 16 in 16..256). */
+int32_t ap_conv_final_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W);
+int64_t ap_conv_final_dgrad_bf16_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
+int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* workspace, float* gp,
+                             ap_stream_t stream);
 /* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
  * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);

@@ -406,3 +406,31 @@ def test_stem_gradient_stored_as_bf16(dev):
     ys = torch.randn(1, 8, 32, 32, generator=gen).to(dev)
     fs = ops.Feat(ys, ys.mean((2, 3)).flatten().contiguous(), (ys.var((2, 3), unbiased=False) + 1e-5).rsqrt().flatten().contiguous(), ops.ACT_RELU)
     assert ops.instnorm_bwd([(torch.randn(1, 8, 32, 32, generator=gen).to(dev), 0)], fs, out_bf16=True).dtype == torch.float32
+
+
+@pytest.mark.parametrize('case', [(2, 64, 24, 32), (3, 32, 19, 80), (1, 64, 9, 256), (1, 64, 5, 16)], ids=lambda c: 'N%d C%d %dx%d' % c)
+def test_final_layer_dgrad_on_the_matrix_pipe(dev, case):
+    """ap_conv_final_dgrad_bf16 (csrc/dgrad_k7.h): the gradient w.r.t. the reflection-padded input of the last layer
+    (networks.py:1277-1279) in plain-bf16 arithmetic = fp32-accumulated sums of bf16(w) x bf16(g), in padded coordinates; folded
+    over the reflection it is the layer's data gradient."""
+    from animateportrait_amd import ops
+    n, c, H, W = case
+    gen = torch.Generator().manual_seed(3 + sum(case))
+    w = torch.randn(1, c, 7, 7, generator=gen) * 0.05
+    gy = torch.randn(n, 1, H, W, generator=gen)
+    gp = ops.final_dgrad_k7(ops.Feat(gy.to(dev)), w.to(dev))
+    assert tuple(gp.shape) == (n, c, H + 6, W + 6)
+
+    def ref(wv, gv):
+        xp = torch.zeros(n, c, H + 6, W + 6, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(xp, wv) * gv).sum().backward()
+        return xp.grad
+    ref16, exact = ref(r16(w), r16(gy)), ref(w.double(), gy.double())
+    sc = float(ref16.abs().max())
+    e16, eex = linf(gp, ref16) / sc, linf(gp, exact) / sc
+    assert e16 < 3e-5, (case, e16, eex)
+    assert eex > 10 * e16, (case, e16, eex)
+    # folded over the reflection = the gradient w.r.t. the layer's input
+    x = torch.zeros(n, c, H, W, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(F.pad(x, (3,) * 4, mode='reflect'), r16(w)) * r16(gy)).sum().backward()
+    assert linf(ops.fold_add(gp, 3, None), x.grad) / sc < 3e-5

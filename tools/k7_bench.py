@@ -38,3 +38,29 @@ for name, final_form, mw, cn in (('stem 3->64', 0, 64, 3), ('stem 3->32', 0, 32,
                                                      e0.elapsed_time(e1) / iters * 1e3), flush=True)
     a, b = res[True], res[False]
     print('%-12s relative L-inf between the routes: %.2e' % (name, float((a - b).abs().max() / b.abs().max())), flush=True)
+
+# ---- the last layer's data gradient (padded coordinates): dgrad_k7.h against the fp32 matrix kernel
+from animateportrait_amd import autograd
+from animateportrait_amd.networks import ConvLayer
+ops.DEFAULT_PRECISION = ops.PRECISION_BF16
+layer = ConvLayer([64], 1, 7, 1, 3, ops.PAD_REFLECT).to(dev)
+layer.spec.precision = ops.PRECISION_BF16
+torch.nn.init.normal_(layer.weight, 0, 0.02)
+spec, fold = autograd._dgrad_spec(layer, 64)
+packed = layer.packed_dgrad(0, spec, layer.weight.detach())
+g = ops.Feat(torch.randn(n, 1, H, W, device=dev))
+outs = {}
+for route in (True, False, True, False):
+    fn = (lambda: ops.final_dgrad_k7(g, layer.weight)) if route else (lambda: ops.conv2d(spec, [g], packed, None).data)
+    for _ in range(3):
+        y = fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        y = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    outs[route] = y
+    print('final dgrad  %-28s %8.1f us per operator' % ('dgrad_k7 (bf16 matrix pipe)' if route else 'fp32 matrix kernel', e0.elapsed_time(e1) / iters * 1e3), flush=True)
+print('final dgrad  relative L-inf between the routes: %.2e' % float((outs[True] - outs[False]).abs().max() / outs[False].abs().max()))
