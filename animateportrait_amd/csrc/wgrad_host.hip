@@ -12,6 +12,7 @@
 #include "wgrad_final.h"
 #include "wgrad_k7.h"
 #include "dgrad_k7.h"
+#include "conv_d0.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -688,6 +689,29 @@ int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t 
     hipError_t e = hipLaunchKernel(fn, dim3(N * p.blocks_per_img), dim3(512), args, lds, stream);
     if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "dgrad_k7 launch: %s", hipGetErrorString(e));
     return AP_OK;
+}
+
+// ---- the PatchGAN's first layer as an output stream on the bf16 matrix pipe (conv_d0.h)
+int32_t ap_conv_d0_fwd_bf16_ok(int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
+    return (N >= 1 && (Cin == 1 || Cin == 2) && Cout == 64 && H >= 2 && (H & 1) == 0 && W >= 8 && W <= 256 && (W & 3) == 0) ? 1 : 0;
+}
+
+int ap_conv_d0_fwd_bf16(const float* x, const float* w, const float* bias, int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                        int32_t act, float* y, ap_stream_t stream_) {
+    if (!x || !w || !y) return fail(AP_ERR_INVALID, "conv_d0_fwd_bf16: null pointer");
+    if (!ap_conv_d0_fwd_bf16_ok(N, Cin, Cout, H, W))
+        return fail(AP_ERR_UNSUPPORTED, "conv_d0_fwd_bf16: N=%d %d -> %d channels %dx%d not served (1 | 2 -> 64, even H, W %% 4 == 0, W <= 256)",
+                    N, Cin, Cout, H, W);
+    if (act < 0 || act > 2) return fail(AP_ERR_UNSUPPORTED, "conv_d0_fwd_bf16: act %d", act);
+    ConvD0Params p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.w = w; p.bias = bias; p.y = y; p.N = N; p.H = H; p.W = W; p.OH = H / 2; p.OW = W / 2; p.act = act;
+    p.blocks_per_img = (p.OH + kConvD0Rows - 1) / kConvD0Rows;
+    const size_t lds = (size_t)Cin * (2 * kConvD0Rows + 2) * (W + 8) * 2;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (Cin == 1) hipLaunchKernelGGL(conv_d0_kernel<1>, dim3(N * p.blocks_per_img), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(conv_d0_kernel<2>, dim3(N * p.blocks_per_img), dim3(512), lds, stream, p);
+    return check_launch("conv_d0_kernel");
 }
 
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d) {

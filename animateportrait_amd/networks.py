@@ -70,6 +70,9 @@ class ConvLayer(nn.Module):
         if not isinstance(srcs, (list, tuple)):
             srcs = [srcs]
         spec, packed = self.spec, None
+        if norm_act is None and ops.conv_d0_ok(spec, srcs, act):
+            # the PatchGAN's first layer in plain-bf16 arithmetic: an output stream on the bf16 matrix pipe (csrc/conv_d0.h)
+            return ops.conv_d0(srcs[0], self.weight, self.bias.detach(), act)
         if ops.stem_rows_eligible(spec) and not srcs[0].is_split_only:
             # 7x7 stem on <= 4 channels: 1x7 split-bf16 convolution over the row expansion of the input
             spec, packed = self.rows_spec(), self.packed_rows()

@@ -661,6 +661,8 @@ FUSED_NORM = os.environ.get('APAMD_FUSED_NORM', '0') == '1'
 RESIDUAL_AS_SPLIT = True
 # plain-bf16 arithmetic: the 7x7 edge layers' weight gradients on the bf16 matrix pipe (wgrad_k7.h); 0: the fp32 / vector-ALU kernels (A/B)
 K7_WGRAD = os.environ.get('APAMD_NO_K7_WGRAD', '0') != '1'
+# ... and the PatchGAN's first layer as an output stream on the matrix pipe (conv_d0.h); 0: the fp32 implicit-GEMM kernel (A/B)
+D0_MFMA = K7_WGRAD and os.environ.get('APAMD_NO_D0_MFMA', '0') != '1'
 
 
 def fused_norm_ok(spec, srcs):
@@ -1170,6 +1172,31 @@ def instnorm_bwd(contribs, f, out_bf16=False):
     C.check(C.lib().ap_instnorm_bwd(_ptr(g1), pad, _ptr(g2), _ptr(f.data), _ptr(f.mean), _ptr(f.rstd), f.act | (0x100 if b16 else 0),
                                     n * c, h, w, _ptr(ws), _ptr(dy), _stream()), 'instnorm_bwd')
     return dy
+
+
+def conv_d0_ok(spec, srcs, act):
+    """Is this layer the PatchGAN's first (1 | 2 -> 64 channels, 4x4 stride 2 on a plain image) in plain-bf16 arithmetic, served as
+    an output stream on the bf16 matrix pipe (ap_conv_d0_fwd_bf16)?"""
+    if not (D0_MFMA and DEFAULT_PRECISION == PRECISION_BF16 and spec.precision == PRECISION_BF16 and not spec.transposed and
+            spec.k == 4 and spec.stride == 2 and spec.pad == 1 and spec.pad_mode == PAD_ZERO and len(srcs) == 1 and act in (ACT_NONE, ACT_RELU, ACT_LRELU)):
+        return False
+    f = srcs[0]
+    if f.is_split_only or f.virtual or f.act != ACT_NONE or f.data.dtype != torch.float32:
+        return False
+    n, c, h, w = f.data.shape
+    return C.lib().ap_conv_d0_fwd_bf16_ok(n, c, spec.cout, h, w) == 1
+
+
+def conv_d0(f, weight, bias, act):
+    n, c, h, w = f.data.shape
+    _require_device(f.data, 'conv_d0 input')
+    y = torch.empty((n, weight.shape[0], h // 2, w // 2), dtype=torch.float32, device=f.data.device)
+    wt = weight.detach().contiguous()
+    if PROFILER is not None:
+        PROFILER.note('conv_d0<%d>' % c)
+    C.check(C.lib().ap_conv_d0_fwd_bf16(_ptr(f.data), _ptr(wt), _ptr(bias), n, c, weight.shape[0], h, w, act, _ptr(y), _stream()),
+            'conv_d0_fwd_bf16')
+    return Feat(y)
 
 
 def final_dgrad_k7_ok(spec, g, f):

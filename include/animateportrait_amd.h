@@ -391,6 +391,13 @@ int32_t ap_conv_final_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W);
 int64_t ap_conv_final_dgrad_bf16_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
 int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* workspace, float* gp,
                              ap_stream_t stream);
+/* The PatchGAN's first layer, y = act(Conv2d(Cin = 1 | 2, 64, 4, stride 2, pad 1)(x) + bias) (networks.py:2620-2623), in plain-bf16
+ * arithmetic on the bf16 matrix pipe as an output stream (csrc/conv_d0.h).  x: plain [N][Cin][H][W], w: the layer's weight
+ * [64][Cin][4][4], bias [64] or NULL, act AP_ACT_NONE / RELU / LRELU, y [N][64][H/2][W/2].
+ * Served: ap_conv_d0_fwd_bf16_ok() == 1 (even H, W a multiple of 4 up to 256). */
+int32_t ap_conv_d0_fwd_bf16_ok(int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W);
+int ap_conv_d0_fwd_bf16(const float* x, const float* w, const float* bias, int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                        int32_t act, float* y, ap_stream_t stream);
 /* workspace = padded copies of the operands (normalisation / activation / concat / padding applied once, streaming)
  * + per-split partial sums */
 int64_t ap_conv2d_wgrad_workspace_floats(const ap_wgrad_desc* d);

@@ -434,3 +434,39 @@ def test_final_layer_dgrad_on_the_matrix_pipe(dev, case):
     x = torch.zeros(n, c, H, W, dtype=torch.float64, requires_grad=True)
     (F.conv2d(F.pad(x, (3,) * 4, mode='reflect'), r16(w)) * r16(gy)).sum().backward()
     assert linf(ops.fold_add(gp, 3, None), x.grad) / sc < 3e-5
+
+
+@pytest.mark.parametrize('case', [(2, 1, 256, 256, 2), (1, 2, 256, 256, 2), (3, 2, 64, 48, 0), (2, 1, 18, 8, 1), (48, 1, 256, 256, 2)],
+                         ids=lambda c: 'N%d Cin%d %dx%d act%d' % c)
+def test_patchgan_first_layer_on_the_matrix_pipe(dev, case, monkeypatch):
+    """ap_conv_d0_fwd_bf16 (csrc/conv_d0.h): Conv2d(1 | 2, 64, 4, stride 2, pad 1) + bias + activation (networks.py:2620-2623) in
+    plain-bf16 arithmetic = fp32-accumulated sums of bf16(x) x bf16(w); reached through ConvLayer.run in that mode."""
+    from animateportrait_amd import ops
+    from animateportrait_amd.networks import ConvLayer
+    n, cin, H, W, act = case
+    monkeypatch.setattr(ops, 'DEFAULT_PRECISION', ops.PRECISION_BF16)
+    gen = torch.Generator().manual_seed(17 + sum(case))
+    layer = ConvLayer([cin], 64, 4, 2, 1).to(dev)
+    layer.spec.precision = ops.PRECISION_BF16
+    w = torch.randn(64, cin, 4, 4, generator=gen) * 0.1
+    b = torch.randn(64, generator=gen) * 0.1
+    x = torch.randn(n, cin, H, W, generator=gen)
+    with torch.no_grad():
+        layer.weight.copy_(w); layer.bias.copy_(b)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    try:
+        y = layer.run(ops.Feat(x.to(dev)), act=act)
+    finally:
+        ops.PROFILER = None
+    assert prof.calls.get('conv_d0<%d>' % cin) == 1, prof.calls
+    assert not y.virtual and tuple(y.data.shape) == (n, 64, H // 2, W // 2)
+
+    def ref(xv, wv):
+        r = F.conv2d(xv, wv, b.double(), stride=2, padding=1)
+        return F.relu(r) if act == 1 else (F.leaky_relu(r, 0.2) if act == 2 else r)
+    ref16, exact = ref(r16(x), r16(w)), ref(x.double(), w.double())
+    sc = float(ref16.abs().max())
+    e16, eex = linf(y.data, ref16) / sc, linf(y.data, exact) / sc
+    assert e16 < 3e-5, (case, e16, eex)
+    assert eex > 10 * e16, (case, e16, eex)
