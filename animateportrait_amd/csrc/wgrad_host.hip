@@ -649,6 +649,71 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
     return check_launch("wgrad_k7_reduce_kernel");
 }
 
+// ---- weight gradient of the PatchGAN's first layer: form 2 of the same kernel (wide = the output gradient [N][64][H/2][W/2])
+static bool d0w_plan(int N, int M, int Cin, int H, int W, K7Plan& k) {
+    if (N < 1 || M != 64 || (Cin != 1 && Cin != 2) || H < 2 || (H & 1) || W < 32 || W > 512 || (W & 31)) return false;
+    const int OH = H / 2, OW = W / 2;                              // OW: a multiple of 16 in 16..256
+    k.MT = 2;
+    k.NT = 1;
+    k.R = OH;
+    k.A = H + 2;
+    k.NW = OW + 16;
+    int bpi = std::max(1, (num_cus_w() + N - 1) / N);
+    if (bpi > k.R / 2) bpi = std::max(1, k.R / 2);
+    k.RB = (k.R + bpi - 1) / bpi;
+    k.RB += k.RB & 1;
+    k.bpi = (k.R + k.RB - 1) / k.RB;
+    k.grid = N * k.bpi;
+    k.narrow_floats = round4(((long long)N * Cin * k.A * 4 * k.NW + 1) / 2);
+    k.part_floats = (long long)k.grid * k.MT * k.NT * 1024;
+    const size_t tiles = (size_t)k.MT * 32 * ((OW + 8) * 2 + 16) + (size_t)8 * Cin * 4 * (k.NW + 8) * 2;
+    const size_t red = (size_t)k.MT * k.NT * 16 * 64 * 4;
+    k.lds = std::max(tiles, red);
+    return true;
+}
+
+int32_t ap_wgrad_d0_bf16_ok(int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W) {
+    K7Plan k;
+    return d0w_plan(N, M, Cin, H, W, k) ? 1 : 0;
+}
+
+int64_t ap_wgrad_d0_bf16_workspace_floats(int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W) {
+    K7Plan k;
+    if (!d0w_plan(N, M, Cin, H, W, k)) return fail(AP_ERR_UNSUPPORTED, "wgrad_d0_bf16: shape not served (see ap_wgrad_d0_bf16_ok)");
+    return k.narrow_floats + k.part_floats;
+}
+
+int ap_wgrad_d0_bf16(const float* g, const float* x, int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W, float* workspace, float* dw,
+                     ap_stream_t stream_) {
+    if (!g || !x || !workspace || !dw) return fail(AP_ERR_INVALID, "wgrad_d0_bf16: null pointer");
+    K7Plan k;
+    if (!d0w_plan(N, M, Cin, H, W, k))
+        return fail(AP_ERR_UNSUPPORTED, "wgrad_d0_bf16: N=%d %d <- %d channels %dx%d not served (1 | 2 -> 64, even H, W a multiple of 32 up to 512)", N, M, Cin, H, W);
+    hipStream_t stream = (hipStream_t)stream_;
+    K7NarrowParams np;
+    np.src = x; np.dst = reinterpret_cast<unsigned*>(workspace);
+    np.N = N; np.CN = Cin; np.H = H; np.W = W; np.A = k.A; np.NW = k.NW; np.final_form = 2;
+    const long long ndw = (long long)N * Cin * k.A * 2 * (k.NW / 2);
+    hipLaunchKernelGGL(wgrad_d0_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
+    int rc = check_launch("wgrad_d0_narrow_kernel");
+    if (rc) return rc;
+    WgradK7Params p;
+    memset(&p, 0, sizeof(p));
+    p.wide = g;
+    p.narrow = reinterpret_cast<const unsigned short*>(workspace);
+    p.N = N; p.MW = M; p.CN = Cin; p.H = H / 2; p.W = W / 2; p.R = k.R; p.A = k.A; p.NW = k.NW; p.RB = k.RB; p.blocks_per_img = k.bpi;
+    p.partial = workspace + k.narrow_floats;
+    const void* fn = reinterpret_cast<const void*>(&wgrad_k7_kernel<2, 1, 2>);
+    rc = ensure_wattr(fn);
+    if (rc) return rc;
+    void* args[] = {&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(k.grid), dim3(256), args, k.lds, stream);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "wgrad_d0 launch: %s", hipGetErrorString(e));
+    const int total = k.MT * k.NT * 1024;
+    hipLaunchKernelGGL(wgrad_k7_reduce_kernel, dim3(total / 64), dim3(256), 0, stream, p.partial, k.grid, total, k.NT, M, Cin, 0, dw, 16);
+    return check_launch("wgrad_k7_reduce_kernel");
+}
+
 // ---- data gradient of the last layer on the bf16 matrix pipe (dgrad_k7.h)
 int32_t ap_conv_final_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W) {
     return (N >= 1 && (C == 32 || C == 64) && H >= 1 && W >= 16 && W <= 256 && (W & 15) == 0) ? 1 : 0;

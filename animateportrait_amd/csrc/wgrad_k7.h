@@ -79,6 +79,28 @@ static __global__ __launch_bounds__(256) void wgrad_k7_narrow_kernel(const K7Nar
     }
 }
 
+// Form 2 (PatchGAN first layer): rows a <-> input row a - 1 (zero outside), planes (phase, copy): phase 0 holds the even columns,
+// phase 1 the odd ones, element j <-> column 2 (j - 1) + phase (zero outside); copy 1 is copy 0 shifted by one element.
+static __global__ __launch_bounds__(256) void wgrad_d0_narrow_kernel(const K7NarrowParams p) {
+    const int D = p.NW / 2;
+    const long long total = (long long)p.N * p.CN * p.A * 2 * D;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
+        const int d = (int)(j % D);
+        const long long t = j / D;
+        const int phase = (int)(t & 1);
+        const long long row = t >> 1;                               // (n * CN + c) * A + a
+        const int iy = (int)(row % p.A) - 1;
+        const float* plane = p.src + (row / p.A) * p.H * p.W;
+        auto val = [&](int e) -> float {
+            const int x = 2 * (e - 1) + phase;
+            return (e >= 1 && iy >= 0 && iy < p.H && x < p.W) ? plane[iy * p.W + x] : 0.f;
+        };
+        const float em = val(2 * d - 1), e0 = val(2 * d), e1 = val(2 * d + 1);
+        p.dst[((row * 2 + phase) * 2) * D + d] = k7_pack(e0, e1);
+        p.dst[((row * 2 + phase) * 2 + 1) * D + d] = k7_pack(em, e0);
+    }
+}
+
 struct WgradK7Params {
     const float* wide;        // [N][MW][H][W] (fp32, or bf16 values: wgrad_k7_kernel<.., WB16>)
     const float* wmean;       // [N*MW] or null: InstanceNorm of the wide operand ...
@@ -90,9 +112,18 @@ struct WgradK7Params {
 };
 
 // WB16: the wide tensor holds bf16 values (the stems' gradient as ap_instnorm_bwd stores it on request): half the bytes, no conversion
-template <int MT, int NT, bool FINAL, bool WB16 = false>
+// FORM 0: stem, 1: final (see the head of the file); 2: the PatchGAN's first layer Conv2d(1 | 2, 64, 4, stride 2, pad 1)
+// (networks.py:2620-2623): D = OH x OW, Wd = the layer's output gradient, and the narrow operand is the input image read at
+// (2 r + ky - 1, 2 q + kx - 1) -- its rows are prepared by wgrad_d0_narrow_kernel as the EVEN and the ODD columns apart (two copies
+// each), so that a lane's 8 pixels of tap kx are contiguous again; a tile advances the ring by two input rows.
+template <int MT, int NT, int FORM, bool WB16 = false>
 static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Params p) {
-    static_assert(!(FINAL && WB16), "bf16 wide operand: the stem form");
+    constexpr bool FINAL = FORM == 1, D0 = FORM == 2;
+    static_assert(!WB16 || FORM == 0, "bf16 wide operand: the stem form");
+    constexpr int TAPS = D0 ? 16 : 49, KW = D0 ? 4 : 7, KH = KW;   // taps per narrow channel
+    constexpr int NPL = D0 ? 4 : 2;                                 // planes of a narrow row: copies (x phases)
+    constexpr int RS = D0 ? 2 : 1;                                  // narrow rows a tile advances by
+    constexpr int NQ = D0 ? 2 : 1;                                  // 16-byte narrow loads per thread and tile
     constexpr int CPW = MT * 8;                                     // channel rows per wave and tile
     using QT = std::conditional_t<WB16, uint2, float4>;             // four pixels of a channel row, as loaded
     extern __shared__ __attribute__((aligned(16))) unsigned char k7_smem[];
@@ -101,10 +132,10 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
     const int H = p.H, W = p.W, NW = p.NW, CN = p.CN, A = p.A;
     const int WSB = (W + 8) * 2;                                    // wide tile: bytes per channel row
     const int NWLB = (NW + 8) * 2;                                  // narrow ring: bytes per (channel, copy) row
-    const int SLOT = CN * 2 * NWLB;                                 // ... per ring slot
+    const int SLOT = CN * NPL * NWLB;                               // ... per ring slot
     unsigned char* const wide_l = k7_smem;                          // [MT*32][WSB]
     unsigned char* const bord_l = wide_l + MT * 32 * WSB;           // [MT*32][16]: the reflected columns (final form)
-    unsigned char* const nar_l = bord_l + MT * 32 * 16;             // [8][CN][2][NWLB]
+    unsigned char* const nar_l = bord_l + MT * 32 * 16;             // [8][CN][NPL][NWLB]
     const int n = blockIdx.x / p.blocks_per_img, rb = blockIdx.x - n * p.blocks_per_img;
     const int r0 = rb * p.RB;
     const int r1 = r0 + p.RB < p.R ? r0 + p.RB : p.R;
@@ -115,10 +146,13 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         int tap = nt * 32 + l32;
-        if (tap >= CN * 49) tap = CN * 49 - 1;                      // padding columns: any legal address, the sums are dropped
-        const int c = tap / 49, t = tap - c * 49, ky = t / 7, kx = t - ky * 7;
-        const int c0 = 8 * half + (FINAL ? 3 : 0) + kx, copy = c0 & 1;
-        nb_off[nt] = (c * 2 + copy) * NWLB + (c0 + copy) * 2;
+        if (tap >= CN * TAPS) tap = CN * TAPS - 1;                  // padding columns: any legal address, the sums are dropped
+        const int c = tap / TAPS, t = tap - c * TAPS, ky = t / KW, kx = t - ky * KW;
+        // first of the lane's 8 elements in its plane row.  D0: tap kx reads the odd columns from q - 1 (kx 0) / q (kx 2) and the
+        // even ones from q (kx 1) / q + 1 (kx 3); the phase rows carry one zero element on the left
+        const int c0 = 8 * half + (D0 ? (kx + 1) >> 1 : (FINAL ? 3 : 0) + kx), copy = c0 & 1;
+        const int plane = D0 ? (1 - (kx & 1)) * 2 + copy : copy;
+        nb_off[nt] = (c * NPL + plane) * NWLB + (c0 + copy) * 2;
         nky[nt] = ky;
         nkx[nt] = kx;
         ncc[nt] = c;
@@ -145,17 +179,32 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-    // ---- narrow ring: one row per tile and (c, copy), 16 bytes per thread
-    const int NV = NW >> 3, per_row = CN * 2 * NV;
-    const bool nact = tid < per_row;
-    const int nidx = nact ? tid : 0, ncopyrow = nidx / NV, nk = nidx - ncopyrow * NV;   // ncopyrow = c * 2 + copy
-    auto narrow_src = [&](int a) {
-        return reinterpret_cast<const uint4*>(p.narrow + ((((long long)n * CN + (ncopyrow >> 1)) * A + a) * 2 + (ncopyrow & 1)) * NW) + nk;
+    // ---- narrow ring: RS rows per tile, each CN x NPL plane rows of NW elements; 16 bytes per thread and load
+    const int NV = NW >> 3, per_row = CN * NPL * NV;
+    // (per-load values as named scalars -- indexed arrays of them were kept in scratch memory; load 1 exists in form 2 only)
+    auto nq_decode = [&](int j, bool& act, int& row, int& plane, int& k) {
+        const int e = tid + j * 256;
+        act = e < RS * per_row && j < NQ;
+        const int ec = act ? e : 0;
+        row = ec / per_row;
+        const int rem = ec - row * per_row;
+        plane = rem / NV;
+        k = rem - plane * NV;
     };
-    auto narrow_dst = [&](int a) { return reinterpret_cast<uint4*>(nar_l + (a & 7) * SLOT + ncopyrow * NWLB) + nk; };
+    bool nact0, nact1;
+    int nrow0, nrow1, nplane0, nplane1, nk0, nk1;
+    nq_decode(0, nact0, nrow0, nplane0, nk0);
+    nq_decode(1, nact1, nrow1, nplane1, nk1);
+    auto narrow_src = [&](int a, int j) {
+        const int pl = j ? nplane1 : nplane0, k = j ? nk1 : nk0;
+        return reinterpret_cast<const uint4*>(p.narrow + ((((long long)n * CN + pl / NPL) * A + a) * NPL + pl % NPL) * NW) + k;
+    };
+    auto narrow_dst = [&](int a, int j) { return reinterpret_cast<uint4*>(nar_l + (a & 7) * SLOT + (j ? nplane1 : nplane0) * NWLB) + (j ? nk1 : nk0); };
+    // the rows tile r adds to the ring: RS r + KH - RS .. RS r + KH - 1
+    auto new_row = [&](int r, int j) { return RS * r + KH - RS + (j ? nrow1 : nrow0); };
 
     QT q[2][CPW];
-    uint4 nq0, nq1;
+    uint4 nq00, nq01, nq10, nq11;                                   // [set][load]
     const bool wact_lane = 4 * lane < W;
     auto issue = [&](auto setc, int r) __attribute__((always_inline)) {
         constexpr int set = decltype(setc)::value;
@@ -166,8 +215,13 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
             if constexpr (WB16) q[set][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.wide) + e0 + (long long)i * H * W);
             else q[set][i] = *reinterpret_cast<const float4*>(p.wide + e0 + (long long)i * H * W);
         }
-        if constexpr (set == 0) nq0 = *narrow_src(r + 6);
-        else nq1 = *narrow_src(r + 6);
+        if constexpr (set == 0) {
+            nq00 = *narrow_src(new_row(r, 0), 0);
+            if constexpr (NQ > 1) nq01 = *narrow_src(new_row(r, 1), 1);
+        } else {
+            nq10 = *narrow_src(new_row(r, 0), 0);
+            if constexpr (NQ > 1) nq11 = *narrow_src(new_row(r, 1), 1);
+        }
     };
     auto commit = [&](auto setc, int r) __attribute__((always_inline)) {
         constexpr int set = decltype(setc)::value;
@@ -193,12 +247,15 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
                 }
             }
         }
-        if (nact) *narrow_dst(r + 6) = set == 0 ? nq0 : nq1;
+        if (nact0) *narrow_dst(new_row(r, 0), 0) = set == 0 ? nq00 : nq10;
+        if constexpr (NQ > 1) {
+            if (nact1) *narrow_dst(new_row(r, 1), 1) = set == 0 ? nq01 : nq11;
+        }
     };
     auto compute = [&](int r) __attribute__((always_inline)) {
         const unsigned char* bp[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bp[nt] = nar_l + ((r + nky[nt]) & 7) * SLOT + nb_off[nt];
+        for (int nt = 0; nt < NT; ++nt) bp[nt] = nar_l + ((RS * r + nky[nt]) & 7) * SLOT + nb_off[nt];
         const unsigned char* ap = wide_l + l32 * WSB + 16 * half;
         for (int s = wave; s < S; s += 4) {
             k7_bf16x8 af[MT], bf[NT];
@@ -246,17 +303,27 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
 
     // ---- prologue: the six ring rows under the first tile's, then two tiles of loads in flight
     {
-        const uint4 pre0 = *narrow_src(r0), pre1 = *narrow_src(r0 + 1), pre2 = *narrow_src(r0 + 2);
-        const uint4 pre3 = *narrow_src(r0 + 3), pre4 = *narrow_src(r0 + 4), pre5 = *narrow_src(r0 + 5);
-        issue(Set0{}, r0);
-        issue(Set1{}, r0 + 1 < r1 ? r0 + 1 : r1 - 1);
-        if (nact) {
-            *narrow_dst(r0) = pre0;
-            *narrow_dst(r0 + 1) = pre1;
-            *narrow_dst(r0 + 2) = pre2;
-            *narrow_dst(r0 + 3) = pre3;
-            *narrow_dst(r0 + 4) = pre4;
-            *narrow_dst(r0 + 5) = pre5;
+        // (rows RS r0 .. RS r0 + KH - RS - 1, in groups of RS as the tiles load them: the group of "tile" r0 - g)
+        // (named registers: an array here was kept in scratch memory)
+        if constexpr (D0) {
+            const uint4 pre0 = *narrow_src(RS * r0 + nrow0, 0), pre1 = *narrow_src(RS * r0 + nrow1, 1);
+            issue(Set0{}, r0);
+            issue(Set1{}, r0 + 1 < r1 ? r0 + 1 : r1 - 1);
+            if (nact0) *narrow_dst(RS * r0 + nrow0, 0) = pre0;
+            if (nact1) *narrow_dst(RS * r0 + nrow1, 1) = pre1;
+        } else {
+            const uint4 pre0 = *narrow_src(r0, 0), pre1 = *narrow_src(r0 + 1, 0), pre2 = *narrow_src(r0 + 2, 0);
+            const uint4 pre3 = *narrow_src(r0 + 3, 0), pre4 = *narrow_src(r0 + 4, 0), pre5 = *narrow_src(r0 + 5, 0);
+            issue(Set0{}, r0);
+            issue(Set1{}, r0 + 1 < r1 ? r0 + 1 : r1 - 1);
+            if (nact0) {
+                *narrow_dst(r0, 0) = pre0;
+                *narrow_dst(r0 + 1, 0) = pre1;
+                *narrow_dst(r0 + 2, 0) = pre2;
+                *narrow_dst(r0 + 3, 0) = pre3;
+                *narrow_dst(r0 + 4, 0) = pre4;
+                *narrow_dst(r0 + 5, 0) = pre5;
+            }
         }
     }
     // a tile: registers -> LDS, loads of the tile after next, K-steps.  Row indices beyond the block are clamped (a repeated
@@ -310,7 +377,7 @@ static __global__ __launch_bounds__(256, 1) void wgrad_k7_kernel(const WgradK7Pa
 // dW = sum over the P workgroups' partial tiles, in fixed order: a block owns 64 consecutive elements, wave w adds the
 // workgroups [w P/4, (w+1) P/4) one after the other (eight loads in flight), the four sums are added as (0 + 1) + (2 + 3).
 static __global__ __launch_bounds__(256) void wgrad_k7_reduce_kernel(const float* __restrict__ partial, int P, int total, int NT,
-                                                                     int MW, int CN, int final_form, float* __restrict__ dw) {
+                                                                     int MW, int CN, int final_form, float* __restrict__ dw, int TAPS = 49) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
@@ -335,9 +402,9 @@ static __global__ __launch_bounds__(256) void wgrad_k7_reduce_kernel(const float
     const int mt = tl / NT, nt = tl - mt * NT;
     const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
     const int col = nt * 32 + (l & 31);
-    if (m >= MW || col >= CN * 49) return;
+    if (m >= MW || col >= CN * TAPS) return;
     if (final_form) dw[m * 49 + (48 - col)] = s;                     // dW[0][m][6 - ky][6 - kx]
-    else dw[(long long)m * CN * 49 + col] = s;                       // dW[m][c][ky][kx]
+    else dw[(long long)m * CN * TAPS + col] = s;                     // dW[m][c][ky][kx]
 }
 
 }  // namespace apamd

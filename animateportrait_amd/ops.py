@@ -981,6 +981,22 @@ def wgrad(k, stride, pad, pad_mode, g, srcs, out_shape, precision=None, out=None
             return dw
     if g.data.dtype == torch.bfloat16 and g_t is None and g_xs is None:
         g = Feat(g.data.float(), g._mean, g._rstd, g.act)       # (only wgrad_k7 reads a bf16-stored gradient)
+    if (D0_MFMA and prec == PRECISION_BF16 and k == 4 and stride == 2 and pad == 1 and pad_mode == PAD_ZERO and len(srcs) == 1 and
+            g_t is None and g_xs is None and not g.virtual and g.act == ACT_NONE and not srcs[0].virtual and srcs[0].act == ACT_NONE and
+            not srcs[0].is_split_only and srcs[0].data.dtype == torch.float32 and tuple(out_shape) == (m, cin, k, k)):
+        # the PatchGAN's first layer, plain-bf16 arithmetic: one pass over the gradient on the bf16 matrix pipe (wgrad_k7.h, form 2)
+        f = srcs[0]
+        h, w = f.data.shape[2:]
+        if (gh, gw) == (h // 2, w // 2) and C.lib().ap_wgrad_d0_bf16_ok(n, m, cin, h, w) == 1:
+            _require_device(f.data, 'wgrad source')
+            _require_device(g.data, 'wgrad gradient')
+            ws = torch.empty(C.check(C.lib().ap_wgrad_d0_bf16_workspace_floats(n, m, cin, h, w), 'wgrad_d0_ws'),
+                             dtype=torch.float32, device=g.data.device)
+            dw = _grad_out(out, out_shape, g.data.device)
+            if PROFILER is not None:
+                PROFILER.note('wgrad_k7<d0>')
+            C.check(C.lib().ap_wgrad_d0_bf16(_ptr(g.data), _ptr(f.data), n, m, cin, h, w, _ptr(ws), _ptr(dw), _stream()), 'wgrad_d0_bf16')
+            return dw
     if (m == 1 and k == 7 and stride == 1 and pad == 3 and len(srcs) == 1 and cin >= 16 and not g.virtual and
             g.act == ACT_NONE and tuple(out_shape) == (1, cin, k, k)):
         # the generator's last layer: vector-ALU kernel, window through LDS (wgrad_final.h)

@@ -470,3 +470,33 @@ def test_patchgan_first_layer_on_the_matrix_pipe(dev, case, monkeypatch):
     e16, eex = linf(y.data, ref16) / sc, linf(y.data, exact) / sc
     assert e16 < 3e-5, (case, e16, eex)
     assert eex > 10 * e16, (case, e16, eex)
+
+
+@pytest.mark.parametrize('case', [(2, 1, 64, 64), (3, 2, 36, 96), (1, 2, 256, 256), (2, 1, 256, 256)], ids=lambda c: 'N%d Cin%d %dx%d' % c)
+def test_patchgan_first_layer_wgrad_on_the_matrix_pipe(dev, case):
+    """ap_wgrad_d0_bf16 (form 2 of csrc/wgrad_k7.h): the weight gradient of Conv2d(1 | 2, 64, 4, stride 2, pad 1)
+    (networks.py:2620-2623) in plain-bf16 arithmetic = fp32-accumulated sums of bf16(g) x bf16(x)."""
+    from animateportrait_amd import ops
+    n, cin, H, W = case
+    gen = torch.Generator().manual_seed(23 + sum(case))
+    x = torch.randn(n, cin, H, W, generator=gen)
+    gy = torch.randn(n, 64, H // 2, W // 2, generator=gen)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    try:
+        dw = ops.wgrad(4, 2, 1, ops.PAD_ZERO, ops.Feat(gy.to(dev)), [ops.Feat(x.to(dev))], (64, cin, 4, 4), precision=ops.PRECISION_BF16)
+    finally:
+        ops.PROFILER = None
+    assert prof.calls.get('wgrad_k7<d0>') == 1, prof.calls
+
+    def wgrad_ref(xv, gv):
+        w = torch.zeros(64, cin, 4, 4, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(xv, w, stride=2, padding=1) * gv).sum().backward()
+        return w.grad
+    ref16, exact = wgrad_ref(r16(x), r16(gy)), wgrad_ref(x.double(), gy.double())
+    sc = float(ref16.abs().max())
+    e16, eex = linf(dw, ref16) / sc, linf(dw, exact) / sc
+    assert e16 < 3e-5, (case, e16, eex)
+    assert eex > 10 * e16, (case, e16, eex)
+    dw2 = ops.wgrad(4, 2, 1, ops.PAD_ZERO, ops.Feat(gy.to(dev)), [ops.Feat(x.to(dev))], (64, cin, 4, 4), precision=ops.PRECISION_BF16)
+    assert torch.equal(dw, dw2)
