@@ -653,6 +653,8 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
 static bool d0w_plan(int N, int M, int Cin, int H, int W, K7Plan& k) {
     if (N < 1 || M != 64 || (Cin != 1 && Cin != 2) || H < 2 || (H & 1) || W < 32 || W > 512 || (W & 31)) return false;
     const int OH = H / 2, OW = W / 2;                              // OW: a multiple of 16 in 16..256
+    // the ring's two new rows per tile are fetched with at most two 16-byte loads per thread (wgrad_k7.h, NQ)
+    if (Cin * 4 * ((OW + 16) / 8) * 2 > 512) return false;
     k.MT = 2;
     k.NT = 1;
     k.R = OH;

@@ -400,7 +400,7 @@ int ap_conv_d0_fwd_bf16(const float* x, const float* w, const float* bias, int32
                         int32_t act, float* y, ap_stream_t stream);
 /* ... and its weight gradient, dw[m][c][ky][kx] = sum g[n,m,oy,ox] * zeropad1(x)[n,c,2oy+ky,2ox+kx] (g: [N][64][H/2][W/2] plain, x: the
  * layer's input), on the same kernel as ap_wgrad_k7_bf16 (form 2 of csrc/wgrad_k7.h: the gradient is read once).  Served:
- * ap_wgrad_d0_bf16_ok() == 1 (M = 64, Cin 1 | 2, even H, W a multiple of 32 up to 512). */
+ * ap_wgrad_d0_bf16_ok() == 1 (M = 64, Cin 1 | 2, even H, W a multiple of 32 up to 512 for one input channel, up to 448 for two). */
 int32_t ap_wgrad_d0_bf16_ok(int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W);
 int64_t ap_wgrad_d0_bf16_workspace_floats(int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W);
 int ap_wgrad_d0_bf16(const float* g, const float* x, int32_t N, int32_t M, int32_t Cin, int32_t H, int32_t W, float* workspace, float* dw,

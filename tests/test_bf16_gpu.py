@@ -330,6 +330,9 @@ K7_CASES = [
     ('final 64->1', 1, 64, 1, 2, 24, 32),
     ('final 32->1, odd rows', 1, 32, 1, 3, 19, 80),
     ('final 64->1 at 256 columns', 1, 64, 1, 1, 9, 256),
+    ('stem 3->64, 300 small images (one block per image)', 0, 64, 3, 300, 4, 16),
+    ('final 32->1, 290 small images', 1, 32, 1, 290, 5, 16),
+    ('stem 3->32, one tall image', 0, 32, 3, 1, 301, 32),
 ]
 
 
@@ -408,7 +411,7 @@ def test_stem_gradient_stored_as_bf16(dev):
     assert ops.instnorm_bwd([(torch.randn(1, 8, 32, 32, generator=gen).to(dev), 0)], fs, out_bf16=True).dtype == torch.float32
 
 
-@pytest.mark.parametrize('case', [(2, 64, 24, 32), (3, 32, 19, 80), (1, 64, 9, 256), (1, 64, 5, 16)], ids=lambda c: 'N%d C%d %dx%d' % c)
+@pytest.mark.parametrize('case', [(2, 64, 24, 32), (3, 32, 19, 80), (1, 64, 9, 256), (1, 64, 5, 16), (270, 32, 4, 16), (1, 64, 4, 16)], ids=lambda c: 'N%d C%d %dx%d' % c)
 def test_final_layer_dgrad_on_the_matrix_pipe(dev, case):
     """ap_conv_final_dgrad_bf16 (csrc/dgrad_k7.h): the gradient w.r.t. the reflection-padded input of the last layer
     (networks.py:1277-1279) in plain-bf16 arithmetic = fp32-accumulated sums of bf16(w) x bf16(g), in padded coordinates; folded
@@ -472,7 +475,8 @@ def test_patchgan_first_layer_on_the_matrix_pipe(dev, case, monkeypatch):
     assert eex > 10 * e16, (case, e16, eex)
 
 
-@pytest.mark.parametrize('case', [(2, 1, 64, 64), (3, 2, 36, 96), (1, 2, 256, 256), (2, 1, 256, 256)], ids=lambda c: 'N%d Cin%d %dx%d' % c)
+@pytest.mark.parametrize('case', [(2, 1, 64, 64), (3, 2, 36, 96), (1, 2, 256, 256), (2, 1, 256, 256), (1, 1, 2, 32), (290, 2, 4, 32), (1, 1, 10, 512), (1, 2, 6, 448)],
+                         ids=lambda c: 'N%d Cin%d %dx%d' % c)
 def test_patchgan_first_layer_wgrad_on_the_matrix_pipe(dev, case):
     """ap_wgrad_d0_bf16 (form 2 of csrc/wgrad_k7.h): the weight gradient of Conv2d(1 | 2, 64, 4, stride 2, pad 1)
     (networks.py:2620-2623) in plain-bf16 arithmetic = fp32-accumulated sums of bf16(g) x bf16(x)."""
@@ -488,6 +492,8 @@ def test_patchgan_first_layer_wgrad_on_the_matrix_pipe(dev, case):
     finally:
         ops.PROFILER = None
     assert prof.calls.get('wgrad_k7<d0>') == 1, prof.calls
+    from animateportrait_amd import _capi
+    assert _capi.lib().ap_wgrad_d0_bf16_ok(1, 64, 2, 10, 512) == 0       # (two channels of 256-pixel output rows: not served, the fp32 kernel runs)
 
     def wgrad_ref(xv, gv):
         w = torch.zeros(64, cin, 4, 4, dtype=torch.float64, requires_grad=True)
