@@ -570,8 +570,6 @@ struct K7Plan {
     long long narrow_floats, part_floats;
     size_t lds;
 };
-// (a block row per prepared row, at most 32768 block rows: the kernels walk the rest)
-static dim3 k7_narrow_grid(int NW, long long rows) { return dim3((unsigned)((NW / 2 + 255) / 256), (unsigned)std::min<long long>(rows, 32768)); }
 static bool k7_plan(int N, int MW, int CN, int H, int W, int final_form, K7Plan& k) {
     if (N < 1 || H < 4 || W < 16 || W > 256 || (W & 15) || (MW != 32 && MW != 64)) return false;
     if (final_form ? CN != 1 : (CN != 1 && CN != 3)) return false;
@@ -624,7 +622,8 @@ int ap_wgrad_k7_bf16(const ap_src* wide, const ap_src* narrow, int32_t N, int32_
     K7NarrowParams np;
     np.src = narrow->data; np.dst = reinterpret_cast<unsigned*>(workspace);
     np.N = N; np.CN = narrow->C; np.H = H; np.W = W; np.A = k.A; np.NW = k.NW; np.final_form = final_form;
-    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, k7_narrow_grid(k.NW, (long long)N * narrow->C * k.A), dim3(256), 0, stream, np);
+    const long long ndw = (long long)N * narrow->C * k.A * (k.NW / 2);
+    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
     int rc = check_launch("wgrad_k7_narrow_kernel");
     if (rc) return rc;
     WgradK7Params p;
@@ -696,7 +695,8 @@ int ap_wgrad_d0_bf16(const float* g, const float* x, int32_t N, int32_t M, int32
     K7NarrowParams np;
     np.src = x; np.dst = reinterpret_cast<unsigned*>(workspace);
     np.N = N; np.CN = Cin; np.H = H; np.W = W; np.A = k.A; np.NW = k.NW; np.final_form = 2;
-    hipLaunchKernelGGL(wgrad_d0_narrow_kernel, k7_narrow_grid(k.NW, (long long)N * Cin * k.A * 2), dim3(256), 0, stream, np);
+    const long long ndw = (long long)N * Cin * k.A * 2 * (k.NW / 2);
+    hipLaunchKernelGGL(wgrad_d0_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
     int rc = check_launch("wgrad_d0_narrow_kernel");
     if (rc) return rc;
     WgradK7Params p;
@@ -736,7 +736,8 @@ int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t 
     K7NarrowParams np;
     np.src = g; np.dst = reinterpret_cast<unsigned*>(workspace);
     np.N = N; np.CN = 1; np.H = H; np.W = W; np.A = A; np.NW = NW; np.final_form = 1;
-    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, k7_narrow_grid(NW, (long long)N * A), dim3(256), 0, stream, np);
+    const long long ndw = (long long)N * A * (NW / 2);
+    hipLaunchKernelGGL(wgrad_k7_narrow_kernel, dim3((unsigned)std::min<long long>((ndw + 255) / 256, 4096)), dim3(256), 0, stream, np);
     int rc = check_launch("wgrad_k7_narrow_kernel");
     if (rc) return rc;
     DgradK7Params p;

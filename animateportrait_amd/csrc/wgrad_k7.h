@@ -55,14 +55,15 @@ struct K7NarrowParams {
 };
 
 // Nr rows as the main kernel reads them: copy 0 holds element e at position e, copy 1 at position e + 1.
-// grid: (ceil(NW / 2 / 256), rows) with rows = N * CN * A walked in steps of gridDim.y: a row per block row, no 64-bit divisions
 static __global__ __launch_bounds__(256) void wgrad_k7_narrow_kernel(const K7NarrowParams p) {
-    const int D = p.NW / 2, d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
-    const int rows = p.N * p.CN * p.A;
-    for (int row = blockIdx.y; row < rows; row += gridDim.y) {      // row = (n * CN + c) * A + a
-        const int nc = row / p.A, a = row - nc * p.A;
-        const float* plane = p.src + (long long)nc * p.H * p.W;
+    const int D = p.NW / 2;
+    const long long total = (long long)p.N * p.CN * p.A * D;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
+        const int d = (int)(j % D);
+        const long long row = j / D;                                // (n * CN + c) * A + a
+        const int a = (int)(row % p.A);
+        const long long nc = row / p.A;
+        const float* plane = p.src + nc * p.H * p.W;
         auto val = [&](int b) -> float {
             if (b < 0) return 0.f;
             if (p.final_form) {
@@ -73,28 +74,30 @@ static __global__ __launch_bounds__(256) void wgrad_k7_narrow_kernel(const K7Nar
             return plane[reflect_clamp(a - 3, p.H) * p.W + reflect_clamp(b - 3, p.W)];
         };
         const float em = val(2 * d - 1), e0 = val(2 * d), e1 = val(2 * d + 1);
-        p.dst[(long long)row * 2 * D + d] = k7_pack(e0, e1);
-        p.dst[((long long)row * 2 + 1) * D + d] = k7_pack(em, e0);
+        p.dst[row * 2 * D + d] = k7_pack(e0, e1);
+        p.dst[(row * 2 + 1) * D + d] = k7_pack(em, e0);
     }
 }
 
 // Form 2 (PatchGAN first layer): rows a <-> input row a - 1 (zero outside), planes (phase, copy): phase 0 holds the even columns,
 // phase 1 the odd ones, element j <-> column 2 (j - 1) + phase (zero outside); copy 1 is copy 0 shifted by one element.
 static __global__ __launch_bounds__(256) void wgrad_d0_narrow_kernel(const K7NarrowParams p) {
-    const int D = p.NW / 2, d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= D) return;
-    const int rows2 = p.N * p.CN * p.A * 2;                        // (row, phase) pairs; grid as wgrad_k7_narrow_kernel
-    for (int t = blockIdx.y; t < rows2; t += gridDim.y) {
-        const int phase = t & 1, row = t >> 1;                      // row = (n * CN + c) * A + a
-        const int nc = row / p.A, iy = row - nc * p.A - 1;
-        const float* plane = p.src + (long long)nc * p.H * p.W;
+    const int D = p.NW / 2;
+    const long long total = (long long)p.N * p.CN * p.A * 2 * D;
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < total; j += (long long)gridDim.x * 256) {
+        const int d = (int)(j % D);
+        const long long t = j / D;
+        const int phase = (int)(t & 1);
+        const long long row = t >> 1;                               // (n * CN + c) * A + a
+        const int iy = (int)(row % p.A) - 1;
+        const float* plane = p.src + (row / p.A) * p.H * p.W;
         auto val = [&](int e) -> float {
             const int x = 2 * (e - 1) + phase;
             return (e >= 1 && iy >= 0 && iy < p.H && x < p.W) ? plane[iy * p.W + x] : 0.f;
         };
         const float em = val(2 * d - 1), e0 = val(2 * d), e1 = val(2 * d + 1);
-        p.dst[((long long)t * 2) * D + d] = k7_pack(e0, e1);
-        p.dst[((long long)t * 2 + 1) * D + d] = k7_pack(em, e0);
+        p.dst[((row * 2 + phase) * 2) * D + d] = k7_pack(e0, e1);
+        p.dst[((row * 2 + phase) * 2 + 1) * D + d] = k7_pack(em, e0);
     }
 }
 
