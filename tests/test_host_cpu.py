@@ -79,6 +79,36 @@ def test_plans_of_the_special_layers_need_no_gpu():
     assert _capi.check(lib.ap_conv2d_wgrad_workspace_floats(ctypes.byref(d)), 'wgrad_ws') > 64 * 16 * 256 * 256
 
 
+def test_edge_layer_routes_served_shapes_need_no_gpu():
+    """The plain-bf16 train step's narrow-sided layers (include/animateportrait_amd.h: ap_wgrad_k7_bf16, ap_wgrad_d0_bf16,
+    ap_conv_final_dgrad_bf16, ap_conv_d0_fwd_bf16): which shapes the matrix-pipe kernels serve is host logic -- everything else
+    stays on the general kernels -- and so is the workspace they ask for."""
+    from animateportrait_amd import _capi
+    lib = _capi.lib()
+    k7 = lib.ap_wgrad_k7_bf16_ok
+    assert k7(32, 64, 3, 256, 256, 0) == 1 and k7(32, 32, 3, 256, 256, 0) == 1 and k7(2, 64, 1, 16, 16, 0) == 1    # stems
+    assert k7(32, 64, 1, 256, 256, 1) == 1 and k7(1, 32, 1, 9, 80, 1) == 1                                          # last layer
+    assert k7(32, 64, 2, 256, 256, 0) == 0          # two narrow channels: no instantiation
+    assert k7(32, 64, 3, 256, 256, 1) == 0          # final form: one gradient channel
+    assert k7(32, 48, 3, 256, 256, 0) == 0          # wide channels: 32 or 64
+    assert k7(32, 64, 3, 256, 250, 0) == 0 and k7(32, 64, 3, 256, 272, 0) == 0 and k7(32, 64, 3, 3, 256, 0) == 0
+    d0 = lib.ap_wgrad_d0_bf16_ok
+    assert d0(16, 64, 2, 256, 256) == 1 and d0(48, 64, 1, 256, 256) == 1 and d0(1, 64, 1, 10, 512) == 1 and d0(1, 64, 2, 6, 448) == 1
+    assert d0(1, 64, 2, 10, 512) == 0 and d0(16, 32, 2, 256, 256) == 0 and d0(16, 64, 3, 256, 256) == 0 and d0(16, 64, 1, 255, 256) == 0
+    dg = lib.ap_conv_final_dgrad_bf16_ok
+    assert dg(32, 64, 256, 256) == 1 and dg(1, 32, 4, 16) == 1
+    assert dg(32, 48, 256, 256) == 0 and dg(32, 64, 256, 272) == 0 and dg(32, 64, 256, 24) == 0
+    f0 = lib.ap_conv_d0_fwd_bf16_ok
+    assert f0(16, 2, 64, 256, 256) == 1 and f0(3, 1, 64, 18, 8) == 1
+    assert f0(16, 3, 64, 256, 256) == 0 and f0(16, 2, 32, 256, 256) == 0 and f0(16, 2, 64, 255, 256) == 0 and f0(16, 2, 64, 256, 258) == 0
+    # workspace = the prepared narrow rows (bf16, two copies, A = H + 6 rows of W + 16) + one accumulator-order tile set per workgroup
+    # (256 workgroups where no device answers: 8 row blocks per image at N = 32)
+    narrow = 32 * 3 * (256 + 6) * 2 * (256 + 16) // 2
+    assert lib.ap_wgrad_k7_bf16_workspace_floats(32, 64, 3, 256, 256, 0) == narrow + 256 * 2 * 5 * 1024
+    assert lib.ap_conv_final_dgrad_bf16_workspace_floats(32, 64, 256, 256) == 32 * (256 + 12) * 2 * (256 + 16) // 2
+    assert lib.ap_wgrad_k7_bf16_workspace_floats(32, 64, 2, 256, 256, 0) < 0 and b'not served' in lib.ap_last_error()
+
+
 def test_planning_errors_are_reported():
     from animateportrait_amd import ops, _capi
     with pytest.raises(RuntimeError, match='stride'):
