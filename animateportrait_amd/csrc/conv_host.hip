@@ -950,15 +950,27 @@ static int conv2d_fwd_impl(const ap_conv_desc* d, const ap_out_view* view, const
         p.src.C = d->src[0].C; p.src.act = d->src[0].act;
         p.N = d->N; p.C = pl.Cin; p.H = d->H; p.W = d->W; p.OH = pl.Hout; p.OW = pl.Wout;
         p.w = packed + pl.head_w_off; p.bias = bias; p.act = d->act; p.y = y;
-        // rows per workgroup: the tallest band that still gives every CU a workgroup (N x bands >= ~200) -- with 10-row bands a
-        // B = 16 launch is 48 workgroups on 256 CUs (53 us for 50 MB); shorter bands re-read 3 halo rows each, which is cheap here
-        const int rb10 = d->N * ((pl.Hout + 9) / 10), rb5 = d->N * ((pl.Hout + 4) / 5);
-        if (rb10 >= 200)
-            hipLaunchKernelGGL(conv_head_fwd_kernel<10>, dim3(d->N, (pl.Hout + 9) / 10), dim3(1024), 0, (hipStream_t)stream, p);
-        else if (rb5 >= 200)
-            hipLaunchKernelGGL(conv_head_fwd_kernel<5>, dim3(d->N, (pl.Hout + 4) / 5), dim3(1024), 0, (hipStream_t)stream, p);
-        else
-            hipLaunchKernelGGL(conv_head_fwd_kernel<3>, dim3(d->N, (pl.Hout + 2) / 3), dim3(1024), 0, (hipStream_t)stream, p);
+        // Rows per workgroup.  The kernel is bound by its vector ALUs (normalisation, activation, three wave shifts and 16 FMAs per
+        // staged row element, on RB + 3 rows for RB outputs) and a launch is a few hundred 1024-thread workgroups: what counts is
+        // the number of workgroup ROUNDS on the CUs times the rows a workgroup stages.  (Round 6; before: 3-row bands unless taller
+        // ones still gave >= 200 workgroups -- 320 workgroups = two rounds at 2B = 32, 160 = 5/8 of the chip at B = 16.)
+        const int cus = num_cus();
+        int best = 3;
+        long long best_cost = -1;
+        for (int rb : {2, 3, 4, 5, 6, 10}) {
+            const long long wgs = (long long)d->N * ((pl.Hout + rb - 1) / rb);
+            const long long cost = ((wgs + cus - 1) / cus) * (rb + 3);
+            if (best_cost < 0 || cost < best_cost) { best = rb; best_cost = cost; }
+        }
+        const dim3 hg(d->N, (pl.Hout + best - 1) / best);
+        switch (best) {
+            case 2: hipLaunchKernelGGL(conv_head_fwd_kernel<2>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+            case 4: hipLaunchKernelGGL(conv_head_fwd_kernel<4>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+            case 5: hipLaunchKernelGGL(conv_head_fwd_kernel<5>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+            case 6: hipLaunchKernelGGL(conv_head_fwd_kernel<6>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+            case 10: hipLaunchKernelGGL(conv_head_fwd_kernel<10>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL(conv_head_fwd_kernel<3>, hg, dim3(1024), 0, (hipStream_t)stream, p); break;
+        }
         return check_launch("conv_head_fwd_kernel");
     }
     if (pl.small) {
