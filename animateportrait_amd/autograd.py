@@ -259,6 +259,11 @@ def conv_backward(tape, layer, srcs, out, norm, act):
                 tape.add(f, ops.final_dgrad_k7(gfeat, layer.weight), fold_pad)
                 c0 += c
                 continue
+            if len(srcs) == 1 and s.cout == 1 and ops.head_dgrad_ok(s, gfeat, f):
+                # the PatchGAN's output layer in plain-bf16 arithmetic: its 512-channel gradient as an output stream (dgrad_k7.h)
+                tape.add(f, ops.head_dgrad(gfeat, layer.weight, f.data.shape[2], f.data.shape[3]), fold_pad)
+                c0 += c
+                continue
             w = layer.weight.detach()
             if len(srcs) > 1:
                 w = w[c0:c0 + c] if s.transposed else w[:, c0:c0 + c]       # a view: the packer takes strides

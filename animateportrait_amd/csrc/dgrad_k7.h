@@ -154,4 +154,90 @@ static __global__ __launch_bounds__(512) void dgrad_k7_final_kernel(const DgradK
     }
 }
 
+
+// ---- data gradient of the PatchGAN's output layer, Conv2d(C, 1, 4, stride 1, pad 1) on a small map (networks.py:2643), plain bf16:
+//     gx[n][c][iy][ix] = sum_{ky, kx} w[0][c][ky][kx] * g[n][0][iy - ky + 1][ix - kx + 1]        (g: (H-1) x (W-1), zero outside)
+// One gradient channel against 512 outputs of 31 x 31: the fp32 matrix kernel (conv_igemm_f32<ConvCfg<2,1,4,..>>) took 32 us for
+// 31-94 MB of output.  Same form as dgrad_k7_final_kernel with K = (ky, kx) = 16 = ONE K-step: a workgroup owns 32 channels of
+// one image -- their planes are one contiguous 32 H W block of the output, which is assembled in LDS (lane = flat pixel) and
+// leaves as a linear copy: 20.5 us.  (16 channels per workgroup, two workgroups per CU: 23.9 us.)
+struct DgradHeadParams {
+    const float* g;           // [N][1][H-1][W-1]
+    const float* w;           // [C][4][4] = weight[0][c][ky][kx]
+    float* gx;                // [N][C][H][W]
+    int N, C, H, W;
+};
+
+static __global__ __launch_bounds__(256) void dgrad_head_kernel(const DgradHeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dh_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, HW = H * W, GH = H - 1, GW = W - 1;
+    const int cg = p.C >> 5, n = blockIdx.x / cg, c0 = (blockIdx.x - n * cg) * 32;
+    const int RP = W + 8, RPB = RP * 2, LR = H + 3;                 // staged row: element e <-> gradient column e - 2
+    float* const ob = reinterpret_cast<float*>(dh_smem);            // [32][HW]
+    unsigned short* const gt = reinterpret_cast<unsigned short*>(dh_smem + (size_t)32 * HW * 4);   // [LR][2 copies][RP]: row t <-> gradient row t - 2
+    // ---- the gradient map as zero-framed bf16 rows in two copies one element apart
+    // (all of a thread's loads first, from clamped addresses, then the stores)
+    const float* gsrc = p.g + (long long)n * GH * GW;
+    constexpr int NI = 7;                                           // ceil((34 + 3) * (34 + 8) / 256): H W <= 1156
+    float g0[NI], g1[NI];
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = tid + k * 256, ic = i < LR * RP ? i : 0;
+        const int t = ic / RP, e = ic - t * RP;
+        const int gy = t - 2, gx0 = e - 2;
+        const int gyc = gy < 0 ? 0 : (gy > GH - 1 ? GH - 1 : gy);
+        const int xa = gx0 < 0 ? 0 : (gx0 > GW - 1 ? GW - 1 : gx0), xb = gx0 - 1 < 0 ? 0 : (gx0 - 1 > GW - 1 ? GW - 1 : gx0 - 1);
+        g0[k] = gsrc[gyc * GW + xa];
+        g1[k] = gsrc[gyc * GW + xb];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) {
+        const int i = tid + k * 256;
+        if (i < LR * RP) {
+            const int t = i / RP, e = i - t * RP;
+            const int gy = t - 2, gx0 = e - 2;
+            const bool rowok = gy >= 0 && gy < GH;
+            const __bf16 v0 = (__bf16)((rowok && gx0 >= 0 && gx0 < GW) ? g0[k] : 0.f);
+            const __bf16 v1 = (__bf16)((rowok && gx0 - 1 >= 0 && gx0 - 1 < GW) ? g1[k] : 0.f);
+            gt[(t * 2) * RP + e] = __builtin_bit_cast(unsigned short, v0);        // copy 0: element e at position e
+            gt[(t * 2 + 1) * RP + e] = __builtin_bit_cast(unsigned short, v1);    // copy 1: element e - 1 at position e
+        }
+    }
+    // ---- weights: lane (c, half): k-slot j <-> (ky = 2 half + (j >> 2), kx = 3 - (j & 3))
+    k7_bf16x8 af;
+    {
+        const float* wr = p.w + (c0 + l32) * 16 + 8 * half;
+        const float4 a = reinterpret_cast<const float4*>(wr)[0], b = reinterpret_cast<const float4*>(wr)[1];
+        const uint4 pk = make_uint4(k7_pack(a.w, a.z), k7_pack(a.y, a.x), k7_pack(b.w, b.z), k7_pack(b.y, b.x));
+        af = __builtin_bit_cast(k7_bf16x8, pk);
+    }
+    __syncthreads();
+    const int NB = (HW + 31) >> 5;
+    for (int b = wave; b < NB; b += 4) {
+        const int f = b * 32 + l32, fc = f < HW ? f : HW - 1;
+        const int iy = fc / W, ix = fc - iy * W;
+        // tap row ky reads gradient row iy - ky + 1 = staged row iy + 3 - ky; its four columns ix - 2 .. ix + 1 = elements ix .. ix + 3
+        const int copy = ix & 1;
+        const unsigned* r0 = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(gt) + ((iy + 3 - 2 * half) * 2 + copy) * RPB + (ix + copy) * 2);
+        const unsigned* r1 = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(gt) + ((iy + 2 - 2 * half) * 2 + copy) * RPB + (ix + copy) * 2);
+        const uint4 w4 = make_uint4(r0[0], r0[1], r1[0], r1[1]);
+        const k7_bf16x8 bf = __builtin_bit_cast(k7_bf16x8, w4);
+        k7_f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+        if (f < HW) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[((r & 3) + 8 * (r >> 2) + 4 * half) * HW + f] = acc[r];
+        }
+    }
+    __syncthreads();
+    // ---- the 32 planes are one contiguous block of the output (32 H W floats, 16-byte aligned for C % 32 == 0)
+    float4* dst = reinterpret_cast<float4*>(p.gx + ((long long)n * p.C + c0) * HW);
+    const float4* src = reinterpret_cast<const float4*>(ob);
+    for (int i = tid; i < 8 * HW; i += 256) dst[i] = src[i];
+}
+
 }  // namespace apamd

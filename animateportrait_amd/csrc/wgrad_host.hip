@@ -758,6 +758,27 @@ int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t 
     return AP_OK;
 }
 
+// ---- data gradient of the PatchGAN's output layer (dgrad_k7.h: dgrad_head_kernel)
+int32_t ap_conv_head_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W) {
+    return (N >= 1 && C >= 32 && (C & 31) == 0 && H >= 2 && W >= 2 && H * W <= 1156 && (long long)N * (C / 32) < 2147483647LL) ? 1 : 0;
+}
+
+int ap_conv_head_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* gx, ap_stream_t stream_) {
+    if (!g || !w || !gx) return fail(AP_ERR_INVALID, "conv_head_dgrad_bf16: null pointer");
+    if (!ap_conv_head_dgrad_bf16_ok(N, C, H, W))
+        return fail(AP_ERR_UNSUPPORTED, "conv_head_dgrad_bf16: N=%d C=%d %dx%d not served (C a multiple of 32, H W <= 1156)", N, C, H, W);
+    DgradHeadParams p;
+    p.g = g; p.w = w; p.gx = gx; p.N = N; p.C = C; p.H = H; p.W = W;
+    const size_t lds = (size_t)32 * H * W * 4 + (size_t)(H + 3) * 2 * (W + 8) * 2;
+    const void* fn = reinterpret_cast<const void*>(&dgrad_head_kernel);
+    int rc = ensure_wattr(fn);
+    if (rc) return rc;
+    void* args[] = {&p};
+    hipError_t e = hipLaunchKernel(fn, dim3(N * (C / 32)), dim3(256), args, lds, (hipStream_t)stream_);
+    if (e != hipSuccess) return fail(AP_ERR_LAUNCH, "dgrad_head launch: %s", hipGetErrorString(e));
+    return AP_OK;
+}
+
 // ---- the PatchGAN's first layer as an output stream on the bf16 matrix pipe (conv_d0.h)
 int32_t ap_conv_d0_fwd_bf16_ok(int32_t N, int32_t Cin, int32_t Cout, int32_t H, int32_t W) {
     return (N >= 1 && (Cin == 1 || Cin == 2) && Cout == 64 && H >= 2 && (H & 1) == 0 && W >= 8 && W <= 256 && (W & 3) == 0) ? 1 : 0;

@@ -1239,6 +1239,29 @@ def final_dgrad_k7(g, weight):
     return gp
 
 
+def head_dgrad_ok(spec, g, f):
+    """Is the data gradient of this layer the PatchGAN output layer's, served on the bf16 matrix pipe (ap_conv_head_dgrad_bf16)?"""
+    n, m, gh, gw = g.data.shape
+    h, w = f.data.shape[2:]
+    return (D0_MFMA and DEFAULT_PRECISION == PRECISION_BF16 and spec.precision == PRECISION_BF16 and not spec.transposed and
+            spec.k == 4 and spec.stride == 1 and spec.pad == 1 and spec.pad_mode == PAD_ZERO and m == 1 and not g.virtual and
+            g.act == ACT_NONE and g.data.dtype == torch.float32 and (gh, gw) == (h - 1, w - 1) and
+            C.lib().ap_conv_head_dgrad_bf16_ok(n, f.data.shape[1], h, w) == 1)
+
+
+def head_dgrad(g, weight, h, w):
+    """Gradient w.r.t. the input of Conv2d(C, 1, 4, 1, 1): (N, C, h, w)."""
+    n = g.data.shape[0]
+    c = weight.shape[1]
+    _require_device(g.data, 'head dgrad gradient')
+    wt = weight.detach().contiguous()
+    gx = torch.empty((n, c, h, w), dtype=torch.float32, device=g.data.device)
+    if PROFILER is not None:
+        PROFILER.note('dgrad_head')
+    C.check(C.lib().ap_conv_head_dgrad_bf16(_ptr(g.data), _ptr(wt), n, c, h, w, _ptr(gx), _stream()), 'conv_head_dgrad_bf16')
+    return gx
+
+
 def k7_stem_wgrad_ok(spec, g_shape, srcs):
     """Does wgrad() serve this layer's weight gradient in the stem form of ap_wgrad_k7_bf16 (which also reads a bf16-stored gradient)?"""
     n, m, h, w = g_shape

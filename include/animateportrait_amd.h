@@ -391,6 +391,12 @@ int32_t ap_conv_final_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W);
 int64_t ap_conv_final_dgrad_bf16_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
 int ap_conv_final_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* workspace, float* gp,
                              ap_stream_t stream);
+/* Data gradient of the PatchGAN's output layer Conv2d(C, 1, 4, stride 1, pad 1) (networks.py:2643) in plain-bf16 arithmetic on the
+ * bf16 matrix pipe (csrc/dgrad_k7.h):  gx[n][c][iy][ix] = sum_{ky,kx} w[0][c][ky][kx] * g[n][0][iy-ky+1][ix-kx+1]  (g: [N][1][H-1][W-1],
+ * zero outside; w: the layer's weight [1][C][4][4]; gx: [N][C][H][W]).  Served: ap_conv_head_dgrad_bf16_ok() == 1 (C a multiple of 32,
+ * H W <= 1156). */
+int32_t ap_conv_head_dgrad_bf16_ok(int32_t N, int32_t C, int32_t H, int32_t W);
+int ap_conv_head_dgrad_bf16(const float* g, const float* w, int32_t N, int32_t C, int32_t H, int32_t W, float* gx, ap_stream_t stream);
 /* The PatchGAN's first layer, y = act(Conv2d(Cin = 1 | 2, 64, 4, stride 2, pad 1)(x) + bias) (networks.py:2620-2623), in plain-bf16
  * arithmetic on the bf16 matrix pipe as an output stream (csrc/conv_d0.h).  x: plain [N][Cin][H][W], w: the layer's weight
  * [64][Cin][4][4], bias [64] or NULL, act AP_ACT_NONE / RELU / LRELU, y [N][64][H/2][W/2].

@@ -506,3 +506,26 @@ def test_patchgan_first_layer_wgrad_on_the_matrix_pipe(dev, case):
     assert eex > 10 * e16, (case, e16, eex)
     dw2 = ops.wgrad(4, 2, 1, ops.PAD_ZERO, ops.Feat(gy.to(dev)), [ops.Feat(x.to(dev))], (64, cin, 4, 4), precision=ops.PRECISION_BF16)
     assert torch.equal(dw, dw2)
+
+
+@pytest.mark.parametrize('case', [(2, 512, 31, 31), (3, 64, 17, 30), (1, 32, 2, 2), (40, 96, 34, 34)], ids=lambda c: 'N%d C%d %dx%d' % c)
+def test_patchgan_output_layer_dgrad_on_the_matrix_pipe(dev, case):
+    """ap_conv_head_dgrad_bf16 (csrc/dgrad_k7.h: dgrad_head_kernel): the data gradient of Conv2d(C, 1, 4, 1, 1) (networks.py:2643) in
+    plain-bf16 arithmetic = fp32-accumulated sums of bf16(w) x bf16(g)."""
+    from animateportrait_amd import ops
+    n, c, H, W = case
+    gen = torch.Generator().manual_seed(31 + sum(case))
+    w = torch.randn(1, c, 4, 4, generator=gen) * 0.05
+    gy = torch.randn(n, 1, H - 1, W - 1, generator=gen)
+    gx = ops.head_dgrad(ops.Feat(gy.to(dev)), w.to(dev), H, W)
+    assert tuple(gx.shape) == (n, c, H, W)
+
+    def ref(wv, gv):
+        x = torch.zeros(n, c, H, W, dtype=torch.float64, requires_grad=True)
+        (F.conv2d(x, wv, padding=1) * gv).sum().backward()
+        return x.grad
+    ref16, exact = ref(r16(w), r16(gy)), ref(w.double(), gy.double())
+    sc = float(ref16.abs().max())
+    e16, eex = linf(gx, ref16) / sc, linf(gx, exact) / sc
+    assert e16 < 3e-5, (case, e16, eex)
+    assert eex > 10 * e16, (case, e16, eex)
