@@ -98,6 +98,8 @@ def test_edge_layer_routes_served_shapes_need_no_gpu():
     dg = lib.ap_conv_final_dgrad_bf16_ok
     assert dg(32, 64, 256, 256) == 1 and dg(1, 32, 4, 16) == 1
     assert dg(32, 48, 256, 256) == 0 and dg(32, 64, 256, 272) == 0 and dg(32, 64, 256, 24) == 0
+    hd = lib.ap_conv_head_dgrad_bf16_ok
+    assert hd(16, 512, 31, 31) == 1 and hd(1, 32, 2, 2) == 1 and hd(16, 500, 31, 31) == 0 and hd(16, 512, 35, 35) == 0
     f0 = lib.ap_conv_d0_fwd_bf16_ok
     assert f0(16, 2, 64, 256, 256) == 1 and f0(3, 1, 64, 18, 8) == 1
     assert f0(16, 3, 64, 256, 256) == 0 and f0(16, 2, 32, 256, 256) == 0 and f0(16, 2, 64, 255, 256) == 0 and f0(16, 2, 64, 256, 258) == 0
