@@ -149,6 +149,9 @@ SIGNATURES = {
     'ap_conv_head_dgrad_bf16_ok': (ctypes.c_int32, [ctypes.c_int32] * 4),
     'ap_conv_head_dgrad_bf16': (ctypes.c_int, [c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_f32p,
                                                ctypes.c_void_p]),
+    'ap_act_bwd_bias_workspace_floats': (ctypes.c_int64, [ctypes.c_int32] * 4),
+    'ap_act_bwd_bias': (ctypes.c_int, [c_f32p, ctypes.c_int32, c_f32p, c_f32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                       ctypes.c_int32, c_f32p, c_f32p, c_f32p, ctypes.c_void_p]),
     'ap_conv2d_wgrad_workspace_floats': (ctypes.c_int64, [ctypes.POINTER(ApWgradDesc)]),
     'ap_pad_materialize': (ctypes.c_int, [ctypes.POINTER(ApSrc), ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                           ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -207,7 +207,7 @@ def conv_backward(tape, layer, srcs, out, norm, act):
     if not contribs:
         return
     s = layer.spec
-    gt = strip = g_xs = None
+    gt = strip = g_xs = db = None
     plan = _split_backward_plan(tape, layer, srcs, out, contribs) if norm else None
     if plan is not None:
         # the gradient only feeds the bf16 matrix kernels: its producer writes their operands, no fp32 dy (ops.instnorm_bwd_split)
@@ -223,7 +223,13 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         # which rounds it to bf16 -- it is stored that way (ops.instnorm_bwd out_bf16)
         dy16 = (norm and layer.weight.requires_grad and not any(tape.tracked(f) for f in srcs) and
                 ops.k7_stem_wgrad_ok(s, tuple(out.data.shape), srcs))
-        dy = ops.instnorm_bwd(contribs, out, out_bf16=dy16) if norm else ops.act_bwd(contribs, out.data, act)
+        if norm:
+            dy = ops.instnorm_bwd(contribs, out, out_bf16=dy16)
+        elif layer.bias.requires_grad and act != ACT_NONE:
+            # a plain layer with an activation (the PatchGAN's first): the bias gradient's block sums are formed while dy is written
+            dy, db = ops.act_bwd_bias(contribs, out.data, act, tape.slot(layer.bias))
+        else:
+            dy = ops.act_bwd(contribs, out.data, act)
         gfeat = Feat(dy)
         # split-bf16 layers served by ap_conv2d_wgrad_xs (3x3, the PatchGAN's 4x4): the gradient's split copy -- which the data-gradient
         # convolution stages anyway (cached on the Feat) -- is the weight gradient's operand too: no operand preparation
@@ -247,7 +253,7 @@ def conv_backward(tape, layer, srcs, out, norm, act):
         if norm:
             tape.add_param(layer.bias, slot if slot is not None else torch.zeros_like(layer.bias))   # block is zero-filled
         else:
-            tape.add_param(layer.bias, ops.bias_grad(dy, out=slot))
+            tape.add_param(layer.bias, db if db is not None else ops.bias_grad(dy, out=slot))
     # ---- data gradients, one launch per input segment that needs one
     c0 = 0
     for i, f in enumerate(srcs):

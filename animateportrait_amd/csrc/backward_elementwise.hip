@@ -687,9 +687,15 @@ __global__ __launch_bounds__(1024) void instnorm_bwd_fused_big_kernel(const floa
 }
 
 // dy = (fold(g1) + g2) * act'(out): act 1 relu / 2 lrelu (sign of the ACTIVATED output) / 3 tanh (1 - out^2)
+// SUMS: the block's sum of dy goes to sums[(c * N + n) * gridDim.x + blockIdx.x] -- the partials bias_grad_final_kernel adds in fixed
+// order: the bias gradient of a layer without InstanceNorm (the PatchGAN's first layer: 64 x 128 x 128 per image) costs no second pass
+// over dy (round 6; bias_grad_partial_kernel re-read 1.1 GB per train step)
+template <bool SUMS>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g1, int p1, const float* __restrict__ g2,
                                                       const float* __restrict__ outv, int act, int H, int W,
-                                                      float* __restrict__ dy) {
+                                                      float* __restrict__ dy, float* __restrict__ sums = nullptr, int C = 1) {
+    __shared__ float sred[8];
+    float ssum = 0.f;
     const int nc = blockIdx.y;
     const int HW = H * W;
     FoldReader fr{g1 + (long long)nc * (H + 2 * p1) * (W + 2 * p1), H, W, p1, W + 2 * p1};
@@ -717,9 +723,9 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 }
             }
             reinterpret_cast<float4*>(out)[i] = gv;
+            if constexpr (SUMS) ssum += (gv.x + gv.y) + (gv.z + gv.w);
         }
-        return;
-    }
+    } else {
     // four elements per thread and trip, every load before the first store (one at a time this loop was four serial
     // memory round trips per thread: 150 us on the residual stream's 32 x 256 x 64 x 64 fold, 2.7 TB/s)
     for (int base = blockIdx.x * 1024; base < HW; base += gridDim.x * 1024) {
@@ -744,7 +750,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                 else if (act == 2) v = o[k] > 0.f ? v : 0.2f * v;
                 else if (act == 3) v *= 1.f - o[k] * o[k];
                 out[i] = v;
+                if constexpr (SUMS) ssum += v;
             }
+        }
+    }
+    }
+    if constexpr (SUMS) {
+        ssum = block_sum(ssum, sred);
+        if (threadIdx.x == 0) {
+            const int n = nc / C, c = nc - n * C, N = gridDim.y / C;
+            sums[((long long)c * N + n) * gridDim.x + blockIdx.x] = ssum;
         }
     }
 }
@@ -828,6 +843,17 @@ __global__ __launch_bounds__(64) void bias_grad_final_kernel(const float* __rest
     float s = 0.f;
     for (int i = 0; i < count; ++i) s += ws[(long long)c * count + i];
     db[c] = s;
+}
+
+// db[c] = sum of the count block sums act_bwd_kernel<true> left for channel c: lane t adds elements t, t + 64, ..., then the
+// lanes are added as a fixed tree
+__global__ __launch_bounds__(64) void bias_sums_final_kernel(const float* __restrict__ ws, int count, float* __restrict__ db) {
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < count; i += 64) s += ws[(long long)c * count + i];
+#pragma unroll
+    for (int sh = 32; sh >= 1; sh >>= 1) s += __shfl_xor(s, sh, 64);
+    if (threadIdx.x == 0) db[c] = s;
 }
 
 }  // namespace apamd
@@ -984,9 +1010,34 @@ int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* ou
                            g2, out, act, H, W, dy);
         return check_launch("act_bwd_fold1_kernel");
     }
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, out, act, H, W,
-                       dy);
+    hipLaunchKernelGGL(act_bwd_kernel<false>, dim3(bx, NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, out, act, H, W,
+                       dy, (float*)nullptr, 1);
     return check_launch("act_bwd_kernel");
+}
+
+// act_bwd + the bias gradient db[c] = sum_{n, y, x} dy of the same layer in one pass (workspace: ap_act_bwd_bias_workspace_floats)
+int64_t ap_act_bwd_bias_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W) {
+    if (N < 1 || C < 1 || H < 1 || W < 1) return fail(AP_ERR_INVALID, "act_bwd_bias: bad sizes");
+    int bx = (H * W + 1023) / 1024;
+    if (bx > 32) bx = 32;
+    return (int64_t)N * C * bx;
+}
+
+int ap_act_bwd_bias(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t N, int32_t C,
+                    int32_t H, int32_t W, float* dy, float* workspace, float* db, ap_stream_t stream) {
+    int rc = fold_args_ok(g1, g1_pad, H, W, "act_bwd_bias");
+    if (rc) return rc;
+    if (!dy || !workspace || !db || (act != AP_ACT_NONE && !out)) return fail(AP_ERR_INVALID, "act_bwd_bias: null pointer");
+    if (act < 0 || act > 3) return fail(AP_ERR_INVALID, "act_bwd_bias: act %d", act);
+    if (N < 1 || C < 1 || (long long)N * C > 65535) return fail(AP_ERR_UNSUPPORTED, "act_bwd_bias: N*C=%lld", (long long)N * C);
+    int bx = (H * W + 1023) / 1024;
+    if (bx > 32) bx = 32;
+    hipLaunchKernelGGL(act_bwd_kernel<true>, dim3(bx, N * C), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2, out, act, H, W, dy,
+                       workspace, C);
+    rc = check_launch("act_bwd_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bias_sums_final_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, workspace, N * bx, db);
+    return check_launch("bias_sums_final_kernel");
 }
 
 int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, ap_stream_t stream) {

@@ -1325,6 +1325,23 @@ def act_bwd(contribs, out, act):
     return dy
 
 
+def act_bwd_bias(contribs, out, act, db_out=None):
+    """act_bwd of a layer without InstanceNorm AND its bias gradient (sum of dy over n, y, x) in one pass: (dy, db).
+    Served for one plain-or-pad-1 contribution pattern that ap_act_bwd's general kernel takes; otherwise the two operators separately."""
+    g1, pad, g2 = _split_contribs(contribs)
+    g1, g2 = _as_fp32_grad(g1), _as_fp32_grad(g2)
+    n, c, h, w = out.shape
+    fused = not (pad == 1 and w % 4 == 0 and h >= 3 and w >= 4) and n * c <= 65535 and h * w >= 4096
+    if not fused:
+        dy = act_bwd(contribs, out, act)
+        return dy, bias_grad(dy, out=db_out)
+    dy = torch.empty_like(out)
+    db = _grad_out(db_out, (c,), out.device)
+    ws = torch.empty(C.check(C.lib().ap_act_bwd_bias_workspace_floats(n, c, h, w), 'act_bwd_bias_ws'), dtype=torch.float32, device=out.device)
+    C.check(C.lib().ap_act_bwd_bias(_ptr(g1), pad, _ptr(g2), _ptr(out), act, n, c, h, w, _ptr(dy), _ptr(ws), _ptr(db), _stream()), 'act_bwd_bias')
+    return dy, db
+
+
 def bias_grad(dy, out=None):
     n, c, h, w = dy.shape
     db = _grad_out(out, (c,), dy.device)

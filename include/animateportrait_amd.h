@@ -459,6 +459,11 @@ int ap_conv2d_wgrad_xs(const ap_wgrad_desc* d, const void* g_xs, float* workspac
  * (out may then be NULL).  AP_ACT_TANH: 1 - out^2; RELU / LRELU: from the sign of the activated output. */
 int ap_act_bwd(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t NC,
                int32_t H, int32_t W, float* dy, ap_stream_t stream);
+/* ap_act_bwd of a layer WITHOUT InstanceNorm together with its bias gradient db[c] = sum_{n,y,x} dy[n][c][y][x] (fixed summation order):
+ * the block sums of dy are formed while it is written, no second pass over it.  workspace: ap_act_bwd_bias_workspace_floats() floats. */
+int64_t ap_act_bwd_bias_workspace_floats(int32_t N, int32_t C, int32_t H, int32_t W);
+int ap_act_bwd_bias(const float* g1, int32_t g1_pad, const float* g2, const float* out, int32_t act, int32_t N, int32_t C,
+                    int32_t H, int32_t W, float* dy, float* workspace, float* db, ap_stream_t stream);
 /* db[c] = sum over n and pixels of dy (layers whose bias is live) */
 int ap_bias_grad(const float* dy, int32_t N, int32_t C, int32_t HW, float* db, ap_stream_t stream);
 /* the same sum in two stages (parallel over n and slices of the plane, then a fixed-order add): the form to use when

@@ -1477,3 +1477,26 @@ def test_residual_stream_as_split_copies(dev):
     ya, yb = unsplit(a), unsplit(b)
     assert linf(yb, b.data) <= 2 ** -16 * float(b.data.abs().max())
     assert linf(ya, yb) <= 3e-5 * float(yb.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [(3, 64, 128, 128, 2, 0), (2, 8, 64, 80, 1, 0), (2, 16, 66, 66, 2, 1), (1, 5, 70, 61, 3, 0)],
+                         ids=lambda c: 'N%d C%d %dx%d act%d pad%d' % c)
+def test_act_bwd_with_the_bias_gradient_in_one_pass(dev, case):
+    """ap_act_bwd_bias: dy of a layer without InstanceNorm and db[c] = sum dy in one pass (the PatchGAN's first layer,
+    networks.py:2620-2623: autograd's LeakyReLU backward + the bias gradient of the convolution in front of it)."""
+    from animateportrait_amd import ops
+    n, c, h, w, act, pad = case
+    gen = torch.Generator().manual_seed(41 + sum(case))
+    out = torch.randn(n, c, h, w, generator=gen)
+    if act == 3:
+        out = torch.tanh(out)
+    g1 = torch.randn(n, c, h + 2 * pad, w + 2 * pad, generator=gen)
+    g2 = torch.randn(n, c, h, w, generator=gen)
+    contribs = [(g1.to(dev), pad), (g2.to(dev), 0)]
+    dy_ref = ops.act_bwd(contribs, out.to(dev), act)
+    dy, db = ops.act_bwd_bias(contribs, out.to(dev), act)
+    assert torch.equal(dy, dy_ref)
+    ref = dy_ref.double().sum((0, 2, 3))
+    assert linf(db, ref) <= 2e-6 * float(dy_ref.double().abs().sum((0, 2, 3)).max())
+    assert torch.equal(db, ops.act_bwd_bias(contribs, out.to(dev), act)[1])          # fixed summation order
