@@ -312,6 +312,62 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_fused_kernel(const float* __r
     }
 }
 
+// The same for an unfolded gradient with H W % 4 == 0 (every launch of the train step that is not on the operand-writing route),
+// with the load-phase rule applied (section 3.5 of DESIGN.md): all 16-byte loads of a thread -- y, g1 and, as a template parameter,
+// g2 -- are issued from clamped indices before any arithmetic.  (In the general kernel above the `i < HW / 4` test, the fold test and
+// the `g2 != nullptr` test sit between the loads: 8-12 dependent round trips per thread, 3.9 TB/s.)
+template <int NT, int EPT, bool G2>
+__global__ __launch_bounds__(NT) void instnorm_bwd_fused_vec_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                    const float* __restrict__ y, const float* __restrict__ mean,
+                                                                    const float* __restrict__ rstd, int act, int HW,
+                                                                    float* __restrict__ dy) {
+    __shared__ float red[NT / 64];
+    constexpr int NG = EPT / 4;
+    const int nc = blockIdx.x, tid = threadIdx.x, Q = HW >> 2;
+    const float4* y4 = reinterpret_cast<const float4*>(y + (long long)nc * HW);
+    const float4* ga = reinterpret_cast<const float4*>(g1 + (long long)nc * HW);
+    const float4* gb = reinterpret_cast<const float4*>((G2 ? g2 : g1) + (long long)nc * HW);
+    float4 yv[NG], gq[NG], gr[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = k * NT + tid, ic = i < Q ? i : Q - 1;
+        yv[k] = y4[ic];
+        gq[k] = ga[ic];
+        if constexpr (G2) gr[k] = gb[ic];
+    }
+    const float m = mean[nc], r = rstd[nc];
+    float gv[EPT], xh[EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const bool in = k * NT + tid < Q;
+        const float yy[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
+        float gg[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w};
+        if constexpr (G2) { gg[0] += gr[k].x; gg[1] += gr[k].y; gg[2] += gr[k].z; gg[3] += gr[k].w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = in ? (yy[j] - m) * r : 0.f;
+            const float g = in ? gg[j] * act_grad_from_xhat(x, act) : 0.f;
+            xh[k * 4 + j] = x;
+            gv[k * 4 + j] = g;
+            s1 += g;
+            s2 += g * x;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float inv = 1.f / (float)HW;
+    const float a1 = s1 * inv, a2 = s2 * inv;
+    float4* o4 = reinterpret_cast<float4*>(dy + (long long)nc * HW);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = k * NT + tid;
+        if (i < Q)
+            o4[i] = make_float4(r * (gv[k * 4] - a1 - xh[k * 4] * a2), r * (gv[k * 4 + 1] - a1 - xh[k * 4 + 1] * a2),
+                                r * (gv[k * 4 + 2] - a1 - xh[k * 4 + 2] * a2), r * (gv[k * 4 + 3] - a1 - xh[k * 4 + 3] * a2));
+    }
+}
+
 // ---- instnorm_bwd_split: the InstanceNorm backward of a layer whose gradient goes straight into the bf16 matrix kernels.
 // The fp32 gradient dy of such a layer was written once (4 B / element) and read twice -- by the split pass in front of the
 // data-gradient convolution and by the transposition in front of the weight gradient -- to be rounded to bf16 head (+ tail)
@@ -881,14 +937,19 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
     if (ob16 && !(g1_pad == 0 && H * W > 16384 && H * W <= 65536 && (W % 4) == 0))
         return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: a bf16 dy is written by the big-plane kernel only (%dx%d, fold %d)", H, W, g1_pad);
     constexpr bool fused_ok = true;
+    const bool plain_vec = g1_pad == 0 && ((H * W) & 3) == 0;     // unfolded gradient, whole 16-byte groups: the load-phase form
     if (fused_ok && H * W <= 4096) {
-        hipLaunchKernelGGL((instnorm_bwd_fused_kernel<256, 16>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2,
-                           y, mean, rstd, act, H, W, dy);
+        if (plain_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<256, 16, true>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else if (plain_vec) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<256, 16, false>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<256, 16>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2,
+                                y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
     }
     if (fused_ok && H * W <= 16384) {
-        hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1024, 16>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g1_pad,
-                           g2, y, mean, rstd, act, H, W, dy);
+        if (plain_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<1024, 16, true>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else if (plain_vec) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<1024, 16, false>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1024, 16>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g1_pad,
+                                g2, y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
     }
     if (fused_ok && H * W <= 65536 && (W % 4) == 0 && W >= 4) {
