@@ -368,6 +368,134 @@ __global__ __launch_bounds__(NT) void instnorm_bwd_fused_vec_kernel(const float*
     }
 }
 
+// ... and for the gradient of a pad-1 reflection-padded consumer (g1: (H + 2) x (W + 2) planes, W % 4 == 0, H >= 3): the padded row's
+// 16 bytes and ONE edge dword (padded column 0 or W + 1, whichever this group could need) are loaded unconditionally with y and g2; the
+// reflected ROWS 0 and H + 1 belong to the groups of rows 1 and H - 2 only and are added in a second phase that a wave enters only if
+// it holds such a group (as instnorm_bwd_split_kernel does).
+template <int NT, int EPT, bool G2>
+__global__ __launch_bounds__(NT) void instnorm_bwd_fused_fold1_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                      const float* __restrict__ y, const float* __restrict__ mean,
+                                                                      const float* __restrict__ rstd, int act, int H, int W,
+                                                                      float* __restrict__ dy) {
+    __shared__ float red[NT / 64];
+    constexpr int NG = EPT / 4;
+    const int nc = blockIdx.x, tid = threadIdx.x, HW = H * W, Q = HW >> 2, W4 = W >> 2;
+    const float4* y4 = reinterpret_cast<const float4*>(y + (long long)nc * HW);
+    const float* gp = g1 + (long long)nc * (H + 2) * (W + 2);
+    const float4* gb = reinterpret_cast<const float4*>((G2 ? g2 : y) + (long long)nc * HW);
+    float4 yv[NG], gr[NG];
+    float4u gm[NG];
+    float ge[NG];
+    int gy[NG], gx[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = k * NT + tid, ic = i < Q ? i : Q - 1;
+        gy[k] = ic / W4;
+        gx[k] = (ic - gy[k] * W4) * 4;
+        const float* rp = gp + (gy[k] + 1) * (W + 2);
+        gm[k] = *reinterpret_cast<const float4u*>(rp + gx[k] + 1);
+        ge[k] = rp[gx[k] == 0 ? 0 : W + 1];
+        yv[k] = y4[ic];
+        if constexpr (G2) gr[k] = gb[ic];
+    }
+    const float m = mean[nc], r = rstd[nc];
+    float4 gq[NG];
+    bool border = false;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        gq[k] = make_float4(gm[k].x, gm[k].y, gm[k].z, gm[k].w);
+        if (gx[k] == 0) gq[k].y += ge[k];                 // padded column 0 is the reflection of column 1
+        if (gx[k] == W - 4) gq[k].z += ge[k];             // padded column W + 1 is the reflection of column W - 2
+        border = border || gy[k] == 1 || gy[k] == H - 2;
+    }
+    if (__builtin_amdgcn_ballot_w64(border) != 0) {       // wave-uniform: this wave holds groups of row 1 or row H - 2
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            if (gy[k] == 1) { const float4 t = fold1_row4(gp, W, 0, gx[k]); gq[k].x += t.x; gq[k].y += t.y; gq[k].z += t.z; gq[k].w += t.w; }
+            if (gy[k] == H - 2) { const float4 t = fold1_row4(gp, W, H + 1, gx[k]); gq[k].x += t.x; gq[k].y += t.y; gq[k].z += t.z; gq[k].w += t.w; }
+        }
+    }
+    float gv[EPT], xh[EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const bool in = k * NT + tid < Q;
+        const float yy[4] = {yv[k].x, yv[k].y, yv[k].z, yv[k].w};
+        float gg[4] = {gq[k].x, gq[k].y, gq[k].z, gq[k].w};
+        if constexpr (G2) { gg[0] += gr[k].x; gg[1] += gr[k].y; gg[2] += gr[k].z; gg[3] += gr[k].w; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float x = in ? (yy[j] - m) * r : 0.f;
+            const float g = in ? gg[j] * act_grad_from_xhat(x, act) : 0.f;
+            xh[k * 4 + j] = x;
+            gv[k * 4 + j] = g;
+            s1 += g;
+            s2 += g * x;
+        }
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float inv = 1.f / (float)HW;
+    const float a1 = s1 * inv, a2 = s2 * inv;
+    float4* o4 = reinterpret_cast<float4*>(dy + (long long)nc * HW);
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = k * NT + tid;
+        if (i < Q)
+            o4[i] = make_float4(r * (gv[k * 4] - a1 - xh[k * 4] * a2), r * (gv[k * 4 + 1] - a1 - xh[k * 4 + 1] * a2),
+                                r * (gv[k * 4 + 2] - a1 - xh[k * 4 + 2] * a2), r * (gv[k * 4 + 3] - a1 - xh[k * 4 + 3] * a2));
+    }
+}
+
+// ... and for small planes of any size with an unfolded gradient (the PatchGAN's 31 x 31 maps: H W = 961 is odd, so the general
+// kernel took its element-wise path -- 16 predicated iterations with the loads behind their tests): four elements per thread, every
+// load from a clamped index first.
+template <bool G2>
+__global__ __launch_bounds__(256) void instnorm_bwd_fused_small_kernel(const float* __restrict__ g1, const float* __restrict__ g2,
+                                                                       const float* __restrict__ y, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, int act, int HW,
+                                                                       float* __restrict__ dy) {
+    __shared__ float red[4];
+    constexpr int EPT = 4;
+    const int nc = blockIdx.x, tid = threadIdx.x;
+    const float* yp = y + (long long)nc * HW;
+    const float* ga = g1 + (long long)nc * HW;
+    const float* gb = (G2 ? g2 : g1) + (long long)nc * HW;
+    float yv[EPT], gq[EPT], gr[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = k * 256 + tid, ic = i < HW ? i : HW - 1;
+        yv[k] = yp[ic];
+        gq[k] = ga[ic];
+        if constexpr (G2) gr[k] = gb[ic];
+    }
+    const float m = mean[nc], r = rstd[nc];
+    float gv[EPT], xh[EPT];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const bool in = k * 256 + tid < HW;
+        const float x = in ? (yv[k] - m) * r : 0.f;
+        float g = gq[k];
+        if constexpr (G2) g += gr[k];
+        g = in ? g * act_grad_from_xhat(x, act) : 0.f;
+        xh[k] = x;
+        gv[k] = g;
+        s1 += g;
+        s2 += g * x;
+    }
+    s1 = block_sum(s1, red);
+    s2 = block_sum(s2, red);
+    const float inv = 1.f / (float)HW;
+    const float a1 = s1 * inv, a2 = s2 * inv;
+    float* out = dy + (long long)nc * HW;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int i = k * 256 + tid;
+        if (i < HW) out[i] = r * (gv[k] - a1 - xh[k] * a2);
+    }
+}
+
 // ---- instnorm_bwd_split: the InstanceNorm backward of a layer whose gradient goes straight into the bf16 matrix kernels.
 // The fp32 gradient dy of such a layer was written once (4 B / element) and read twice -- by the split pass in front of the
 // data-gradient convolution and by the transposition in front of the weight gradient -- to be rounded to bf16 head (+ tail)
@@ -938,9 +1066,17 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
         return fail(AP_ERR_UNSUPPORTED, "instnorm_bwd: a bf16 dy is written by the big-plane kernel only (%dx%d, fold %d)", H, W, g1_pad);
     constexpr bool fused_ok = true;
     const bool plain_vec = g1_pad == 0 && ((H * W) & 3) == 0;     // unfolded gradient, whole 16-byte groups: the load-phase form
+    const bool fold1_vec = g1_pad == 1 && (W & 3) == 0 && H >= 3 && W >= 8;   // pad-1 fold, the same
+    if (fused_ok && g1_pad == 0 && H * W <= 1024 && ((H * W) & 3) != 0) {      // small planes that are not whole 16-byte groups
+        if (g2) hipLaunchKernelGGL(instnorm_bwd_fused_small_kernel<true>, dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else hipLaunchKernelGGL(instnorm_bwd_fused_small_kernel<false>, dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        return check_launch("instnorm_bwd_fused_small_kernel");
+    }
     if (fused_ok && H * W <= 4096) {
         if (plain_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<256, 16, true>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
         else if (plain_vec) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<256, 16, false>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else if (fold1_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_fold1_kernel<256, 16, true>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H, W, dy);
+        else if (fold1_vec) hipLaunchKernelGGL((instnorm_bwd_fused_fold1_kernel<256, 16, false>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H, W, dy);
         else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<256, 16>), dim3(NC), dim3(256), 0, (hipStream_t)stream, g1, g1_pad, g2,
                                 y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
@@ -948,6 +1084,8 @@ int ap_instnorm_bwd(const float* g1, int32_t g1_pad, const float* g2, const floa
     if (fused_ok && H * W <= 16384) {
         if (plain_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<1024, 16, true>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
         else if (plain_vec) hipLaunchKernelGGL((instnorm_bwd_fused_vec_kernel<1024, 16, false>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H * W, dy);
+        else if (fold1_vec && g2) hipLaunchKernelGGL((instnorm_bwd_fused_fold1_kernel<1024, 16, true>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H, W, dy);
+        else if (fold1_vec) hipLaunchKernelGGL((instnorm_bwd_fused_fold1_kernel<1024, 16, false>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g2, y, mean, rstd, act, H, W, dy);
         else hipLaunchKernelGGL((instnorm_bwd_fused_kernel<1024, 16>), dim3(NC), dim3(1024), 0, (hipStream_t)stream, g1, g1_pad,
                                 g2, y, mean, rstd, act, H, W, dy);
         return check_launch("instnorm_bwd_fused_kernel");
